@@ -1,0 +1,769 @@
+/*
+ * oracle/llz_oracle.c -- CPU restatement of the libllzfilter hot path.  TEST INFRASTRUCTURE ONLY
+ * (see llz_oracle.h: never linked into, imported by or called from the product).
+ *
+ * Parity: PINNED bit-for-bit against the compiled reference (oracle/_ref) and tests/golden/.
+ * Build with -O2 -ffp-contract=off (the reference's default build has no FMA contraction on x86-64).
+ *
+ * Expression trees in the design functions are kept in the reference's association order on purpose:
+ * the taps feed bit-exact comparisons, and double arithmetic is not associative.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "llz_oracle.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------ windows (llz_fir.c:61-158) */
+
+int orc_hamming(double *w, int n)
+{
+    /* llz_fir.c:61-71: filled from both ends, i <= j */
+    for (int i = 0, j = n - 1; i <= j; i++, j--)
+        w[j] = w[i] = 0.54 - 0.46 * cos(2 * M_PI * i / (n - 1));
+    return n;
+}
+
+int orc_blackman(double *w, int n)
+{
+    /* llz_fir.c:73-83 */
+    for (int i = 0, j = n - 1; i <= j; i++, j--)
+        w[j] = w[i] = 0.42 - 0.5 * cos(2 * M_PI * i / (n - 1)) + 0.08 * cos(4 * M_PI * i / (n - 1));
+    return n;
+}
+
+/* modified Bessel I0 by its power series, stop when the term drops under 1e-16 * sum (llz_fir.c:85-103) */
+static double bessel_i0(double x)
+{
+    double half = 0.5 * x, sum = 1.0, p = 1.0, term = 1.0;
+    int k = 0;
+    while (term > sum * 1E-16) {
+        ++k;
+        p = p * (half / k);
+        term = p * p;
+        sum = sum + term;
+    }
+    return sum;
+}
+
+int orc_kaiser_beta(double *w, int n, double beta)
+{
+    /* llz_fir.c:141-158: no symmetry trick, every point evaluated */
+    double denom = bessel_i0(beta);
+    for (int i = 0; i < n; i++) {
+        double x = (2. * i / (n - 1)) - 1;
+        w[i] = bessel_i0(beta * sqrt(1. - x * x)) / denom;
+    }
+    return n;
+}
+
+int orc_kaiser(double *w, int n)
+{
+    return orc_kaiser_beta(w, n, 8.96); /* llz_fir.c:121-139, beta fixed */
+}
+
+double orc_kaiser_atten2beta(double atten)
+{
+    /* llz_fir.c:105-118 */
+    if (atten <= 21.)
+        return 0.;
+    if (atten < 50.)
+        return 0.5842 * pow(atten - 21., 0.4) + 0.07886 * (atten - 21.);
+    return 0.1102 * (atten - 8.7);
+}
+
+int orc_hamming_cof_num(double ftrans)  { return (int)(6.2 / ftrans); }   /* llz_fir.c:173-176 */
+int orc_blackman_cof_num(double ftrans) { return (int)(6.6 / ftrans); }   /* llz_fir.c:178-181 */
+
+int orc_kaiser_cof_num(double ftrans, double atten)
+{
+    /* llz_fir.c:183-193 */
+    if (atten <= 21.)
+        return (int)((0.9222 * 2.) / ftrans);
+    return (int)(((atten - 7.95) * 2.) / (14.36 * ftrans));
+}
+
+/* ------------------------------------------------------------------ tap design (llz_fir.c:39-59, 201-393) */
+
+static double sinc_pi(double x)
+{
+    /* llz_fir.c:39-59: 1 at 0, exactly 0 at the other integers, else sin(pi*fmod(x,2))/(pi*x) */
+    if (x == 0.0)
+        return 1.0;
+    if (x == floor(x))
+        return 0.0;
+    return sin(M_PI * fmod(x, 2.0)) / (M_PI * x);
+}
+
+static void make_window(double *w, int n, int win)
+{
+    switch (win) {
+    case ORC_HAMMING:  orc_hamming(w, n);  break;
+    case ORC_BLACKMAN: orc_blackman(w, n); break;
+    case ORC_KAISER:   orc_kaiser(w, n);   break;
+    default: for (int i = 0; i < n; i++) w[i] = 0.0; break; /* reference leaves w uninitialised */
+    }
+}
+
+int orc_fir_design(int kind, double *h, int n, double fc1, double fc2, int win)
+{
+    if (kind != ORC_LPF && !(n & 1))
+        n = n + 1;                                   /* llz_fir.c:305-307, 337-339, 369-371 */
+    double *w = (double *)malloc(sizeof(double) * (size_t)n);
+    make_window(w, n, win);
+
+    if (kind == ORC_LPF) {
+        /* llz_fir.c:201-215: real-valued delay, even n allowed */
+        double delay = (double)(n - 1) / 2;
+        for (int i = 0, j = n - 1; i <= delay; i++, j--)
+            h[j] = h[i] = fc1 * sinc_pi(fc1 * (i - delay)) * w[i];
+    } else {
+        int delay = (n - 1) / 2;
+        for (int i = 0, j = n - 1; i <= delay; i++, j--) {
+            double v;
+            if (kind == ORC_HPF)                     /* llz_fir.c:225-228 */
+                v = -fc1 * sinc_pi(fc1 * (i - delay)) * w[i];
+            else if (kind == ORC_BPF)                /* llz_fir.c:243-246 */
+                v = (fc2 * sinc_pi(fc2 * (i - delay)) - fc1 * sinc_pi(fc1 * (i - delay))) * w[i];
+            else                                     /* llz_fir.c:261-264 */
+                v = -(fc2 * sinc_pi(fc2 * (i - delay)) - fc1 * sinc_pi(fc1 * (i - delay))) * w[i];
+            h[j] = h[i] = v;
+        }
+        if (kind == ORC_HPF)      h[delay] = 1 - fc1;            /* :229 */
+        else if (kind == ORC_BPF) h[delay] = fc2 - fc1;          /* :247 */
+        else                      h[delay] = 1 - (fc2 - fc1);    /* :265 */
+    }
+    free(w);
+    return n;
+}
+
+/* ------------------------------------------------------------------ streaming FIR (llz_fir.c:411-625) */
+
+double orc_conv(const double *x, const double *h, int h_len)
+{
+    /* llz_fir.c:411-426: y = sum_i h[i]*x[n-i], i ascending, plain multiply then add */
+    double y = 0.0;
+    for (int i = 0; i < h_len; i++)
+        y += h[i] * x[-i];
+    return y;
+}
+
+typedef struct {
+    int flt_len, frame_len, buf_len, alloc_len;
+    double *h, *buf;
+} orc_fir_t;
+
+static void *fir_finish(orc_fir_t *f, int frame_len)
+{
+    f->frame_len = frame_len;
+    f->buf_len = f->flt_len + frame_len - 1;                     /* llz_fir.c:457 */
+    /* the reference's flush reads up to buf[2*flt_len-3] (llz_fir.c:611-622) which overruns buf_len when
+     * flt_len-2 >= frame_len; the restatement owns enough zeroed storage for that read to be defined */
+    f->alloc_len = f->buf_len;
+    if (f->alloc_len < 2 * f->flt_len) f->alloc_len = 2 * f->flt_len;
+    f->buf = (double *)calloc((size_t)f->alloc_len, sizeof(double));
+    return f;
+}
+
+void *orc_fir_new(int kind, int frame_len, int flt_len, double fc1, double fc2, int win)
+{
+    orc_fir_t *f = (orc_fir_t *)calloc(1, sizeof(*f));
+    f->h = (double *)malloc(sizeof(double) * (size_t)(flt_len + 1));
+    f->flt_len = orc_fir_design(kind, f->h, flt_len, fc1, fc2, win);   /* stored length = returned length */
+    return fir_finish(f, frame_len);
+}
+
+void *orc_fir_new_taps(int frame_len, const double *h, int flt_len)
+{
+    orc_fir_t *f = (orc_fir_t *)calloc(1, sizeof(*f));
+    f->h = (double *)malloc(sizeof(double) * (size_t)flt_len);
+    memcpy(f->h, h, sizeof(double) * (size_t)flt_len);
+    f->flt_len = flt_len;
+    return fir_finish(f, frame_len);
+}
+
+int orc_fir_flt_len(void *p) { return ((orc_fir_t *)p)->flt_len; }
+const double *orc_fir_taps(void *p) { return ((orc_fir_t *)p)->h; }
+
+int orc_fir_run(void *p, const double *in, double *out, int frame_len)
+{
+    orc_fir_t *f = (orc_fir_t *)p;
+    if (frame_len > f->frame_len)
+        return -1;                                   /* reference: assert (llz_fir.c:559) */
+    int hist = f->flt_len - 1;
+    /* llz_fir.c:562-566: the tail is taken from the INIT frame length's offset, so the
+     * state machine is only a correct streaming filter when every call uses the init frame length */
+    int from = f->buf_len - f->flt_len + 1;
+    for (int i = 0; i < hist; i++)
+        f->buf[i] = f->buf[from + i];
+    for (int i = 0; i < frame_len; i++)
+        f->buf[hist + i] = in[i];
+    for (int i = 0; i < frame_len; i++)
+        out[i] = orc_conv(f->buf + hist + i, f->h, f->flt_len);
+    return frame_len;
+}
+
+int orc_fir_flush(void *p, double *out)
+{
+    orc_fir_t *f = (orc_fir_t *)p;
+    int hist = f->flt_len - 1;
+    int from = f->buf_len - f->flt_len + 1;          /* llz_fir.c:605-609 */
+    for (int i = 0; i < hist; i++)
+        f->buf[i] = f->buf[from + i];
+    for (int i = 0; i < f->frame_len; i++)
+        f->buf[hist + i] = 0;
+    for (int i = 0; i < hist; i++)                   /* llz_fir.c:612-622 */
+        out[i] = orc_conv(f->buf + hist + i, f->h, f->flt_len);
+    return hist;
+}
+
+void orc_fir_free(void *p)
+{
+    orc_fir_t *f = (orc_fir_t *)p;
+    if (!f) return;
+    free(f->h); free(f->buf); free(f);
+}
+
+/* ------------------------------------------------------------------ IIR (llz_iir.c:37-156) */
+
+typedef struct {
+    int M, N;
+    double *a, *b, *x, *y;
+} orc_iir_t;
+
+void *orc_iir_new(int M, const double *a, int N, const double *b)
+{
+    orc_iir_t *f = (orc_iir_t *)calloc(1, sizeof(*f));
+    f->M = M; f->N = N;
+    f->a = (double *)calloc((size_t)M + 1, sizeof(double));
+    f->b = (double *)calloc((size_t)N + 1, sizeof(double));
+    f->x = (double *)calloc((size_t)N + 1, sizeof(double));
+    f->y = (double *)calloc((size_t)M + 1, sizeof(double));
+    for (int i = 0; i <= M; i++) f->a[i] = a[i];
+    if (b) for (int i = 0; i <= N; i++) f->b[i] = b[i];          /* b == NULL -> zeros (llz_iir.c:54-59) */
+    return f;
+}
+
+static double iir_step(orc_iir_t *f, double x_in)
+{
+    /* llz_iir.c:103-132: shift both delay lines, feed-forward sum first, then subtract the feedback
+     * terms one by one; a[0] never used */
+    int N = f->N, M = f->M;
+    for (int i = 0; i < N; i++) f->x[i] = f->x[i + 1];
+    f->x[N] = x_in;
+    for (int i = 0; i < M; i++) f->y[i] = f->y[i + 1];
+    double acc = 0.;
+    for (int k = 0; k <= N; k++) acc += f->b[k] * f->x[N - k];
+    for (int k = 1; k <= M; k++) acc -= f->a[k] * f->y[M - k];
+    f->y[M] = acc;
+    return acc;
+}
+
+int orc_iir_run(void *p, const double *x, double *y, int frame_len)
+{
+    for (int i = 0; i < frame_len; i++)
+        y[i] = iir_step((orc_iir_t *)p, x[i]);
+    return frame_len;
+}
+
+int orc_iir_flush(void *p, double *y)
+{
+    orc_iir_t *f = (orc_iir_t *)p;
+    for (int i = 0; i < f->N; i++)                   /* llz_iir.c:147-156 */
+        y[i] = iir_step(f, 0.0);
+    return f->N;
+}
+
+void orc_iir_free(void *p)
+{
+    orc_iir_t *f = (orc_iir_t *)p;
+    if (!f) return;
+    free(f->a); free(f->b); free(f->x); free(f->y); free(f);
+}
+
+/* ------------------------------------------------------------------ resample family (llz_resample.c) */
+
+typedef struct {
+    int mode;            /* 0 decimate, 1 interp, 2 rational */
+    int L, M;
+    int n;               /* prototype taps */
+    int rows, cols;      /* coefficient matrix shape */
+    double *h;           /* prototype */
+    double *mat;         /* rows x cols */
+    double gain;         /* output gain applied per sample */
+    int num_in, num_out;
+    long long out_index;
+    int hist;            /* samples of history kept in front of the frame */
+    short *buf;          /* hist + num_in */
+} orc_rs_t;
+
+static int igcd(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+static int proto_len_estimate(double ftrans, int win)
+{
+    switch (win) {                                   /* llz_resample.c:135-148 / 204-215 */
+    case ORC_HAMMING:  return orc_hamming_cof_num(ftrans);
+    case ORC_BLACKMAN: return orc_blackman_cof_num(ftrans);
+    case ORC_KAISER:   return orc_kaiser_cof_num(ftrans, 90);
+    }
+    return 0;
+}
+
+/* shared by polyphase_filter_init (llz_resample.c:124-176) and timevary_filter_init (:193-255):
+ * phases = m (polyphase) or L (time-varying); step = phase index multiplier (1 for polyphase: h[m*j+i];
+ * M for time-varying: h[j*L + (i*M)%L]) */
+static void build_matrix(orc_rs_t *r, int phases, int step_M, double fc, double mgain, int win)
+{
+    if (mgain == 0) mgain = 1.0;
+    int n0 = proto_len_estimate(0.15 * fc, win);
+    int half = n0 / (2 * phases);
+    r->n = 2 * half * phases + 1;
+    r->rows = phases;
+    r->cols = r->n / phases + 1;
+    r->h = (double *)malloc(sizeof(double) * (size_t)(r->n + 1));
+    orc_fir_design(ORC_LPF, r->h, r->n, fc, 0.0, win);
+    r->mat = (double *)calloc((size_t)r->rows * r->cols, sizeof(double));
+    for (int i = 0; i < r->rows; i++)
+        for (int j = 0; j < r->cols; j++) {
+            int u = j * phases + (step_M ? (i * step_M) % phases : i);
+            r->mat[(size_t)i * r->cols + j] = (u < r->n) ? mgain * r->h[u] : 0;
+        }
+}
+
+void *orc_rs_new(int mode, int L, int M, double gain, int win)
+{
+    orc_rs_t *r = (orc_rs_t *)calloc(1, sizeof(*r));
+    r->mode = mode; r->gain = gain;
+    if (mode == 0) {                                 /* llz_decimate_init, llz_resample.c:271-301 */
+        if (M > 16) { free(r); return NULL; }
+        r->L = 1; r->M = M;
+        build_matrix(r, M, 0, 1. / M, 1, win);
+        int m = 1024 / M;
+        r->num_in = m * M; r->num_out = m;
+        r->hist = r->n;
+    } else if (mode == 1) {                          /* llz_interp_init, :320-349 */
+        if (L > 16) { free(r); return NULL; }
+        r->L = L; r->M = 1;
+        build_matrix(r, L, 0, 1. / L, L, win);
+        r->num_in = 1024; r->num_out = 1024 * L;
+        r->hist = 0;
+    } else {                                         /* llz_resample_filter_init, :367-407 */
+        double ratio = ((double)L) / M;
+        if (ratio > 16 || (1. / ratio) > 16) { free(r); return NULL; }
+        r->L = L; r->M = M;
+        double fc = (1. / L < 1. / M) ? 1. / L : 1. / M;
+        build_matrix(r, L, M, fc, L, win);
+        r->num_in = (L * M) / igcd(L, M);
+        while (r->num_in < 1024) r->num_in *= 2;
+        r->num_out = (r->num_in * L) / M;
+        r->hist = r->cols;
+    }
+    /* + cols of zeroed slack behind the frame: llz_interp reads x[i+k] past the frame end
+     * (llz_resample.c:515-523); the restatement defines those reads as zeros */
+    r->buf = (short *)calloc((size_t)r->hist + r->num_in + r->cols + 1, sizeof(short));
+    return r;
+}
+
+int orc_rs_bytes_in(void *p)  { return 2 * ((orc_rs_t *)p)->num_in; }
+int orc_rs_bytes_out(void *p) { return 2 * ((orc_rs_t *)p)->num_out; }
+int orc_rs_num_taps(void *p)  { return ((orc_rs_t *)p)->n; }
+int orc_rs_sub_len(void *p)   { return ((orc_rs_t *)p)->cols; }
+const double *orc_rs_matrix(void *p) { return ((orc_rs_t *)p)->mat; }
+const double *orc_rs_proto(void *p)  { return ((orc_rs_t *)p)->h; }
+
+static short clamp_trunc(double y)
+{
+    if (y > 32767)  y = 32767;                       /* llz_resample.c:596-601 */
+    if (y < -32768) y = -32768;
+    return (short)y;                                 /* C conversion: toward zero */
+}
+
+int orc_rs_run(void *p, const unsigned char *in, int in_bytes, unsigned char *out, int *out_bytes)
+{
+    orc_rs_t *r = (orc_rs_t *)p;
+    if (in_bytes != 2 * r->num_in)
+        return -1;                                   /* reference: assert */
+    const short *src = (const short *)in;
+    short *dst = (short *)out;
+    short *x = r->buf + r->hist;                     /* first sample of this frame */
+    for (int i = 0; i < r->hist; i++)                /* keep the last `hist` samples in front */
+        r->buf[i] = r->buf[r->num_in + i];
+    memcpy(x, src, sizeof(short) * (size_t)r->num_in);
+
+    if (r->mode == 0) {
+        /* llz_decimate, llz_resample.c:457-483: y = sum_m sum_k x[iM + m + Mk - n] * p[m][k] */
+        int M = r->M, K = r->cols, n = r->n;
+        for (int i = 0; i < r->num_out; i++) {
+            double y = 0.0;
+            const short *xi = x + (size_t)i * M;
+            for (int m = 0; m < M; m++)
+                for (int k = 0; k < K; k++)
+                    y += xi[m + M * k - n] * r->mat[(size_t)m * K + k];
+            y *= r->gain;
+            dst[i] = clamp_trunc(y);
+        }
+    } else if (r->mode == 1) {
+        /* llz_interp, :515-536: no history; output slot order reversed within each input sample */
+        int L = r->L, K = r->cols;
+        for (int i = 0; i < r->num_in; i++)
+            for (int m = 0; m < L; m++) {
+                double y = 0.0;
+                for (int k = 0; k < K; k++)
+                    y += x[i + k] * r->mat[(size_t)m * K + k];
+                y *= r->gain;
+                dst[i * L + (L - 1 - m)] = clamp_trunc(y);
+            }
+    } else {
+        /* llz_resample, :583-603 */
+        int L = r->L, M = r->M, Q = r->cols;
+        for (int i = 0; i < r->num_out; i++) {
+            const short *xp = x + (i * M) / L;
+            int l = (int)(r->out_index % L);
+            r->out_index++;
+            const double *g = r->mat + (size_t)l * Q;
+            double y = 0.0;
+            for (int k = 0; k < Q; k++)
+                y += xp[-k] * g[k];
+            y *= r->gain;
+            dst[i] = clamp_trunc(y);
+        }
+    }
+    *out_bytes = 2 * r->num_out;
+    return 0;
+}
+
+void orc_rs_free(void *p)
+{
+    orc_rs_t *r = (orc_rs_t *)p;
+    if (!r) return;
+    free(r->h); free(r->mat); free(r->buf); free(r);
+}
+
+/* ------------------------------------------------------------------ float FFT (llz_fft.c) */
+
+typedef struct {
+    int size, base;
+    int *rev;
+    double *work, *c, *s;
+} orc_fft_t;
+
+static void bitrev_table(int *rev, int size)
+{
+    /* llz_fft.c:33-49: Gray-code style incremental bit reversal */
+    int r = 0, s = 0, i = 0;
+    do {
+        rev[i++] = s;
+        r += 2;
+        s ^= size - (size / (r & -r));
+    } while (r < (size << 1));
+}
+
+static int ceil_log2(int size)
+{
+    int base = (int)(log(size) / log(2));           /* llz_fft.c:211-214 */
+    if ((1 << base) < size) base += 1;
+    return base;
+}
+
+void *orc_fft_new(int size)
+{
+    orc_fft_t *f = (orc_fft_t *)calloc(1, sizeof(*f));
+    f->size = size; f->base = ceil_log2(size);
+    f->rev = (int *)malloc(sizeof(int) * (size_t)size);
+    f->work = (double *)malloc(sizeof(double) * 2 * (size_t)size);
+    f->c = (double *)malloc(sizeof(double) * (size_t)size);
+    f->s = (double *)malloc(sizeof(double) * (size_t)size);
+    bitrev_table(f->rev, size);
+    for (int i = 0; i < size; i++) {
+        double ang = (double)(2 * M_PI * i) / size;  /* llz_fft.c:223-227 */
+        f->c[i] = cos(ang);
+        f->s[i] = sin(ang);
+    }
+    return f;
+}
+
+static void permute_f64(orc_fft_t *f, double *d, int divide)
+{
+    int n = f->size;
+    for (int i = 0; i < n; i++) {
+        int b = f->rev[i];
+        f->work[2 * i] = d[2 * b]; f->work[2 * i + 1] = d[2 * b + 1];
+    }
+    for (int i = 0; i < n; i++) {
+        d[2 * i]     = divide ? f->work[2 * i] / n     : f->work[2 * i];
+        d[2 * i + 1] = divide ? f->work[2 * i + 1] / n : f->work[2 * i + 1];
+    }
+}
+
+void orc_fft_fwd(void *p, double *d)
+{
+    orc_fft_t *f = (orc_fft_t *)p;
+    long n = f->size;
+    /* llz_fft.c:61-89: DIF, span halves each stage, twiddle index step doubles, w = cos - j sin */
+    long tstep = 1;
+    for (long span = n; span > 1; span >>= 1, tstep += tstep) {
+        long halfc = span / 2;                       /* complex elements per half */
+        for (long blk = 0; blk < n; blk += span)
+            for (long q = 0; q < halfc; q++) {
+                /* the reference's dl counts DOUBLES between partners, i.e. span/2 complex elements */
+                double *u = d + 2 * (blk + q), *v = u + span;
+                double wr = f->c[q * tstep], wi = -f->s[q * tstep];
+                double xr = u[0] + v[0], xi = u[1] + v[1];
+                double dr = u[0] - v[0], di = u[1] - v[1];
+                u[0] = xr; u[1] = xi;
+                v[0] = dr * wr - di * wi;
+                v[1] = dr * wi + di * wr;
+            }
+    }
+    permute_f64(f, d, 0);                            /* llz_fft.c:155-163 */
+}
+
+void orc_fft_inv(void *p, double *d)
+{
+    orc_fft_t *f = (orc_fft_t *)p;
+    long n = f->size;
+    permute_f64(f, d, 1);                            /* llz_fft.c:182-195: gather, then divide by size */
+    /* llz_fft.c:101-130: DIT, span doubles each stage, w = cos + j sin */
+    long tstep = n >> 1;
+    for (long span = 2; tstep > 0; span += span, tstep >>= 1) {
+        long halfc = span / 2;
+        for (long blk = 0; blk < n; blk += span)
+            for (long q = 0; q < halfc; q++) {
+                double *u = d + 2 * (blk + q), *v = u + span;
+                double wr = f->c[q * tstep], wi = f->s[q * tstep];
+                double xr = u[0], xi = u[1], yr = v[0], yi = v[1];
+                double dr = yr * wr - yi * wi;
+                double di = yr * wi + yi * wr;
+                u[0] = xr + dr; u[1] = xi + di;
+                v[0] = xr - dr; v[1] = xi - di;
+            }
+    }
+}
+
+void orc_fft_free(void *p)
+{
+    orc_fft_t *f = (orc_fft_t *)p;
+    if (!f) return;
+    free(f->rev); free(f->work); free(f->c); free(f->s); free(f);
+}
+
+/* ------------------------------------------------------------------ fixed FFT (llz_fft_fixed.c/.h) */
+
+typedef struct {
+    int size, base;
+    int *rev, *work;
+    short *c, *s;
+} orc_fftx_t;
+
+static short q15(double v)
+{
+    /* llz_fft_fixed.h:42-66: round half away from zero of v*2^15, saturate to int32, clip to +-32767 */
+    double t = v * (double)(1 << 15);
+    double r = (t > 0) ? floor(t + 0.5) : ceil(t - 0.5);
+    int q = (r > 2147483647.0) ? 2147483647 : (r < -2147483648.0) ? (-2147483647 - 1) : (int)r;
+    if (q < -32767) q = -32767;
+    if (q > 32767) q = 32767;
+    return (short)q;
+}
+
+static inline int mul15(int a, int b)
+{
+    return (int)(((int64_t)a * (int64_t)b) >> 15);   /* llz_fft_fixed.h:67, arithmetic shift = floor */
+}
+
+/* the reference adds/subtracts plain ints (overflow is UB there, wraps in practice); wrap explicitly */
+static inline int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+static inline int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+
+void *orc_fftx_new(int size)
+{
+    orc_fftx_t *f = (orc_fftx_t *)calloc(1, sizeof(*f));
+    f->size = size; f->base = ceil_log2(size);
+    f->rev = (int *)malloc(sizeof(int) * (size_t)size);
+    f->work = (int *)malloc(sizeof(int) * 2 * (size_t)size);
+    f->c = (short *)malloc(sizeof(short) * (size_t)size);
+    f->s = (short *)malloc(sizeof(short) * (size_t)size);
+    bitrev_table(f->rev, size);
+    for (int i = 0; i < size; i++) {
+        double ang = (2 * M_PI * i) / size;          /* llz_fft_fixed.c:243-247 */
+        f->c[i] = q15(cos(ang));
+        f->s[i] = q15(sin(ang));
+    }
+    return f;
+}
+
+const short *orc_fftx_cos(void *p) { return ((orc_fftx_t *)p)->c; }
+const short *orc_fftx_sin(void *p) { return ((orc_fftx_t *)p)->s; }
+
+static void permute_i32(orc_fftx_t *f, int *d)
+{
+    int n = f->size;
+    for (int i = 0; i < n; i++) {
+        int b = f->rev[i];
+        f->work[2 * i] = d[2 * b]; f->work[2 * i + 1] = d[2 * b + 1];
+    }
+    memcpy(d, f->work, sizeof(int) * 2 * (size_t)n);
+}
+
+void orc_fftx_fwd(void *p, int *d)
+{
+    orc_fftx_t *f = (orc_fftx_t *)p;
+    long n = f->size, tstep = 1;
+    /* llz_fft_fixed.c:61-95 */
+    for (long span = n; span > 1; span >>= 1, tstep += tstep) {
+        long halfc = span / 2;
+        for (long blk = 0; blk < n; blk += span)
+            for (long q = 0; q < halfc; q++) {
+                int *u = d + 2 * (blk + q), *v = u + span;
+                short wr = f->c[q * tstep], wi = (short)(-f->s[q * tstep]);
+                int xr = wadd(u[0], v[0]), xi = wadd(u[1], v[1]);
+                int dr = wsub(u[0], v[0]), di = wsub(u[1], v[1]);
+                u[0] = xr; u[1] = xi;
+                v[0] = wsub(mul15(dr, wr), mul15(di, wi));
+                v[1] = wadd(mul15(dr, wi), mul15(di, wr));
+            }
+    }
+    permute_i32(f, d);                               /* llz_fft_fixed.c:165-174 */
+}
+
+void orc_fftx_inv(void *p, int *d)
+{
+    orc_fftx_t *f = (orc_fftx_t *)p;
+    long n = f->size;
+    permute_i32(f, d);                               /* llz_fft_fixed.c:200-208 */
+    long tstep = n >> 1;
+    for (long span = 2; tstep > 0; span += span, tstep >>= 1) {   /* :108-140 */
+        long halfc = span / 2;
+        for (long blk = 0; blk < n; blk += span)
+            for (long q = 0; q < halfc; q++) {
+                int *u = d + 2 * (blk + q), *v = u + span;
+                short wr = f->c[q * tstep], wi = f->s[q * tstep];
+                int xr = u[0], xi = u[1], yr = v[0], yi = v[1];
+                int dr = wsub(mul15(yr, wr), mul15(yi, wi));
+                int di = wadd(mul15(yr, wi), mul15(yi, wr));
+                u[0] = wadd(xr, dr); u[1] = wadd(xi, di);
+                v[0] = wsub(xr, dr); v[1] = wsub(xi, di);
+            }
+    }
+    for (long i = 0; i < 2 * n; i++)                 /* :212-215: scale only at the very end */
+        d[i] = d[i] >> f->base;
+}
+
+void orc_fftx_free(void *p)
+{
+    orc_fftx_t *f = (orc_fftx_t *)p;
+    if (!f) return;
+    free(f->rev); free(f->work); free(f->c); free(f->s); free(f);
+}
+
+/* ------------------------------------------------------------------ batch drivers */
+
+void orc_fir_batch_f32(const float *in, double *out, int channels, long n, const double *h, int flt_len)
+{
+    /* one orc_fir state machine per channel, a single frame of n samples (frame_len == init frame_len) */
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int c = 0; c < channels; c++) {
+        void *f = orc_fir_new_taps((int)n, h, flt_len);
+        for (long i = 0; i < n; i++) tmp[i] = (double)in[(size_t)c * n + i];
+        orc_fir_run(f, tmp, out + (size_t)c * n, (int)n);
+        orc_fir_free(f);
+    }
+    free(tmp);
+}
+
+void orc_iir_cascade_batch_f32(const float *in, double *out, int channels, long n,
+                               const double *coef, int stages)
+{
+    double *t0 = (double *)malloc(sizeof(double) * (size_t)n);
+    double *t1 = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int c = 0; c < channels; c++) {
+        for (long i = 0; i < n; i++) t0[i] = (double)in[(size_t)c * n + i];
+        for (int s = 0; s < stages; s++) {
+            const double *q = coef + 6 * s;
+            void *f = orc_iir_new(2, q + 3, 2, q);
+            orc_iir_run(f, t0, t1, (int)n);
+            orc_iir_free(f);
+            double *sw = t0; t0 = t1; t1 = sw;
+        }
+        memcpy(out + (size_t)c * n, t0, sizeof(double) * (size_t)n);
+    }
+    free(t0); free(t1);
+}
+
+long orc_rs_batch_f32(const float *in, double *out, int channels, long n_in, int L, int M,
+                      double gain, int win)
+{
+    orc_rs_t *r = (orc_rs_t *)orc_rs_new(2, L, M, gain, win);
+    if (!r) return -1;
+    int Q = r->cols;
+    long n_out = (n_in * L) / M;
+    for (int c = 0; c < channels; c++) {
+        const float *x = in + (size_t)c * n_in;
+        double *y = out + (size_t)c * n_out;
+        for (long i = 0; i < n_out; i++) {
+            long pos = (i * M) / L;
+            const double *g = r->mat + (size_t)(i % L) * Q;
+            double acc = 0.0;
+            for (int k = 0; k < Q; k++) {
+                long idx = pos - k;
+                double xv = (idx >= 0) ? (double)x[idx] : 0.0;
+                acc += xv * g[k];
+            }
+            y[i] = acc * gain;
+        }
+    }
+    orc_rs_free(r);
+    return n_out;
+}
+
+long orc_rs_batch_i16(const short *in, short *out, int channels, long n_in, int L, int M,
+                      double gain, int win)
+{
+    long n_out_total = -1;
+    for (int c = 0; c < channels; c++) {
+        orc_rs_t *r = (orc_rs_t *)orc_rs_new(2, L, M, gain, win);
+        if (!r) return -1;
+        long frames = n_in / r->num_in;
+        int ob = 0;
+        for (long f = 0; f < frames; f++)
+            orc_rs_run(r, (const unsigned char *)(in + (size_t)c * n_in + (size_t)f * r->num_in),
+                       2 * r->num_in,
+                       (unsigned char *)(out + (size_t)c * (frames * r->num_out) + (size_t)f * r->num_out), &ob);
+        n_out_total = frames * r->num_out;
+        orc_rs_free(r);
+    }
+    return n_out_total;
+}
+
+static inline uint32_t fmix32(uint32_t u)
+{
+    u ^= u >> 16; u *= 0x85EBCA6Bu; u ^= u >> 13; u *= 0xC2B2AE35u; u ^= u >> 16;
+    return u;
+}
+
+static inline uint32_t synth_u32(uint32_t seed, uint32_t c, uint32_t n)
+{
+    return fmix32(seed ^ (c * 0x9E3779B9u) ^ (n * 0x85EBCA6Bu));
+}
+
+void orc_synth_f32(float *dst, int channels, long n, unsigned seed, int chan0)
+{
+    for (int c = 0; c < channels; c++)
+        for (long i = 0; i < n; i++) {
+            uint32_t u = synth_u32(seed, (uint32_t)(c + chan0), (uint32_t)i);
+            dst[(size_t)c * n + i] = (float)(u >> 8) * (1.0f / 8388608.0f) - 1.0f;
+        }
+}
+
+void orc_synth_i16(short *dst, int channels, long n, unsigned seed, int chan0)
+{
+    for (int c = 0; c < channels; c++)
+        for (long i = 0; i < n; i++) {
+            uint32_t u = synth_u32(seed, (uint32_t)(c + chan0), (uint32_t)i);
+            dst[(size_t)c * n + i] = (short)((int32_t)(u >> 17) - 16384);
+        }
+}

@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle.pyoracle import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    from oracle import pyoracle
+    if not pyoracle.have_ref():
+        try:
+            pyoracle.build()
+        except Exception:
+            pass
+    if not pyoracle.have_ref():
+        pytest.skip("oracle/_ref/libllzref.so not available (reference tree absent and no prebuilt copy)")
+    return pyoracle.Ref()
