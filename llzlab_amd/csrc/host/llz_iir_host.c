@@ -1,0 +1,196 @@
+/*
+ * llz_iir_host.c -- handle layer of the IIR path: the reference's single-channel direct-form-I symbols
+ * (reference libllzfilter/llz_iir.c:37-156) and the multi-channel biquad-cascade extension.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "../../../include/llz_iir.h"
+#include "llz_host.h"
+
+/* ---- Part 1: single channel, double, exact order (k_iir_df1_f64_exact) ---- */
+
+typedef struct {
+    int tag;
+    int M, N;
+    double *d_a, *d_b, *d_xs, *d_ys;     /* coefficients and delay lines live on the device between calls */
+    llz_stage_t st_in, st_out;
+} iir1_t;
+
+static void iir1_destroy(iir1_t *f)
+{
+    if (!f) return;
+    llzs_free(f->d_a); llzs_free(f->d_b); llzs_free(f->d_xs); llzs_free(f->d_ys);
+    llz_stage_release(&f->st_in); llz_stage_release(&f->st_out);
+    f->tag = 0;
+    free(f);
+}
+
+unsigned long llz_iir_filter_init(int M, double *a, int N, double *b)
+{
+    if (M < 0 || N < 0 || M > 1024 || N > 1024 || !a) {
+        llzs_set_error("llz_iir_filter_init: M=%d N=%d (0..1024) or NULL a", M, N);
+        return LLZ_BAD_HANDLE;
+    }
+    iir1_t *f = (iir1_t *)calloc(1, sizeof(*f));
+    if (!f) return LLZ_BAD_HANDLE;
+    f->tag = LLZ_TAG_IIR1;
+    f->M = M; f->N = N;
+    double *bz = (double *)calloc((size_t)N + 1, sizeof(double));      /* b == NULL -> zeros (llz_iir.c:54-59) */
+    int rc = bz ? LLZ_OK : LLZ_ERR_NOMEM;
+    if (rc == LLZ_OK) {
+        if (b) memcpy(bz, b, sizeof(double) * ((size_t)N + 1));
+        f->d_a = (double *)llzs_malloc(sizeof(double) * ((size_t)M + 1));
+        f->d_b = (double *)llzs_malloc(sizeof(double) * ((size_t)N + 1));
+        f->d_xs = (double *)llzs_malloc(sizeof(double) * ((size_t)N + 1));
+        f->d_ys = (double *)llzs_malloc(sizeof(double) * ((size_t)M + 1));
+        if (!f->d_a || !f->d_b || !f->d_xs || !f->d_ys) rc = LLZ_ERR_NOMEM;
+    }
+    if (rc == LLZ_OK) rc = llzs_h2d(f->d_a, a, sizeof(double) * ((size_t)M + 1), NULL);
+    if (rc == LLZ_OK) rc = llzs_h2d(f->d_b, bz, sizeof(double) * ((size_t)N + 1), NULL);
+    if (rc == LLZ_OK) rc = llzs_memset(f->d_xs, 0, sizeof(double) * ((size_t)N + 1), NULL);
+    if (rc == LLZ_OK) rc = llzs_memset(f->d_ys, 0, sizeof(double) * ((size_t)M + 1), NULL);
+    if (rc == LLZ_OK) rc = llzs_sync(NULL);
+    free(bz);
+    if (rc != LLZ_OK) {
+        iir1_destroy(f);
+        return LLZ_BAD_HANDLE;
+    }
+    return (unsigned long)f;
+}
+
+void llz_iir_filter_uninit(unsigned long handle)
+{
+    if (LLZ_HANDLE_OK(handle, iir1_t, LLZ_TAG_IIR1))
+        iir1_destroy((iir1_t *)handle);
+}
+
+static int iir1_run(iir1_t *f, const double *x, double *y, int n)
+{
+    const size_t bytes = sizeof(double) * (size_t)n;
+    double *d_in = (double *)llz_stage_reserve(&f->st_in, bytes);
+    double *d_out = (double *)llz_stage_reserve(&f->st_out, bytes);
+    if (!d_in || !d_out) return LLZ_ERR_NOMEM;
+    int rc = x ? llzs_h2d(d_in, x, bytes, NULL) : llzs_memset(d_in, 0, bytes, NULL);
+    if (rc == LLZ_OK) rc = llzs_iir_df1_f64(d_in, d_out, f->d_a, f->d_b, f->d_xs, f->d_ys, f->M, f->N, n, NULL);
+    if (rc == LLZ_OK) rc = llzs_d2h(y, d_out, bytes, NULL);
+    return rc;
+}
+
+int llz_iir_filter(unsigned long handle, double *x, double *y, int frame_len)
+{
+    if (!LLZ_HANDLE_OK(handle, iir1_t, LLZ_TAG_IIR1) || !x || !y || frame_len < 0) {
+        llzs_set_error("llz_iir_filter: bad handle or buffer");
+        return LLZ_ERR_ARG;
+    }
+    if (frame_len == 0) return 0;
+    const int rc = iir1_run((iir1_t *)handle, x, y, frame_len);
+    return rc == LLZ_OK ? frame_len : rc;
+}
+
+int llz_iir_filter_flush(unsigned long handle, double *y)
+{
+    if (!LLZ_HANDLE_OK(handle, iir1_t, LLZ_TAG_IIR1) || !y) {
+        llzs_set_error("llz_iir_filter_flush: bad handle or buffer");
+        return LLZ_ERR_ARG;
+    }
+    iir1_t *f = (iir1_t *)handle;
+    if (f->N == 0) return 0;
+    const int rc = iir1_run(f, NULL, y, f->N);            /* N samples of x = 0 (llz_iir.c:147-156) */
+    return rc == LLZ_OK ? f->N : rc;
+}
+
+/* ---- Part 2: multi-channel biquad cascade (k_iir_cascade_f32) ---- */
+
+typedef struct {
+    int tag;
+    int channels, stages;
+    double *d_coef;      /* stages x {b0,b1,b2,a1,a2} */
+    double *d_state;     /* [channels][stages][x1,x2,y1,y2] */
+    void *stream;
+    llz_stage_t st_in, st_out;
+} iirm_t;
+
+static void iirm_destroy(iirm_t *f)
+{
+    if (!f) return;
+    llzs_free(f->d_coef); llzs_free(f->d_state);
+    llz_stage_release(&f->st_in); llz_stage_release(&f->st_out);
+    f->tag = 0;
+    free(f);
+}
+
+unsigned long llz_iir_cascade_mc_init(int channels, int stages, const double *coef)
+{
+    if (channels < 1 || stages < 1 || stages > 16 || !coef) {
+        llzs_set_error("llz_iir_cascade_mc_init: channels %d stages %d (1..16)", channels, stages);
+        return LLZ_BAD_HANDLE;
+    }
+    iirm_t *f = (iirm_t *)calloc(1, sizeof(*f));
+    if (!f) return LLZ_BAD_HANDLE;
+    f->tag = LLZ_TAG_IIRM;
+    f->channels = channels; f->stages = stages;
+    double *c5 = (double *)malloc(sizeof(double) * 5 * (size_t)stages);
+    const size_t st_bytes = sizeof(double) * 4 * (size_t)stages * (size_t)channels;
+    int rc = c5 ? LLZ_OK : LLZ_ERR_NOMEM;
+    if (rc == LLZ_OK) {
+        for (int s = 0; s < stages; s++) {                 /* {b0,b1,b2,a0,a1,a2} -> {b0,b1,b2,a1,a2}; a0 taken as 1 */
+            c5[5 * s + 0] = coef[6 * s + 0]; c5[5 * s + 1] = coef[6 * s + 1]; c5[5 * s + 2] = coef[6 * s + 2];
+            c5[5 * s + 3] = coef[6 * s + 4]; c5[5 * s + 4] = coef[6 * s + 5];
+        }
+        f->d_coef = (double *)llzs_malloc(sizeof(double) * 5 * (size_t)stages);
+        f->d_state = (double *)llzs_malloc(st_bytes);
+        if (!f->d_coef || !f->d_state) rc = LLZ_ERR_NOMEM;
+    }
+    if (rc == LLZ_OK) rc = llzs_h2d(f->d_coef, c5, sizeof(double) * 5 * (size_t)stages, NULL);
+    if (rc == LLZ_OK) rc = llzs_memset(f->d_state, 0, st_bytes, NULL);
+    if (rc == LLZ_OK) rc = llzs_sync(NULL);
+    free(c5);
+    if (rc != LLZ_OK) {
+        iirm_destroy(f);
+        return LLZ_BAD_HANDLE;
+    }
+    return (unsigned long)f;
+}
+
+void llz_iir_cascade_mc_uninit(unsigned long handle)
+{
+    if (LLZ_HANDLE_OK(handle, iirm_t, LLZ_TAG_IIRM)) {
+        llzs_sync(((iirm_t *)handle)->stream);
+        iirm_destroy((iirm_t *)handle);
+    }
+}
+
+int llz_iir_cascade_mc_set_stream(unsigned long handle, void *stream)
+{
+    if (!LLZ_HANDLE_OK(handle, iirm_t, LLZ_TAG_IIRM)) return LLZ_ERR_ARG;
+    ((iirm_t *)handle)->stream = stream;
+    return LLZ_OK;
+}
+
+int llz_iir_cascade_mc(unsigned long handle, const float *x, float *y, int frame_len)
+{
+    if (!LLZ_HANDLE_OK(handle, iirm_t, LLZ_TAG_IIRM) || !x || !y || frame_len < 1) {
+        llzs_set_error("llz_iir_cascade_mc: bad handle, buffer or frame_len");
+        return LLZ_ERR_ARG;
+    }
+    iirm_t *f = (iirm_t *)handle;
+    const size_t bytes = sizeof(float) * (size_t)f->channels * (size_t)frame_len;
+    const int in_dev = llzs_is_device_ptr(x), out_dev = llzs_is_device_ptr(y);
+    const float *d_in = x;
+    float *d_out = y;
+    int rc = LLZ_OK;
+    if (!in_dev) {
+        d_in = (const float *)llz_stage_reserve(&f->st_in, bytes);
+        if (!d_in) return LLZ_ERR_NOMEM;
+        rc = llzs_h2d((void *)d_in, x, bytes, f->stream);
+    }
+    if (rc == LLZ_OK && !out_dev) {
+        d_out = (float *)llz_stage_reserve(&f->st_out, bytes);
+        if (!d_out) return LLZ_ERR_NOMEM;
+    }
+    if (rc == LLZ_OK)
+        rc = llzs_iir_cascade_f32(d_in, d_out, f->d_coef, f->d_state, f->channels, frame_len, frame_len,
+                                  frame_len, f->stages, f->stream);
+    if (rc == LLZ_OK && !out_dev) rc = llzs_d2h(y, d_out, bytes, f->stream);
+    return rc == LLZ_OK ? frame_len : rc;
+}

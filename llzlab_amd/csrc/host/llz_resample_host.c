@@ -1,0 +1,441 @@
+/*
+ * llz_resample_host.c -- handle layer of the resample family: the reference's int16 single-channel symbols
+ * (reference libllzfilter/llz_resample.c:124-617) and the multi-channel batch extension.  Prototype design and
+ * the polyphase / time-varying tap matrices are host C (setup time); every sample is computed on the device.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "../../../include/llz_resample.h"
+#include "llz_host.h"
+
+/* ---- tap matrices (llz_resample.c:124-176 polyphase, :193-255 time-varying) ---- */
+
+typedef struct {
+    int n;          /* prototype length */
+    int rows, cols; /* phases x taps per phase */
+    double *h;      /* prototype low-pass */
+    double *mat;    /* rows x cols, row major */
+} tapmat_t;
+
+static void tapmat_free(tapmat_t *t)
+{
+    free(t->h); free(t->mat);
+    t->h = t->mat = NULL;
+}
+
+static int proto_estimate(double ftrans, win_t win)
+{
+    switch (win) {
+    case HAMMING:  return llz_hamming_cof_num(ftrans);
+    case BLACKMAN: return llz_blackman_cof_num(ftrans);
+    case KAISER:   return llz_kaiser_cof_num(ftrans, 90);     /* llz_resample.c:143 / :212 */
+    }
+    return -1;
+}
+
+/* phases = M (decimate), L (interp / rational).  tv_M = 0 selects the polyphase fill p[i][j] = g*h[phases*j + i];
+ * tv_M > 0 selects the time-varying fill g[i][j] = g*h[j*phases + (i*tv_M) % phases]. */
+static int tapmat_build(tapmat_t *t, int phases, int tv_M, double fc, double mgain, win_t win)
+{
+    if (mgain == 0) mgain = 1.0;                               /* llz_resample.c:131-132 */
+    const int est = proto_estimate(0.15 * fc, win);            /* transition band = 0.15 * fc */
+    if (est < 0) {
+        llzs_set_error("resample init: unknown window %d", win);
+        return LLZ_ERR_ARG;
+    }
+    t->n = 2 * (est / (2 * phases)) * phases + 1;              /* odd prototype: :151-152 / :218-219 */
+    t->rows = phases;
+    t->cols = t->n / phases + 1;
+    if (llz_host_design(LLZ_KIND_LPF, &t->h, t->n, fc, 0.0, win) != t->n) return LLZ_ERR_ARG;
+    t->mat = (double *)calloc((size_t)t->rows * t->cols, sizeof(double));
+    if (!t->mat) return LLZ_ERR_NOMEM;
+    for (int i = 0; i < t->rows; i++)
+        for (int j = 0; j < t->cols; j++) {
+            const int u = tv_M ? j * phases + (i * tv_M) % phases : phases * j + i;
+            if (u < t->n) t->mat[(size_t)i * t->cols + j] = mgain * t->h[u];
+        }
+    return LLZ_OK;
+}
+
+static int gcd_int(int a, int b)
+{
+    while (b) { const int r = a % b; a = b; b = r; }
+    return a;
+}
+
+/* =====================================================================================================
+ * Part 1: reference-identical int16 single-channel API
+ * ===================================================================================================== */
+
+enum { RS_DECIMATE = 0, RS_INTERP = 1, RS_RATIONAL = 2 };
+
+typedef struct {
+    int tag;
+    int mode, L, M;
+    double gain;
+    tapmat_t taps;
+    int num_in, num_out;
+    long long out_index;        /* running output count: phase = out_index % L (llz_resample.c:586) */
+    int hist;                   /* samples kept in front of each frame */
+    short *buf;                 /* host: [hist | num_in | cols zero slack] */
+    short *d_buf, *d_out;       /* device mirrors */
+    double *d_mat;
+} rs1_t;
+
+static void rs1_destroy(rs1_t *r)
+{
+    if (!r) return;
+    tapmat_free(&r->taps);
+    free(r->buf);
+    llzs_free(r->d_buf); llzs_free(r->d_out); llzs_free(r->d_mat);
+    r->tag = 0;
+    free(r);
+}
+
+static unsigned long rs1_finish(rs1_t *r)
+{
+    const size_t span = (size_t)r->hist + r->num_in + r->taps.cols + 1;
+    const size_t mat_bytes = sizeof(double) * (size_t)r->taps.rows * r->taps.cols;
+    r->buf = (short *)calloc(span, sizeof(short));             /* zero history: llz_resample.c:299-300 */
+    r->d_buf = (short *)llzs_malloc(span * sizeof(short));
+    r->d_out = (short *)llzs_malloc(sizeof(short) * (size_t)r->num_out);
+    r->d_mat = (double *)llzs_malloc(mat_bytes);
+    if (!r->buf || !r->d_buf || !r->d_out || !r->d_mat ||
+        llzs_h2d(r->d_mat, r->taps.mat, mat_bytes, NULL) != LLZ_OK) {
+        rs1_destroy(r);
+        return LLZ_BAD_HANDLE;
+    }
+    return (unsigned long)r;
+}
+
+static rs1_t *rs1_new(int mode, int L, int M, double gain)
+{
+    rs1_t *r = (rs1_t *)calloc(1, sizeof(*r));
+    if (!r) return NULL;
+    r->tag = LLZ_TAG_RS1;
+    r->mode = mode; r->L = L; r->M = M; r->gain = gain;
+    return r;
+}
+
+unsigned long llz_decimate_init(int M, double gain, win_t win_type)
+{
+    if (M < 1 || M > LLZ_RATIO_MAX) {                          /* llz_resample.c:278-279 */
+        llzs_set_error("llz_decimate_init: M=%d outside 1..%d", M, LLZ_RATIO_MAX);
+        return LLZ_BAD_HANDLE;
+    }
+    rs1_t *r = rs1_new(RS_DECIMATE, 1, M, gain);
+    if (!r) return LLZ_BAD_HANDLE;
+    if (tapmat_build(&r->taps, M, 0, 1. / M, 1, win_type) != LLZ_OK) { rs1_destroy(r); return LLZ_BAD_HANDLE; }
+    r->num_out = LLZ_DEFAULT_FRAMELEN / M;                     /* :291-293 */
+    r->num_in = r->num_out * M;
+    r->hist = r->taps.n;                                       /* :297: history of n samples */
+    return rs1_finish(r);
+}
+
+unsigned long llz_interp_init(int L, double gain, win_t win_type)
+{
+    if (L < 1 || L > LLZ_RATIO_MAX) {                          /* :326-327 */
+        llzs_set_error("llz_interp_init: L=%d outside 1..%d", L, LLZ_RATIO_MAX);
+        return LLZ_BAD_HANDLE;
+    }
+    rs1_t *r = rs1_new(RS_INTERP, L, 1, gain);
+    if (!r) return LLZ_BAD_HANDLE;
+    if (tapmat_build(&r->taps, L, 0, 1. / L, L, win_type) != LLZ_OK) { rs1_destroy(r); return LLZ_BAD_HANDLE; }
+    r->num_in = LLZ_DEFAULT_FRAMELEN;                          /* :338-339 */
+    r->num_out = LLZ_DEFAULT_FRAMELEN * L;
+    r->hist = 0;
+    return rs1_finish(r);
+}
+
+unsigned long llz_resample_filter_init(int L, int M, double gain, win_t win_type)
+{
+    if (L < 1 || M < 1) {
+        llzs_set_error("llz_resample_filter_init: L=%d M=%d", L, M);
+        return LLZ_BAD_HANDLE;
+    }
+    const double ratio = ((double)L) / M;
+    if (ratio > LLZ_RATIO_MAX || (1. / ratio) > LLZ_RATIO_MAX) {   /* :375-378 */
+        llzs_set_error("llz_resample_filter_init: ratio %d/%d outside 1/%d..%d", L, M, LLZ_RATIO_MAX, LLZ_RATIO_MAX);
+        return LLZ_BAD_HANDLE;
+    }
+    rs1_t *r = rs1_new(RS_RATIONAL, L, M, gain);
+    if (!r) return LLZ_BAD_HANDLE;
+    const double fc = (1. / L < 1. / M) ? 1. / L : 1. / M;     /* :382 */
+    if (tapmat_build(&r->taps, L, M, fc, L, win_type) != LLZ_OK) { rs1_destroy(r); return LLZ_BAD_HANDLE; }
+    r->num_in = (L * M) / gcd_int(L, M);                       /* :394-396: lcm doubled up to >= 1024 */
+    while (r->num_in < LLZ_DEFAULT_FRAMELEN) r->num_in *= 2;
+    r->num_out = (r->num_in * L) / M;
+    r->hist = r->taps.cols;                                    /* :402: Q samples kept */
+    return rs1_finish(r);
+}
+
+static void rs1_uninit(unsigned long handle)
+{
+    if (LLZ_HANDLE_OK(handle, rs1_t, LLZ_TAG_RS1))
+        rs1_destroy((rs1_t *)handle);
+}
+
+/* the reference's example calls llz_resample_filter_uninit on every kind of handle (main.c:125);
+ * all three release the same structure here, so that call is harmless instead of a crash */
+void llz_decimate_uninit(unsigned long handle)        { rs1_uninit(handle); }
+void llz_interp_uninit(unsigned long handle)          { rs1_uninit(handle); }
+void llz_resample_filter_uninit(unsigned long handle) { rs1_uninit(handle); }
+
+int llz_get_resample_framelen_bytes(unsigned long handle)
+{
+    if (!LLZ_HANDLE_OK(handle, rs1_t, LLZ_TAG_RS1)) return LLZ_ERR_ARG;
+    return 2 * ((rs1_t *)handle)->num_in;
+}
+
+static int rs1_process(unsigned long handle, int mode, unsigned char *in, int in_bytes, unsigned char *out,
+                       int *out_bytes, const char *who)
+{
+    if (!LLZ_HANDLE_OK(handle, rs1_t, LLZ_TAG_RS1) || !in || !out || !out_bytes) {
+        llzs_set_error("%s: bad handle or NULL buffer", who);
+        return LLZ_ERR_ARG;
+    }
+    rs1_t *r = (rs1_t *)handle;
+    if (r->mode != mode) {
+        llzs_set_error("%s: handle was created by a different *_init", who);
+        return LLZ_ERR_ARG;
+    }
+    if (in_bytes != 2 * r->num_in) {                           /* reference: assert (:443, :507, :560) */
+        llzs_set_error("%s: %d input bytes, expected %d", who, in_bytes, 2 * r->num_in);
+        return LLZ_ERR_ARG;
+    }
+    /* [history | frame]; the history is the tail of the previous buffer (:452-455 / :571-576) */
+    memmove(r->buf, r->buf + r->num_in, sizeof(short) * (size_t)r->hist);
+    memcpy(r->buf + r->hist, in, (size_t)in_bytes);
+    const size_t span = (size_t)r->hist + r->num_in + r->taps.cols;
+    int rc = llzs_h2d(r->d_buf, r->buf, span * sizeof(short), NULL);
+    if (rc == LLZ_OK) {
+        if (mode == RS_DECIMATE)
+            rc = llzs_decimate_i16(r->d_buf, r->d_out, r->d_mat, r->M, r->taps.cols, r->taps.n, r->num_out,
+                                   r->gain, NULL);
+        else if (mode == RS_INTERP)
+            rc = llzs_interp_i16(r->d_buf, r->d_out, r->d_mat, r->L, r->taps.cols, r->num_in, r->gain, NULL);
+        else
+            /* frame-local indexing as the reference: x + (i*M)/L with phase out_index % L; frames hold a whole
+             * number of L/M periods, so local and global indexing coincide */
+            rc = llzs_resample_i16(r->d_buf + r->hist, r->d_out, r->d_buf + 1, r->d_mat, 1, r->num_in,
+                                   r->num_out, r->num_in, r->num_out, r->L, r->M, r->taps.cols, r->gain,
+                                   r->out_index % r->L, 0, NULL);
+    }
+    if (rc == LLZ_OK) rc = llzs_d2h(out, r->d_out, sizeof(short) * (size_t)r->num_out, NULL);
+    if (rc != LLZ_OK) return rc;
+    r->out_index += r->num_out;
+    *out_bytes = 2 * r->num_out;
+    return 0;
+}
+
+int llz_decimate(unsigned long handle, unsigned char *sample_in, int sample_in_size, unsigned char *sample_out,
+                 int *sample_out_size)
+{
+    return rs1_process(handle, RS_DECIMATE, sample_in, sample_in_size, sample_out, sample_out_size, "llz_decimate");
+}
+
+int llz_interp(unsigned long handle, unsigned char *sample_in, int sample_in_size, unsigned char *sample_out,
+               int *sample_out_size)
+{
+    return rs1_process(handle, RS_INTERP, sample_in, sample_in_size, sample_out, sample_out_size, "llz_interp");
+}
+
+int llz_resample(unsigned long handle, unsigned char *sample_in, int sample_in_size, unsigned char *sample_out,
+                 int *sample_out_size)
+{
+    return rs1_process(handle, RS_RATIONAL, sample_in, sample_in_size, sample_out, sample_out_size, "llz_resample");
+}
+
+/* =====================================================================================================
+ * Part 2: multi-channel rational resampler
+ * ===================================================================================================== */
+
+typedef struct {
+    int tag;
+    int channels, L, M, fmt, Q;
+    double gain;
+    tapmat_t taps;
+    void *d_mat;                /* float (F32) or double (I16) L x Q */
+    void *d_hist[2];            /* [channels][Q-1] samples of the handle's format, ping-pong */
+    int cur;
+    long long in_count, out_count;   /* samples consumed / produced per channel so far */
+    void *stream;
+    llz_stage_t st_in, st_out;
+} rsm_t;
+
+static size_t rsm_sample_bytes(const rsm_t *r) { return r->fmt == LLZ_PCM_I16 ? sizeof(short) : sizeof(float); }
+
+static void rsm_destroy(rsm_t *r)
+{
+    if (!r) return;
+    tapmat_free(&r->taps);
+    llzs_free(r->d_mat); llzs_free(r->d_hist[0]); llzs_free(r->d_hist[1]);
+    llz_stage_release(&r->st_in); llz_stage_release(&r->st_out);
+    r->tag = 0;
+    free(r);
+}
+
+static int rsm_upload_matrix(rsm_t *r)
+{
+    const size_t count = (size_t)r->L * r->Q;
+    if (r->fmt == LLZ_PCM_I16)
+        return llzs_h2d(r->d_mat, r->taps.mat, sizeof(double) * count, NULL);
+    float *m32 = (float *)malloc(sizeof(float) * count);
+    if (!m32) return LLZ_ERR_NOMEM;
+    for (size_t i = 0; i < count; i++) m32[i] = (float)r->taps.mat[i];
+    const int rc = llzs_h2d(r->d_mat, m32, sizeof(float) * count, NULL);
+    free(m32);
+    return rc;
+}
+
+unsigned long llz_resample_mc_init(int channels, int L, int M, double gain, win_t win_type, int pcm_format)
+{
+    if (channels < 1 || channels > 65535 || L < 1 || M < 1 ||
+        (pcm_format != LLZ_PCM_F32 && pcm_format != LLZ_PCM_I16)) {
+        llzs_set_error("llz_resample_mc_init: channels %d L %d M %d format %d", channels, L, M, pcm_format);
+        return LLZ_BAD_HANDLE;
+    }
+    const double ratio = ((double)L) / M;
+    if (ratio > LLZ_RATIO_MAX || (1. / ratio) > LLZ_RATIO_MAX) {
+        llzs_set_error("llz_resample_mc_init: ratio %d/%d outside 1/%d..%d", L, M, LLZ_RATIO_MAX, LLZ_RATIO_MAX);
+        return LLZ_BAD_HANDLE;
+    }
+    rsm_t *r = (rsm_t *)calloc(1, sizeof(*r));
+    if (!r) return LLZ_BAD_HANDLE;
+    r->tag = LLZ_TAG_RSM;
+    r->channels = channels; r->L = L; r->M = M; r->fmt = pcm_format; r->gain = gain;
+    const double fc = (1. / L < 1. / M) ? 1. / L : 1. / M;
+    int rc = tapmat_build(&r->taps, L, M, fc, L, win_type);
+    if (rc == LLZ_OK) {
+        r->Q = r->taps.cols;
+        const size_t hist_bytes = rsm_sample_bytes(r) * (size_t)channels * (size_t)(r->Q > 1 ? r->Q - 1 : 1);
+        r->d_mat = llzs_malloc((r->fmt == LLZ_PCM_I16 ? sizeof(double) : sizeof(float)) * (size_t)L * r->Q);
+        r->d_hist[0] = llzs_malloc(hist_bytes);
+        r->d_hist[1] = llzs_malloc(hist_bytes);
+        if (!r->d_mat || !r->d_hist[0] || !r->d_hist[1]) rc = LLZ_ERR_NOMEM;
+        if (rc == LLZ_OK) rc = rsm_upload_matrix(r);
+        if (rc == LLZ_OK) rc = llzs_memset(r->d_hist[0], 0, hist_bytes, NULL);
+        if (rc == LLZ_OK) rc = llzs_memset(r->d_hist[1], 0, hist_bytes, NULL);
+        if (rc == LLZ_OK) rc = llzs_sync(NULL);
+    }
+    if (rc != LLZ_OK) {
+        rsm_destroy(r);
+        return LLZ_BAD_HANDLE;
+    }
+    return (unsigned long)r;
+}
+
+void llz_resample_mc_uninit(unsigned long handle)
+{
+    if (LLZ_HANDLE_OK(handle, rsm_t, LLZ_TAG_RSM)) {
+        llzs_sync(((rsm_t *)handle)->stream);
+        rsm_destroy((rsm_t *)handle);
+    }
+}
+
+int llz_resample_mc_sub_len(unsigned long handle)
+{
+    return LLZ_HANDLE_OK(handle, rsm_t, LLZ_TAG_RSM) ? ((rsm_t *)handle)->Q : LLZ_ERR_ARG;
+}
+
+long llz_resample_mc_out_len(unsigned long handle, long n_in)
+{
+    if (!LLZ_HANDLE_OK(handle, rsm_t, LLZ_TAG_RSM) || n_in < 1) return LLZ_ERR_ARG;
+    const rsm_t *r = (const rsm_t *)handle;
+    if ((n_in * r->L) % r->M) {
+        llzs_set_error("llz_resample_mc: n_in*L = %ld*%d is not a multiple of M = %d", n_in, r->L, r->M);
+        return LLZ_ERR_ARG;
+    }
+    return (n_in * r->L) / r->M;
+}
+
+int llz_resample_mc_set_stream(unsigned long handle, void *stream)
+{
+    if (!LLZ_HANDLE_OK(handle, rsm_t, LLZ_TAG_RSM)) return LLZ_ERR_ARG;
+    ((rsm_t *)handle)->stream = stream;
+    return LLZ_OK;
+}
+
+int llz_resample_mc_get_matrix(unsigned long handle, double *dst, int capacity)
+{
+    if (!LLZ_HANDLE_OK(handle, rsm_t, LLZ_TAG_RSM) || !dst) return LLZ_ERR_ARG;
+    const rsm_t *r = (const rsm_t *)handle;
+    const int count = r->L * r->Q;
+    if (capacity < count) {
+        llzs_set_error("llz_resample_mc_get_matrix: capacity %d < %d", capacity, count);
+        return LLZ_ERR_ARG;
+    }
+    memcpy(dst, r->taps.mat, sizeof(double) * (size_t)count);
+    return count;
+}
+
+int llz_resample_mc_set_matrix(unsigned long handle, const double *src, int count)
+{
+    if (!LLZ_HANDLE_OK(handle, rsm_t, LLZ_TAG_RSM) || !src) return LLZ_ERR_ARG;
+    rsm_t *r = (rsm_t *)handle;
+    if (count != r->L * r->Q) {
+        llzs_set_error("llz_resample_mc_set_matrix: %d values, expected %d", count, r->L * r->Q);
+        return LLZ_ERR_ARG;
+    }
+    memcpy(r->taps.mat, src, sizeof(double) * (size_t)count);
+    int rc = llzs_sync(r->stream);
+    if (rc == LLZ_OK) rc = rsm_upload_matrix(r);
+    return rc;
+}
+
+long llz_resample_mc(unsigned long handle, const void *in, long n_in, void *out)
+{
+    if (!LLZ_HANDLE_OK(handle, rsm_t, LLZ_TAG_RSM) || !in || !out) {
+        llzs_set_error("llz_resample_mc: bad handle or NULL buffer");
+        return LLZ_ERR_ARG;
+    }
+    rsm_t *r = (rsm_t *)handle;
+    const long n_out = llz_resample_mc_out_len(handle, n_in);
+    if (n_out < 1) return LLZ_ERR_ARG;
+    /* calls must start on an L/M period boundary so that (i*M)/L stays exact across calls */
+    if ((r->in_count * r->L) % r->M) {
+        llzs_set_error("llz_resample_mc: stream position is not on an L/M boundary");
+        return LLZ_ERR_ARG;
+    }
+    const size_t sb = rsm_sample_bytes(r);
+    const size_t in_bytes = sb * (size_t)r->channels * (size_t)n_in;
+    const size_t out_bytes = sb * (size_t)r->channels * (size_t)n_out;
+    const int in_dev = llzs_is_device_ptr(in), out_dev = llzs_is_device_ptr(out);
+    const void *d_in = in;
+    void *d_out = out;
+    int rc = LLZ_OK;
+    if (!in_dev) {
+        d_in = llz_stage_reserve(&r->st_in, in_bytes);
+        if (!d_in) return LLZ_ERR_NOMEM;
+        rc = llzs_h2d((void *)d_in, in, in_bytes, r->stream);
+    }
+    if (rc == LLZ_OK && !out_dev) {
+        d_out = llz_stage_reserve(&r->st_out, out_bytes);
+        if (!d_out) return LLZ_ERR_NOMEM;
+    }
+    const void *hist = r->Q > 1 ? r->d_hist[r->cur] : NULL;
+    if (rc == LLZ_OK) {
+        if (r->fmt == LLZ_PCM_I16)
+            rc = llzs_resample_i16((const short *)d_in, (short *)d_out, (const short *)hist,
+                                   (const double *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->L, r->M,
+                                   r->Q, r->gain, r->out_count, r->in_count, r->stream);
+        else
+            rc = llzs_resample_f32((const float *)d_in, (float *)d_out, (const float *)hist,
+                                   (const float *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->L, r->M,
+                                   r->Q, (float)r->gain, r->out_count, r->in_count, r->stream);
+    }
+    if (rc == LLZ_OK && r->Q > 1) {
+        if (r->fmt == LLZ_PCM_I16)
+            rc = llzs_tail_i16((const short *)d_in, (const short *)r->d_hist[r->cur],
+                               (short *)r->d_hist[r->cur ^ 1], r->channels, n_in, n_in, r->Q - 1, r->stream);
+        else
+            rc = llzs_fir_tail_f32((const float *)d_in, (const float *)r->d_hist[r->cur],
+                                   (float *)r->d_hist[r->cur ^ 1], r->channels, (int)n_in, n_in, r->Q, r->stream);
+        if (rc == LLZ_OK) r->cur ^= 1;
+    }
+    if (rc == LLZ_OK && !out_dev) rc = llzs_d2h(out, d_out, out_bytes, r->stream);
+    if (rc != LLZ_OK) return rc;
+    r->in_count += n_in;
+    r->out_count += n_out;
+    return n_out;
+}

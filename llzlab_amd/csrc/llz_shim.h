@@ -1,0 +1,93 @@
+/*
+ * llz_shim.h -- INTERNAL boundary between the host C layer (csrc/host, .c files, gcc) and the HIP translation
+ * units (csrc/kernels, .hip files, hipcc).  "Host code stays C and calls HIP through a thin C-ABI shim": the host
+ * layer never includes a HIP header; everything it needs from the device is one of these functions.
+ * All pointers named dev_* / in / out / hist are DEVICE pointers unless stated; stream is a hipStream_t as void*.
+ * Every function returns 0 on success or a negative LLZ_ERR_* code and records text for llz_hip_last_error().
+ */
+#ifndef LLZ_SHIM_H
+#define LLZ_SHIM_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime ---- */
+void  llzs_set_error(const char *fmt, ...);
+void *llzs_malloc(size_t bytes);
+void  llzs_free(void *p);
+int   llzs_h2d(void *dev_dst, const void *host_src, size_t bytes, void *stream);   /* synchronous for the caller */
+int   llzs_d2h(void *host_dst, const void *dev_src, size_t bytes, void *stream);   /* synchronous for the caller */
+int   llzs_d2d(void *dev_dst, const void *dev_src, size_t bytes, void *stream);    /* asynchronous on stream */
+int   llzs_memset(void *dev_dst, int value, size_t bytes, void *stream);
+int   llzs_sync(void *stream);
+int   llzs_is_device_ptr(const void *p);
+
+/* ---- FIR ---- */
+#define LLZS_FIR_TAP_PAD 8      /* time-domain kernels read taps in groups of 8: pad the table with zeros */
+#define LLZS_OLS_NFFT   1024
+#define LLZS_OLS_MAX_TAPS 257   /* overlap = 256, 768 new samples per 1024-point block */
+
+/* y[c][i] = sum_k taps[k] * x[c][i-k]; x[c][i<0] = hist[c][flt_len-1+i] (hist NULL = zeros).
+ * in/out planar with row pitch in_pitch/out_pitch elements. taps: flt_len floats padded to a multiple of 8. */
+int llzs_fir_td_f32(const float *in, float *out, const float *hist, const float *taps_padded,
+                    int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream);
+/* overlap-save: hfreq = 1024 complex floats, FFT(taps)/1024 in natural bin order; twid = 32x32 complex
+ * W_1024^(a*b).  Requires flt_len <= 257. */
+int llzs_fir_ols_f32(const float *in, float *out, const float *hist, const float *hfreq, const float *twid,
+                     int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream);
+/* hist_new[c][:] = last (flt_len-1) samples of concat(hist_old[c], in[c][0:n]) */
+int llzs_fir_tail_f32(const float *in, const float *hist_old, float *hist_new,
+                      int channels, int n, long in_pitch, int flt_len, void *stream);
+/* single channel, double, the reference's exact accumulation order (ascending k, multiply then add) */
+int llzs_fir_td_f64(const double *in, double *out, const double *hist, const double *taps,
+                    int n, int flt_len, void *stream);
+
+/* ---- IIR ---- */
+/* cascade of `stages` biquads; coef: stages x 5 doubles {b0,b1,b2,a1,a2}; state: [channels][stages][4] doubles
+ * {x1,x2,y1,y2} per stage, read and written. */
+int llzs_iir_cascade_f32(const float *in, float *out, const double *coef, double *state,
+                         int channels, int n, long in_pitch, long out_pitch, int stages, void *stream);
+/* general direct form I, one channel, double, the reference's exact operation order (llz_iir.c:103-132).
+ * xs: N+1 doubles, ys: M+1 doubles (delay lines, read and written) */
+int llzs_iir_df1_f64(const double *in, double *out, const double *a, const double *b, double *xs, double *ys,
+                     int M, int N, int n, void *stream);
+
+/* ---- resample ---- */
+/* y[c][i] = gain * sum_{k<Q} x[c][(i0+i)*M/L - k - in0] * g[(i0+i)%L][k], x before the call start comes from
+ * hist[c][Q-1 + idx] (hist holds the previous Q-1 samples).  i0 = global index of the first output of this call,
+ * in0 = global index of the first input sample of this call.  n_out outputs per channel. */
+int llzs_resample_f32(const float *in, float *out, const float *hist, const float *g,
+                      int channels, long n_in, long n_out, long in_pitch, long out_pitch,
+                      int L, int M, int Q, float gain, long long i0, long long in0, void *stream);
+/* int16 PCM, double taps, double accumulate in ascending k with separate multiply and add, clamp, truncate */
+int llzs_resample_i16(const short *in, short *out, const short *hist, const double *g,
+                      int channels, long n_in, long n_out, long in_pitch, long out_pitch,
+                      int L, int M, int Q, double gain, long long i0, long long in0, void *stream);
+int llzs_tail_i16(const short *in, const short *hist_old, short *hist_new, int channels, long n, long in_pitch,
+                  int keep, void *stream);
+/* llz_decimate (forward indexed polyphase sum over a history of n samples) and llz_interp (no history),
+ * single channel int16, exact order: see llz_resample.c:457-483 and :515-536 */
+int llzs_decimate_i16(const short *buf /* n hist + num_in */, short *out, const double *p, int M, int K, int n,
+                      int num_out, double gain, void *stream);
+int llzs_interp_i16(const short *x /* num_in + K zero padded */, short *out, const double *p, int L, int K,
+                    int num_in, double gain, void *stream);
+
+/* ---- FFT ---- */
+/* float32 batch, in place; cs = size cos then size sin values (float). inverse: 0 forward, 1 inverse (divides by size) */
+int llzs_fft_f32(float *data, int count, int size, const float *cs, int inverse, void *stream);
+/* double, one transform, exact reference butterfly order and rounding (no contraction) */
+int llzs_fft_f64(double *data, int size, const double *cs, int inverse, void *stream);
+/* int32 data, Q15 twiddles (size cos then size sin shorts), bit-exact */
+int llzs_fft_fixed(int *data, int count, int size, const short *cs, int inverse, void *stream);
+
+/* ---- synthetic PCM ---- */
+int llzs_synth_f32(float *dst, int channels, long n, long pitch, unsigned seed, int chan0, void *stream);
+int llzs_synth_i16(short *dst, int channels, long n, long pitch, unsigned seed, int chan0, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

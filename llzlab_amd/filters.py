@@ -1,0 +1,401 @@
+"""Python mirror of the reference's handle interface (init / process / flush / uninit) over the C ABI.
+
+Names and argument meaning follow reference libllzfilter/llz_{fir,iir,resample,fft,fft_fixed}.h; the *MC classes
+are the multi-channel float32/int16 batch extension.  Device buffers are torch tensors (used for memory and
+streams only: `tensor.data_ptr()` crosses the boundary as a plain pointer); numpy arrays are accepted as host
+memory.  Nothing here computes: every sample goes through libllzfilter_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import (BAD_HANDLE, BLACKMAN, FIR_ALGO_AUTO, FIR_ALGO_OVERLAP_SAVE, FIR_ALGO_TIME, HAMMING, KAISER,  # noqa: F401
+                   PCM_F32, PCM_I16, LlzError, check, check_handle)
+
+
+def _ptr(buf):
+    """Plain address of a torch tensor (any device) or a numpy array; the library sorts host from device."""
+    if isinstance(buf, np.ndarray):
+        if not buf.flags["C_CONTIGUOUS"]:
+            raise LlzError("numpy buffer must be C-contiguous")
+        return buf.ctypes.data
+    if hasattr(buf, "data_ptr"):
+        if not buf.is_contiguous():
+            raise LlzError("tensor must be contiguous")
+        return buf.data_ptr()
+    raise LlzError(f"unsupported buffer type {type(buf)}")
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return None
+    return getattr(stream, "cuda_stream", stream)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+_dp = C.POINTER(C.c_double)
+
+
+# ------------------------------------------------------------------------------------------ design (host C)
+def fir_design(kind, n, fc1, fc2=0.0, win=HAMMING):
+    """kind: 'lpf' | 'hpf' | 'bandpass' | 'bandstop' -> float64 taps from llz_fir_*_cof (host C code)."""
+    L = capi.lib()
+    hp = _dp()
+    if kind == "lpf":
+        m = L.llz_fir_lpf_cof(C.byref(hp), n, fc1, win)
+    elif kind == "hpf":
+        m = L.llz_fir_hpf_cof(C.byref(hp), n, fc1, win)
+    elif kind == "bandpass":
+        m = L.llz_fir_bandpass_cof(C.byref(hp), n, fc1, fc2, win)
+    elif kind == "bandstop":
+        m = L.llz_fir_bandstop_cof(C.byref(hp), n, fc1, fc2, win)
+    else:
+        raise LlzError("unknown filter kind " + kind)
+    if m < 1:
+        raise LlzError("tap design failed")
+    taps = np.ctypeslib.as_array(hp, shape=(m,)).copy()
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(hp)                       # the caller owns *h (reference llz_fir.h:82-86)
+    return taps
+
+
+def window(win, n, beta=None):
+    L = capi.lib()
+    w = np.zeros(n)
+    p = w.ctypes.data_as(_dp)
+    if beta is not None:
+        L.llz_kaiser_beta(p, n, beta)
+    else:
+        (L.llz_hamming, L.llz_blackman, L.llz_kaiser)[win](p, n)
+    return w
+
+
+# ------------------------------------------------------------------------------------------ FIR
+class FirFilter:
+    """Single channel, double, host buffers: llz_fir_filter_{lpf,hpf,bandpass,bandstop}_init & co."""
+
+    def __init__(self, kind, frame_len, flt_len, fc1, fc2=0.0, win=HAMMING):
+        L = self._L = capi.lib()
+        if kind == "lpf":
+            h = L.llz_fir_filter_lpf_init(frame_len, flt_len, fc1, win)
+        elif kind == "hpf":
+            h = L.llz_fir_filter_hpf_init(frame_len, flt_len, fc1, win)
+        elif kind == "bandpass":
+            h = L.llz_fir_filter_bandpass_init(frame_len, flt_len, fc1, fc2, win)
+        elif kind == "bandstop":
+            h = L.llz_fir_filter_bandstop_init(frame_len, flt_len, fc1, fc2, win)
+        else:
+            raise LlzError("unknown filter kind " + kind)
+        self.handle = check_handle(h, "llz_fir_filter_*_init")
+        self.frame_len = frame_len
+        self.flt_len = flt_len if kind == "lpf" or flt_len & 1 else flt_len + 1
+
+    def filter(self, x):
+        x = _f64(x)
+        y = np.zeros_like(x)
+        check(self._L.llz_fir_filter(self.handle, x.ctypes.data_as(_dp), y.ctypes.data_as(_dp), len(x)),
+              "llz_fir_filter")
+        return y
+
+    def flush(self):
+        y = np.zeros(max(self.flt_len - 1, 1))
+        n = check(self._L.llz_fir_filter_flush(self.handle, y.ctypes.data_as(_dp)), "llz_fir_filter_flush")
+        return y[:n]
+
+    def close(self):
+        if self.handle:
+            self._L.llz_fir_filter_uninit(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
+class FirFilterMC:
+    """channels x frame_len float32, planar; llz_fir_filter_mc_*."""
+
+    def __init__(self, channels, frame_len, taps, algo=FIR_ALGO_AUTO, stream=None):
+        self._L = capi.lib()
+        taps = _f64(taps)
+        self.handle = check_handle(
+            self._L.llz_fir_filter_mc_init_f64taps(channels, frame_len, taps.ctypes.data, len(taps), algo),
+            "llz_fir_filter_mc_init")
+        self.channels, self.frame_len, self.flt_len = channels, frame_len, len(taps)
+        self.algo = self._L.llz_fir_filter_mc_algo(self.handle)
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, stream):
+        check(self._L.llz_fir_filter_mc_set_stream(self.handle, _stream_ptr(stream)), "set_stream")
+
+    def filter(self, x, out):
+        """x, out: [channels, frame_len] float32 (torch device tensors or numpy). Returns out."""
+        check(self._L.llz_fir_filter_mc(self.handle, _ptr(x), _ptr(out), self.frame_len), "llz_fir_filter_mc")
+        return out
+
+    def flush(self, out):
+        check(self._L.llz_fir_filter_mc_flush(self.handle, _ptr(out)), "llz_fir_filter_mc_flush")
+        return out
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            self._L.llz_fir_filter_mc_uninit(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
+# ------------------------------------------------------------------------------------------ IIR
+class IirFilter:
+    """Single channel direct form I, double, host buffers: llz_iir_filter_*."""
+
+    def __init__(self, a, b):
+        self._L = capi.lib()
+        a = _f64(a)
+        self.M = len(a) - 1
+        if b is None:
+            raise LlzError("pass b (zeros for the reference's NULL case)")
+        b = _f64(b)
+        self.N = len(b) - 1
+        self.handle = check_handle(
+            self._L.llz_iir_filter_init(self.M, a.ctypes.data_as(_dp), self.N, b.ctypes.data_as(_dp)),
+            "llz_iir_filter_init")
+
+    def filter(self, x):
+        x = _f64(x)
+        y = np.zeros_like(x)
+        check(self._L.llz_iir_filter(self.handle, x.ctypes.data_as(_dp), y.ctypes.data_as(_dp), len(x)),
+              "llz_iir_filter")
+        return y
+
+    def flush(self):
+        y = np.zeros(max(self.N, 1))
+        n = check(self._L.llz_iir_filter_flush(self.handle, y.ctypes.data_as(_dp)), "llz_iir_filter_flush")
+        return y[:n]
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            self._L.llz_iir_filter_uninit(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
+class IirCascadeMC:
+    """channels x n float32 through a fused cascade of biquads; coef rows {b0,b1,b2,a0,a1,a2}."""
+
+    def __init__(self, channels, coef, stream=None):
+        self._L = capi.lib()
+        coef = _f64(coef).reshape(-1, 6)
+        self.stages = coef.shape[0]
+        self.channels = channels
+        self.handle = check_handle(self._L.llz_iir_cascade_mc_init(channels, self.stages, coef.ctypes.data),
+                                   "llz_iir_cascade_mc_init")
+        if stream is not None:
+            check(self._L.llz_iir_cascade_mc_set_stream(self.handle, _stream_ptr(stream)), "set_stream")
+
+    def filter(self, x, out):
+        n = x.shape[-1]
+        check(self._L.llz_iir_cascade_mc(self.handle, _ptr(x), _ptr(out), n), "llz_iir_cascade_mc")
+        return out
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            self._L.llz_iir_cascade_mc_uninit(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
+# ------------------------------------------------------------------------------------------ resample
+class _Resample1:
+    """int16 single channel, host buffers: llz_{decimate,interp,resample}."""
+    _init = _run = _uninit = None
+
+    def _open(self, h):
+        self.handle = check_handle(h, type(self).__name__ + " init")
+        self.bytes_in = self._L.llz_get_resample_framelen_bytes(self.handle)
+
+    def process(self, pcm):
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        out = np.zeros(len(pcm) * 16 + 16, dtype=np.int16)
+        ob = C.c_int(0)
+        rc = self._run(self.handle, pcm.ctypes.data, 2 * len(pcm), out.ctypes.data, C.byref(ob))
+        check(rc, type(self).__name__)
+        return out[:ob.value // 2].copy()
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            self._uninit(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
+class Decimate(_Resample1):
+    def __init__(self, M, gain=1.0, win=BLACKMAN):
+        self._L = capi.lib()
+        self._run, self._uninit = self._L.llz_decimate, self._L.llz_decimate_uninit
+        self._open(self._L.llz_decimate_init(M, gain, win))
+
+
+class Interp(_Resample1):
+    def __init__(self, L_, gain=1.0, win=BLACKMAN):
+        self._L = capi.lib()
+        self._run, self._uninit = self._L.llz_interp, self._L.llz_interp_uninit
+        self._open(self._L.llz_interp_init(L_, gain, win))
+
+
+class Resample(_Resample1):
+    def __init__(self, L_, M, gain=1.0, win=BLACKMAN):
+        self._L = capi.lib()
+        self._run, self._uninit = self._L.llz_resample, self._L.llz_resample_filter_uninit
+        self._open(self._L.llz_resample_filter_init(L_, M, gain, win))
+
+
+class ResampleMC:
+    """channels x n_in -> channels x n_in*L/M; pcm_format PCM_F32 (float32) or PCM_I16 (bit-exact int16)."""
+
+    def __init__(self, channels, L_, M, gain=1.0, win=BLACKMAN, pcm_format=PCM_F32, stream=None):
+        self._L = capi.lib()
+        self.channels, self.L, self.M, self.fmt = channels, L_, M, pcm_format
+        self.handle = check_handle(self._L.llz_resample_mc_init(channels, L_, M, gain, win, pcm_format),
+                                   "llz_resample_mc_init")
+        self.Q = self._L.llz_resample_mc_sub_len(self.handle)
+        if stream is not None:
+            check(self._L.llz_resample_mc_set_stream(self.handle, _stream_ptr(stream)), "set_stream")
+
+    def out_len(self, n_in):
+        return check(self._L.llz_resample_mc_out_len(self.handle, n_in), "llz_resample_mc_out_len")
+
+    def matrix(self):
+        m = np.zeros(self.L * self.Q)
+        check(self._L.llz_resample_mc_get_matrix(self.handle, m.ctypes.data, m.size), "get_matrix")
+        return m.reshape(self.L, self.Q)
+
+    def set_matrix(self, m):
+        m = _f64(m)
+        check(self._L.llz_resample_mc_set_matrix(self.handle, m.ctypes.data, m.size), "set_matrix")
+
+    def process(self, x, out):
+        n_in = x.shape[-1]
+        return check(self._L.llz_resample_mc(self.handle, _ptr(x), n_in, _ptr(out)), "llz_resample_mc")
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            self._L.llz_resample_mc_uninit(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
+# ------------------------------------------------------------------------------------------ FFT
+class Fft:
+    """Reference API: complex128 host arrays, forward unscaled, inverse / N."""
+
+    def __init__(self, size):
+        self._L = capi.lib()
+        self.size = size
+        self.handle = check_handle(self._L.llz_fft_init(size), "llz_fft_init")
+
+    def _run(self, fn, z):
+        z = np.ascontiguousarray(z, dtype=np.complex128).copy()
+        if len(z) != self.size:
+            raise LlzError("length mismatch")
+        fn(self.handle, z.view(np.float64).ctypes.data_as(_dp))
+        return z
+
+    def fft(self, z):
+        return self._run(self._L.llz_fft, z)
+
+    def ifft(self, z):
+        return self._run(self._L.llz_ifft, z)
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            self._L.llz_fft_uninit(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
+class FftBatch:
+    """count x size complex64 transforms in place (device tensor of float32 pairs or numpy complex64)."""
+
+    def __init__(self, size, stream=None):
+        self._L = capi.lib()
+        self.size = size
+        self.handle = check_handle(self._L.llz_fft_batch_init(size), "llz_fft_batch_init")
+        if stream is not None:
+            check(self._L.llz_fft_batch_set_stream(self.handle, _stream_ptr(stream)), "set_stream")
+
+    def fft(self, data, count):
+        check(self._L.llz_fft_batch(self.handle, _ptr(data), count), "llz_fft_batch")
+        return data
+
+    def ifft(self, data, count):
+        check(self._L.llz_ifft_batch(self.handle, _ptr(data), count), "llz_ifft_batch")
+        return data
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            self._L.llz_fft_batch_uninit(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
+class FftFixed:
+    """int32 interleaved data, Q15 twiddles, bit-exact; single (host) and batched (device or host)."""
+
+    def __init__(self, size, stream=None):
+        self._L = capi.lib()
+        self.size = size
+        self.handle = check_handle(self._L.llz_fft_fixed_init(size), "llz_fft_fixed_init")
+        if stream is not None:
+            check(self._L.llz_fft_fixed_set_stream(self.handle, _stream_ptr(stream)), "set_stream")
+
+    def fft(self, q):
+        q = np.ascontiguousarray(q, dtype=np.int32).copy()
+        self._L.llz_fft_fixed(self.handle, q.ctypes.data_as(C.POINTER(C.c_int)))
+        return q
+
+    def ifft(self, q):
+        q = np.ascontiguousarray(q, dtype=np.int32).copy()
+        self._L.llz_ifft_fixed(self.handle, q.ctypes.data_as(C.POINTER(C.c_int)))
+        return q
+
+    def fft_batch(self, data, count):
+        check(self._L.llz_fft_fixed_batch(self.handle, _ptr(data), count), "llz_fft_fixed_batch")
+        return data
+
+    def ifft_batch(self, data, count):
+        check(self._L.llz_ifft_fixed_batch(self.handle, _ptr(data), count), "llz_ifft_fixed_batch")
+        return data
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            self._L.llz_fft_fixed_uninit(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
+# ------------------------------------------------------------------------------------------ synthetic PCM
+def synth_f32(dst, seed, chan0=0, stream=None):
+    """Fill a [channels, n] float32 device tensor with the counter-hash PCM of SURVEY.md 8(d)."""
+    ch, n = dst.shape
+    check(capi.lib().llz_hip_synth_f32(_ptr(dst), ch, n, dst.stride(0), seed, chan0, _stream_ptr(stream)),
+          "llz_hip_synth_f32")
+    return dst
+
+
+def synth_i16(dst, seed, chan0=0, stream=None):
+    ch, n = dst.shape
+    check(capi.lib().llz_hip_synth_i16(_ptr(dst), ch, n, dst.stride(0), seed, chan0, _stream_ptr(stream)),
+          "llz_hip_synth_i16")
+    return dst

@@ -1,0 +1,386 @@
+"""GPU parity: every kernel through the C ABI (include/*.h) against the CPU oracle and the golden fixtures.
+
+Bit-exact for double (exact-order kernels), int16 and int32; float32 batch paths within 1e-5 RMS absolute and
+relative to rms(reference) -- the tolerance BASELINE.json's north_star states.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from llzlab_amd import capi, filters  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-5   # RMS, north_star
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    assert capi.lib().llz_hip_device_count() >= 1, capi.last_error()
+    torch.cuda.set_device(0)
+    capi.check(capi.lib().llz_hip_set_device(0), "set_device")
+    return torch.device("cuda:0")
+
+
+def rms_check(got, ref, what):
+    got = np.asarray(got, dtype=np.float64)
+    err = float(np.sqrt(np.mean((got - ref) ** 2)))
+    rel = err / max(float(np.sqrt(np.mean(ref ** 2))), 1e-30)
+    assert err <= TOL and rel <= TOL, f"{what}: rms {err:.3g} rel {rel:.3g}"
+    return err, rel
+
+
+# ------------------------------------------------------------------------------------------------ design + synth
+def test_host_design_matches_golden(dev):
+    d = load("design.npz")
+    kinds = ["lpf", "hpf", "bandpass", "bandstop"]
+    for k, kind in enumerate(kinds):
+        for win in range(3):
+            for n in (15, 16, 63, 64, 257):
+                got = filters.fir_design(kind, n, 0.2 if k >= 2 else 0.25, 0.4, win)
+                assert np.array_equal(got, d[f"taps_k{k}_w{win}_n{n}"]), (kind, win, n)
+    for win in range(3):
+        assert np.array_equal(filters.window(win, 33), d[f"win_w{win}_n33"])
+
+
+def test_synth_matches_oracle(dev, oracle):
+    x = torch.empty(5, 3001, dtype=torch.float32, device=dev)
+    filters.synth_f32(x, seed=0x11c0ffee, chan0=3)
+    assert np.array_equal(x.cpu().numpy(), oracle.synth_f32(5, 3001, 0x11c0ffee, chan0=3))
+    s = torch.empty(3, 2048, dtype=torch.int16, device=dev)
+    filters.synth_i16(s, seed=9)
+    assert np.array_equal(s.cpu().numpy(), oracle.synth_i16(3, 2048, 9))
+
+
+# ------------------------------------------------------------------------------------------------ FIR
+def test_fir_single_channel_exact_vs_golden(dev):
+    d = load("fir_stream.npz")
+    kinds = ["lpf", "hpf", "bandpass", "bandstop"]
+    for k, kind in enumerate(kinds):
+        for win in range(3):
+            f = filters.FirFilter(kind, 64, 31, 0.2 if k >= 2 else 0.3, 0.45, win)
+            y = np.concatenate([f.filter(d["x"][o:o + 64]) for o in range(0, len(d["x"]), 64)])
+            tail = f.flush()
+            f.close()
+            assert np.array_equal(y, d[f"y_k{k}_w{win}"]), (kind, win)
+            assert np.array_equal(tail, d[f"tail_k{k}_w{win}"]), (kind, win)
+    f = filters.FirFilter("lpf", 512, 257, 0.1, 0.0, po.KAISER)
+    x = d["x32_257"].astype(np.float64)
+    y = np.concatenate([f.filter(x[o:o + 512]) for o in range(0, len(x), 512)])
+    assert np.array_equal(y, d["y32_257"]) and np.array_equal(f.flush(), d["tail32_257"])
+    f.close()
+
+
+def test_fir_single_channel_rejects_other_frame_len(dev):
+    f = filters.FirFilter("lpf", 64, 31, 0.3)
+    with pytest.raises(capi.LlzError):
+        f.filter(np.zeros(32))
+    f.close()
+
+
+@pytest.mark.parametrize("flt_len,algo", [(63, filters.FIR_ALGO_TIME), (257, filters.FIR_ALGO_TIME),
+                                          (257, filters.FIR_ALGO_OVERLAP_SAVE), (200, filters.FIR_ALGO_OVERLAP_SAVE),
+                                          (5, filters.FIR_ALGO_OVERLAP_SAVE), (1, filters.FIR_ALGO_TIME)])
+@pytest.mark.parametrize("channels,n", [(3, 4096), (5, 1536 * 3), (2, 1000), (7, 2049)])
+def test_fir_mc_vs_oracle(dev, oracle, flt_len, algo, channels, n):
+    taps = oracle.fir_design(po.LPF, flt_len, 0.2, 0.0, po.KAISER) if flt_len > 1 else np.array([0.75])
+    x = torch.empty(channels, n, dtype=torch.float32, device=dev)
+    filters.synth_f32(x, seed=flt_len + n)
+    y = torch.empty_like(x)
+    f = filters.FirFilterMC(channels, n, taps, algo=algo)
+    assert f.algo == algo
+    f.filter(x, y)
+    ref = oracle.fir_batch_f32(x.cpu().numpy(), taps.astype(np.float32).astype(np.float64))
+    rms_check(y.cpu().numpy(), ref, f"fir mc T={flt_len} algo={algo}")
+    f.close()
+
+
+@pytest.mark.parametrize("algo", [filters.FIR_ALGO_TIME, filters.FIR_ALGO_OVERLAP_SAVE])
+def test_fir_mc_streaming_frames_and_flush(dev, oracle, algo):
+    """three equal frames == one long frame (history carried on the device), then flush == the filter's tail"""
+    d = load("fir_stream.npz")
+    taps = oracle.fir_design(po.LPF, 257, 0.1, 0.0, po.KAISER)
+    x = np.stack([d["x32_257"], d["x32_257"][::-1].copy()])            # 2 channels x 1536
+    f = filters.FirFilterMC(2, 512, taps, algo=algo)
+    outs = []
+    for o in range(0, 1536, 512):
+        xi = torch.from_numpy(np.ascontiguousarray(x[:, o:o + 512])).to(dev)
+        yi = torch.empty_like(xi)
+        f.filter(xi, yi)
+        outs.append(yi.cpu().numpy())
+    y = np.concatenate(outs, axis=1)
+    tail = torch.empty(2, 256, dtype=torch.float32, device=dev)
+    f.flush(tail)
+    f.close()
+    rms_check(y[0], d["y32_257"], "streamed frames vs reference fixture")
+    t32 = taps.astype(np.float32).astype(np.float64)
+    full = oracle.fir_batch_f32(np.concatenate([x, np.zeros((2, 256), np.float32)], axis=1), t32)
+    rms_check(y, full[:, :1536], "streamed frames vs oracle")
+    assert np.sqrt(np.mean((tail.cpu().numpy() - full[:, 1536:]) ** 2)) <= TOL
+
+
+def test_fir_mc_host_pointers_and_errors(dev, oracle):
+    taps = oracle.fir_design(po.LPF, 63, 0.25, 0.0, po.HAMMING)
+    x = oracle.synth_f32(4, 2048, 5)
+    y = np.zeros_like(x)
+    f = filters.FirFilterMC(4, 2048, taps)
+    assert f.algo == filters.FIR_ALGO_TIME
+    f.filter(x, y)                                                     # numpy = host memory, staged by the library
+    rms_check(y, oracle.fir_batch_f32(x, taps.astype(np.float32).astype(np.float64)), "host staging")
+    with pytest.raises(capi.LlzError):
+        capi.check(capi.lib().llz_fir_filter_mc(f.handle, x.ctypes.data, y.ctypes.data, 1024), "short frame")
+    f.close()
+    with pytest.raises(capi.LlzError):
+        filters.FirFilterMC(4, 2048, np.ones(300), algo=filters.FIR_ALGO_OVERLAP_SAVE)
+    assert filters.FirFilterMC(2, 64, np.ones(257)).algo == filters.FIR_ALGO_OVERLAP_SAVE
+
+
+def test_fir_linearity_and_impulse_large(dev):
+    """size-independent properties at a larger size: impulse -> taps, and filter(a x1 + x2) = a f(x1) + f(x2)"""
+    taps = filters.fir_design("lpf", 257, 0.1, 0.0, po.KAISER)
+    ch, n = 64, 1 << 16
+    f = filters.FirFilterMC(ch, n, taps)
+    x = torch.zeros(ch, n, dtype=torch.float32, device=dev)
+    x[:, 1000] = 1.0
+    y = torch.empty_like(x)
+    f.filter(x, y)
+    got = y[:, 1000:1257].cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(got - taps[None, :])) < 2e-7
+    assert float(y[:, :1000].abs().max()) < 1e-6 and float(y[:, 1257:].abs().max()) < 1e-6
+    f.close()
+    x1 = torch.empty(ch, n, dtype=torch.float32, device=dev)
+    x2 = torch.empty_like(x1)
+    filters.synth_f32(x1, seed=1)
+    filters.synth_f32(x2, seed=2)
+    ys = []
+    for xi in (x1, x2, 0.5 * x1 + x2):
+        f = filters.FirFilterMC(ch, n, taps)
+        yi = torch.empty_like(xi)
+        f.filter(xi, yi)
+        ys.append(yi)
+        f.close()
+    assert float((ys[2] - (0.5 * ys[0] + ys[1])).pow(2).mean().sqrt()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ IIR
+def test_iir_single_channel_exact_vs_golden(dev):
+    d = load("iir.npz")
+    for a, b, yk, tk, fl in (("a2", "b2", "y2", "tail2", 100), ("a3", "b3", "y3", "tail3", 75),
+                             ("a5", "b5", "y5", "tail5", 300)):
+        f = filters.IirFilter(d[a], d[b])
+        y = np.concatenate([f.filter(d["x"][o:o + fl]) for o in range(0, 300, fl)])
+        assert np.array_equal(y, d[yk]), yk
+        assert np.array_equal(f.flush(), d[tk]), tk
+        f.close()
+    f = filters.IirFilter(d["aq"], d["bq"])
+    assert np.array_equal(f.filter(d["x32"].astype(np.float64)), d["yq"])
+    f.close()
+
+
+@pytest.mark.parametrize("stages", [1, 3, 8])
+@pytest.mark.parametrize("channels,n", [(5, 1000), (70, 777), (64, 4096)])
+def test_iir_cascade_mc_vs_oracle(dev, oracle, stages, channels, n):
+    d = load("iir.npz")
+    rows = [np.concatenate([d["b2"], d["a2"]])] * stages
+    if stages >= 3:
+        rows[1] = np.concatenate([d["bq"], d["aq"]])                   # one high-Q section (pole radius 0.99)
+    coef = np.stack(rows)
+    x = torch.empty(channels, n, dtype=torch.float32, device=dev)
+    filters.synth_f32(x, seed=stages * 100 + channels)
+    y = torch.empty_like(x)
+    f = filters.IirCascadeMC(channels, coef)
+    f.filter(x, y)
+    ref = oracle.iir_cascade_batch_f32(x.cpu().numpy(), coef)
+    rms_check(y.cpu().numpy(), ref, f"iir cascade S={stages}")
+    f.close()
+
+
+def test_iir_cascade_fixture_and_streaming(dev):
+    d = load("iir.npz")
+    coef = np.tile(np.concatenate([d["b2"], d["a2"]]), (8, 1))
+    x = np.tile(d["x32"], (3, 1))
+    f = filters.IirCascadeMC(3, coef)
+    outs = []
+    for o in (0, 500, 1100):                                           # ragged frame lengths: state carries
+        e = {0: 500, 500: 1100, 1100: 2048}[o]
+        xi = torch.from_numpy(np.ascontiguousarray(x[:, o:e])).to(dev)
+        yi = torch.empty_like(xi)
+        f.filter(xi, yi)
+        outs.append(yi.cpu().numpy())
+    f.close()
+    y = np.concatenate(outs, axis=1)
+    for c in range(3):
+        rms_check(y[c], d["y_cascade8"], "cascade8 vs reference fixture")
+
+
+# ------------------------------------------------------------------------------------------------ resample
+def test_resample_single_channel_exact_vs_golden(dev):
+    d = load("resample.npz")
+    for (L, M) in [(1, 3), (2, 3), (3, 2), (147, 160), (160, 147)]:
+        for win in range(3):
+            seed, nin, frames = (int(v) for v in d[f"rs_{L}_{M}_w{win}_seed"])
+            pcm = np.random.default_rng(seed).integers(-16384, 16384, nin * frames).astype(np.int16)
+            r = filters.Resample(L, M, 1.0, win)
+            assert r.bytes_in == 2 * nin
+            out = np.concatenate([r.process(pcm[f * nin:(f + 1) * nin]) for f in range(frames)])
+            r.close()
+            assert np.array_equal(out, d[f"rs_{L}_{M}_w{win}_out"]), (L, M, win)
+    r = filters.Resample(2, 3, 2.0, po.BLACKMAN)
+    nin = r.bytes_in // 2
+    out = np.concatenate([r.process(d["rs_clip_in"][f * nin:(f + 1) * nin]) for f in range(2)])
+    r.close()
+    assert np.array_equal(out, d["rs_clip_out"]) and out.max() == 32767 and out.min() == -32768
+    with pytest.raises(capi.LlzError):
+        filters.Resample(17, 1)
+    r = filters.Resample(1, 3)
+    with pytest.raises(capi.LlzError):
+        r.process(np.zeros(100, dtype=np.int16))                       # wrong frame size: reference asserts
+    r.close()
+
+
+def test_decimate_interp_exact_vs_golden(dev):
+    d = load("resample.npz")
+    for M in (2, 3, 5):
+        seed, nin, frames = (int(v) for v in d[f"dec_{M}_seed"])
+        pcm = np.random.default_rng(seed).integers(-16384, 16384, nin * frames).astype(np.int16)
+        r = filters.Decimate(M)
+        out = np.concatenate([r.process(pcm[f * nin:(f + 1) * nin]) for f in range(frames)])
+        r.close()
+        assert np.array_equal(out, d[f"dec_{M}_out"]), M
+    for L in (2, 3):
+        seed, nin, frames = (int(v) for v in d[f"int_{L}_seed"])
+        pcm = np.random.default_rng(seed).integers(-16384, 16384, nin * frames).astype(np.int16)
+        r = filters.Interp(L)
+        out = np.concatenate([r.process(pcm[f * nin:(f + 1) * nin]) for f in range(frames)])
+        r.close()
+        assert np.array_equal(out, d[f"int_{L}_out"]), L
+
+
+@pytest.mark.parametrize("L,M,win", [(1, 3, po.BLACKMAN), (2, 3, po.HAMMING), (3, 2, po.KAISER), (147, 160, po.BLACKMAN)])
+def test_resample_mc_i16_bit_exact(dev, oracle, L, M, win):
+    info = oracle.rs_info(2, L, M, 1.0, win)
+    nin = info["bytes_in"] // 2
+    frames = 3 if nin < 4000 else 1
+    ch = 5
+    x = oracle.synth_i16(ch, nin * frames, seed=L * 31 + M)
+    ref = oracle.rs_batch_i16(x, L, M, 1.0, win)
+    r = filters.ResampleMC(ch, L, M, 1.0, win, filters.PCM_I16)
+    assert r.Q == info["cols"] and np.array_equal(r.matrix(), info["matrix"])
+    xd = torch.from_numpy(x).to(dev)
+    yd = torch.empty(ch, ref.shape[1], dtype=torch.int16, device=dev)
+    assert r.process(xd, yd) == ref.shape[1]
+    assert np.array_equal(yd.cpu().numpy(), ref)
+    r.close()
+    # streaming in two calls gives the same samples
+    if frames == 3:
+        r = filters.ResampleMC(ch, L, M, 1.0, win, filters.PCM_I16)
+        outs = []
+        for (o, e) in ((0, nin), (nin, 3 * nin)):
+            xi = torch.from_numpy(np.ascontiguousarray(x[:, o:e])).to(dev)
+            yi = torch.empty(ch, (e - o) * L // M, dtype=torch.int16, device=dev)
+            r.process(xi, yi)
+            outs.append(yi.cpu().numpy())
+        r.close()
+        assert np.array_equal(np.concatenate(outs, axis=1), ref)
+
+
+@pytest.mark.parametrize("L,M,win", [(1, 3, po.BLACKMAN), (2, 3, po.HAMMING), (3, 2, po.KAISER), (160, 147, po.BLACKMAN)])
+def test_resample_mc_f32_vs_oracle(dev, oracle, L, M, win):
+    ch = 4
+    n_in = 3 * M * 512
+    x = oracle.synth_f32(ch, n_in, seed=77)
+    r = filters.ResampleMC(ch, L, M, 1.0, win, filters.PCM_F32)
+    n_out = r.out_len(n_in)
+    xd = torch.from_numpy(x).to(dev)
+    yd = torch.empty(ch, n_out, dtype=torch.float32, device=dev)
+    r.process(xd, yd)
+    r.close()
+    # oracle: same indexing with the float-rounded tap matrix the device uses, double accumulate
+    ref = oracle.rs_batch_f32(x, L, M, 1.0, win)
+    got = yd.cpu().numpy().astype(np.float64)
+    err = float(np.sqrt(np.mean((got - ref) ** 2)))
+    assert err <= TOL and err / float(np.sqrt(np.mean(ref ** 2))) <= 3e-5, err
+
+
+def test_resample_mc_f32_integer_input_matches_int16_reference(dev, oracle):
+    """integer-valued float input: trunc(clamp(float path)) equals the bit-exact int16 path except within ~1e-2
+    of an integer boundary (float accumulate), SURVEY.md H3"""
+    ch, n_in = 3, 1536 * 4
+    xi = oracle.synth_i16(ch, n_in, seed=4)
+    ref = oracle.rs_batch_i16(xi, 1, 3, 1.0, po.BLACKMAN)
+    r = filters.ResampleMC(ch, 1, 3, 1.0, po.BLACKMAN, filters.PCM_F32)
+    yd = torch.empty(ch, n_in // 3, dtype=torch.float32, device=dev)
+    r.process(torch.from_numpy(xi.astype(np.float32)).to(dev), yd)
+    r.close()
+    got = np.trunc(np.clip(yd.cpu().numpy(), -32768, 32767)).astype(np.int16)
+    assert np.max(np.abs(got.astype(np.int32) - ref)) <= 1
+    assert np.mean(got != ref) < 0.01
+
+
+# ------------------------------------------------------------------------------------------------ FFT
+@pytest.mark.parametrize("n", [8, 64, 1024, 4096])
+def test_fft_double_exact_vs_golden(dev, n):
+    d = load("fft.npz")
+    z = d[f"fft_in_{n}"].astype(np.complex128)
+    f = filters.Fft(n)
+    assert np.array_equal(f.fft(z), d[f"fft_fwd_{n}"])
+    assert np.array_equal(f.ifft(z), d[f"fft_inv_{n}"])
+    f.close()
+
+
+@pytest.mark.parametrize("n", [8, 64, 1024, 4096])
+def test_fft_fixed_bit_exact_vs_golden(dev, n):
+    d = load("fft.npz")
+    q = d[f"fftx_in_{n}"]
+    f = filters.FftFixed(n)
+    assert np.array_equal(f.fft(q), d[f"fftx_fwd_{n}"])
+    assert np.array_equal(f.ifft(q), d[f"fftx_inv_{n}"])
+    f.close()
+
+
+def test_fft_fixed_known_answers_and_batch(dev, oracle):
+    d = load("fft.npz")
+    f = filters.FftFixed(1024)
+    fw = f.fft(d["fftx_sin_in"])
+    assert np.array_equal(fw, d["fftx_sin_fwd"]) and np.array_equal(f.ifft(fw), d["fftx_sin_roundtrip"])
+    rng = np.random.default_rng(11)
+    batch = rng.integers(-10000, 10001, (37, 2048)).astype(np.int32)
+    bd = torch.from_numpy(batch).to(dev)
+    f.fft_batch(bd, 37)
+    ref = np.stack([oracle.fft_fixed(row) for row in batch])
+    assert np.array_equal(bd.cpu().numpy(), ref)
+    f.ifft_batch(bd, 37)
+    ref2 = np.stack([oracle.fft_fixed(row, inverse=True) for row in ref])
+    assert np.array_equal(bd.cpu().numpy(), ref2)
+    f.close()
+    f = filters.FftFixed(8)
+    ramp = np.zeros(16, dtype=np.int32)
+    ramp[0::2] = 1000 * np.arange(8)
+    assert np.array_equal(f.fft(ramp), d["fftx_ramp_fwd"])
+    f.close()
+
+
+@pytest.mark.parametrize("n", [8, 256, 1024, 4096])
+def test_fft_batch_f32_vs_oracle(dev, oracle, n):
+    rng = np.random.default_rng(n)
+    count = 9
+    z = (rng.uniform(-1, 1, (count, n)) + 1j * rng.uniform(-1, 1, (count, n))).astype(np.complex64)
+    zd = torch.from_numpy(z.view(np.float32).copy()).to(dev)
+    f = filters.FftBatch(n)
+    f.fft(zd, count)
+    got = zd.cpu().numpy().view(np.complex64)
+    ref = np.stack([oracle.fft(row.astype(np.complex128)) for row in z])
+    assert np.sqrt(np.mean(np.abs(got - ref) ** 2)) / np.sqrt(np.mean(np.abs(ref) ** 2)) < 1e-6
+    f.ifft(zd, count)                                                   # round trip = identity
+    back = zd.cpu().numpy().view(np.complex64)
+    assert np.sqrt(np.mean(np.abs(back - z) ** 2)) < 1e-6
+    f.close()
