@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: multi-channel float32 FIR, 257 taps, 4096 channels per GPU (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by the driver under torch.distributed.run, one rank per GPU, backend nccl = RCCL)
+
+A step = one pass of the hot path over one batch: llz_fir_filter_mc() on 4096 channels x 2^20 samples of
+synthetic PCM that is already resident in HBM (generated on the device).  Channels shard across ranks with no
+data-path collective (weak scaling: every GPU filters its own 4096 channels); the only exchange is the tap-table
+broadcast from rank 0 at setup.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+BYTES_PER_SAMPLE = 8           # FIR fp32: 4 B read + 4 B written per sample-channel
+CHANNELS = 4096
+N_SAMPLES = 1 << 20
+FLT_LEN = 257
+SEED = 0x11C0FFEE
+
+
+def cpu_baseline(taps64, oracle_mod):
+    """Reference CPU path (oracle/_ref when built, else the oracle port) on a bounded sample of the same
+    workload, one llz_fir_filter state machine per channel, frame 4096, all host threads."""
+    threads = max(1, min(16, os.cpu_count() or 1))
+    ch_per_thread, n = 8, 1 << 20
+    kind = "reference" if oracle_mod.have_ref() else "port"
+    orc = oracle_mod.Oracle()
+    x = orc.synth_f32(threads * ch_per_thread, n, SEED).astype(np.float64)
+    backend = oracle_mod.Ref() if kind == "reference" else orc
+    frame = 4096
+
+    def work(t):
+        for c in range(ch_per_thread):
+            # design inside the reference (same call the real caller makes), then stream frames
+            backend.fir_stream(0, frame, FLT_LEN, 0.1, 0.0, 2, x[t * ch_per_thread + c], flush=False)
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    t0 = time.perf_counter()
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    dt = time.perf_counter() - t0
+    total = threads * ch_per_thread * n
+    return {"value": total / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": kind,
+            "sample": f"{threads * ch_per_thread} ch x {n} samples, {FLT_LEN}-tap llz_fir_filter, frame {frame}, "
+                      f"{threads} threads ({dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--channels", type=int, default=CHANNELS, help="channels per GPU (weak scaling)")
+    ap.add_argument("--samples", type=int, default=N_SAMPLES)
+    ap.add_argument("--algo", type=int, default=0, help="0 auto (overlap-save), 1 time domain, 2 overlap-save")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--extra", action="store_true", help="also time resample / IIR / 63-tap FIR (reported under 'also')")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from llzlab_amd import capi, filters, shard
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    capi.check(capi.lib().llz_hip_set_device(local_rank), "llz_hip_set_device")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    channels, n = args.channels, args.samples
+    # rank 0 designs the tap set (host C: llz_fir_lpf_cof(257, 0.1, KAISER)); everyone else receives it over RCCL
+    taps = filters.fir_design("lpf", FLT_LEN, 0.1, 0.0, filters.KAISER) if rank == 0 else np.zeros(FLT_LEN)
+    taps = shard.broadcast_table(taps, src=0, device=dev)
+
+    stream = torch.cuda.current_stream()
+    x = torch.empty(channels, n, dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    filters.synth_f32(x, SEED, chan0=rank * channels, stream=stream)
+    fir = filters.FirFilterMC(channels, n, taps, algo=args.algo, stream=stream)
+    L = capi.lib()
+    sptr = stream.cuda_stream
+
+    for _ in range(args.warmup):
+        fir.filter(x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    # per-launch device time of the dominant kernel: HIP events on the stream the kernel runs on
+    timers = [L.llz_hip_timer_new() for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        L.llz_hip_timer_start(timers[k], sptr)
+        fir.filter(x, y)
+        L.llz_hip_timer_stop(timers[k], sptr)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    wall = shard.max_over_ranks(wall, device=dev)
+    launch_ms = [L.llz_hip_timer_ms(t) for t in timers]
+    for t in timers:
+        L.llz_hip_timer_free(t)
+    kern_ms = float(np.mean(launch_ms))
+
+    ms_per_step = wall / args.steps * 1e3
+    samples_per_step = channels * n * world
+    value = samples_per_step / (wall / args.steps) / 1e6                  # Msamples/s, whole job
+
+    # parity spot check against the oracle (outside the timed region): first + last 2 channels, first 16 Ki samples
+    parity = None
+    also = {}
+    cpu = None
+    if rank == 0:
+        from oracle import pyoracle
+        orc = pyoracle.Oracle()
+        sel = [0, 1, channels - 2, channels - 1]
+        m = min(n, 1 << 14)
+        keep = FLT_LEN - 1
+        # the handle streams: every step after the first starts from the previous step's last 256 samples, so
+        # the oracle is fed [tail of x | head of x] and its first 256 outputs are dropped
+        xs = torch.cat([x[sel, n - keep:], x[sel, :m]], dim=1).cpu().numpy()
+        ref = orc.fir_batch_f32(xs, taps.astype(np.float32).astype(np.float64))[:, keep:]
+        got = y[sel, :m].cpu().numpy().astype(np.float64)
+        err = float(np.sqrt(np.mean((got - ref) ** 2)))
+        parity = {"rms_abs": err, "rms_rel": err / float(np.sqrt(np.mean(ref ** 2))), "tolerance": 1e-5,
+                  "checked": f"{len(sel)} ch x {m} samples vs CPU oracle (streaming state included)"}
+        if world == 1 and not args.no_cpu:
+            cpu = cpu_baseline(taps, pyoracle)
+
+    if args.extra and world == 1:
+        also = extra_paths(torch, filters, capi, dev, stream)
+
+    if rank == 0:
+        achieved = BYTES_PER_SAMPLE * channels * n / (kern_ms * 1e-3) / 1e9      # GB/s, algorithmic bytes
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_fir_ols_f32_bytes_per_launch")
+            except Exception:
+                traffic = None
+        algo_name = {1: "time-domain", 2: "overlap-save-1024"}[fir.algo]
+        line = {
+            "metric": "Msamples/s/GPU (float32 FIR 257-tap, 4096 ch) + achieved HBM GB/s vs peak",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{channels}-ch float32 FIR, {FLT_LEN} taps (llz_fir_lpf_cof 0.1 KAISER), "
+                                   f"{n} samples/ch per GPU, {algo_name}, channels sharded over {world} GPU(s)",
+                       "channels_per_gpu": channels, "samples_per_channel": n, "taps": FLT_LEN,
+                       "algorithm": algo_name, "per_gpu_Msamples_s": value / world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_fir_ols_f32" if fir.algo == 2 else "k_fir_td_f32",
+                         "kernel_ms_avg": kern_ms, "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * channels * n},
+            "cpu_baseline": cpu,
+            "parity": parity,
+        }
+        if also:
+            line["also"] = also
+        print(json.dumps(line), flush=True)
+    fir.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def extra_paths(torch, filters, capi, dev, stream):
+    """Other BASELINE.json configs on one GPU, few steps each (context, not the headline)."""
+    L = capi.lib()
+    sptr = stream.cuda_stream
+    out = {}
+
+    def timeit(fn, steps=3):
+        fn()
+        torch.cuda.synchronize()
+        t = L.llz_hip_timer_new()
+        L.llz_hip_timer_start(t, sptr)
+        for _ in range(steps):
+            fn()
+        L.llz_hip_timer_stop(t, sptr)
+        ms = L.llz_hip_timer_ms(t) / steps
+        L.llz_hip_timer_free(t)
+        return ms
+
+    # config 2: 64 ch x 63 taps x 1 Mi, time domain
+    ch, n = 64, 1 << 20
+    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    filters.synth_f32(x, SEED, stream=stream)
+    f = filters.FirFilterMC(ch, n, filters.fir_design("lpf", 63, 0.25, 0.0, filters.HAMMING), stream=stream)
+    ms = timeit(lambda: f.filter(x, y), 10)
+    out["fir63_64ch"] = {"Msamples_s": ch * n / ms / 1e3, "GBs": 8 * ch * n / ms / 1e6, "ms": ms}
+    f.close()
+    # config 5 shape per GPU at 8 GPUs: 1024 ch x 4 Mi, L=1 M=3
+    ch, n = 1024, 1 << 22
+    n -= n % 3
+    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+    y = torch.empty(ch, n // 3, dtype=torch.float32, device=dev)
+    filters.synth_f32(x, SEED, stream=stream)
+    r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, filters.PCM_F32, stream=stream)
+    ms = timeit(lambda: r.process(x, y), 3)
+    out["resample_1to3_f32_1024ch"] = {"Msamples_in_s": ch * n / ms / 1e3, "GBs": (4 + 4 / 3) * ch * n / ms / 1e6,
+                                       "ms": ms}
+    r.close()
+    del x, y
+    # config 4 shape per GPU at 8 GPUs: 128 ch x 1 Mi, 8 biquads
+    ch, n = 128, 1 << 20
+    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    filters.synth_f32(x, SEED, stream=stream)
+    coef = np.tile(np.array([0.2066, 0.4131, 0.2066, 1.0, -0.3695, 0.1958]), (8, 1))
+    q = filters.IirCascadeMC(ch, coef, stream=stream)
+    ms = timeit(lambda: q.filter(x, y), 1)
+    out["iir8_128ch"] = {"Msamples_s": ch * n / ms / 1e3, "GBs": 8 * ch * n / ms / 1e6, "ms": ms}
+    q.close()
+    return out
+
+
+if __name__ == "__main__":
+    main()
