@@ -10,7 +10,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "libllzfilter_hip.so")
+# LLZ_LIB: load another build of the same library (ablation builds under profiles/; never a fallback)
+LIB_PATH = os.environ.get("LLZ_LIB") or os.path.join(HERE, "libllzfilter_hip.so")
 INCLUDE_DIR = os.path.join(ROOT, "include")
 
 BAD_HANDLE = C.c_ulong(-1).value
