@@ -218,8 +218,8 @@ def extra_paths(torch, filters, capi, dev, stream):
     out["fir63_64ch"] = {"Msamples_s": ch * n / ms / 1e3, "GBs": 8 * ch * n / ms / 1e6, "ms": ms}
     f.close()
     # config 5 shape per GPU at 8 GPUs: 1024 ch x 4 Mi, L=1 M=3
-    ch, n = 1024, 1 << 22
-    n -= n % 3
+    ch = 1024
+    n = 3 * (((1 << 22) // 3) // 256 * 256)            # 4 Mi rounded down to a whole number of 3:1 periods x 256
     x = torch.empty(ch, n, dtype=torch.float32, device=dev)
     y = torch.empty(ch, n // 3, dtype=torch.float32, device=dev)
     filters.synth_f32(x, SEED, stream=stream)

@@ -256,6 +256,8 @@ typedef struct {
     double gain;
     tapmat_t taps;
     void *d_mat;                /* float (F32) or double (I16) L x Q */
+    float *d_phase;             /* F32, L == 1: M x tp phase taps for the polyphase fast path (NULL otherwise) */
+    int tp;
     void *d_hist[2];            /* [channels][Q-1] samples of the handle's format, ping-pong */
     int cur;
     long long in_count, out_count;   /* samples consumed / produced per channel so far */
@@ -269,7 +271,7 @@ static void rsm_destroy(rsm_t *r)
 {
     if (!r) return;
     tapmat_free(&r->taps);
-    llzs_free(r->d_mat); llzs_free(r->d_hist[0]); llzs_free(r->d_hist[1]);
+    llzs_free(r->d_mat); llzs_free(r->d_phase); llzs_free(r->d_hist[0]); llzs_free(r->d_hist[1]);
     llz_stage_release(&r->st_in); llz_stage_release(&r->st_out);
     r->tag = 0;
     free(r);
@@ -283,7 +285,20 @@ static int rsm_upload_matrix(rsm_t *r)
     float *m32 = (float *)malloc(sizeof(float) * count);
     if (!m32) return LLZ_ERR_NOMEM;
     for (size_t i = 0; i < count; i++) m32[i] = (float)r->taps.mat[i];
-    const int rc = llzs_h2d(r->d_mat, m32, sizeof(float) * count, NULL);
+    int rc = llzs_h2d(r->d_mat, m32, sizeof(float) * count, NULL);
+    if (rc == LLZ_OK && r->L == 1) {
+        /* phase taps for the decimator fast path: gp[m][j] = g[0][j*M + m], rows zero padded to tp */
+        const int per_phase = (r->Q + r->M - 1) / r->M;
+        r->tp = (per_phase + 15) & ~15;
+        if (llzs_resample_dec_f32_fits(r->M, r->tp)) {
+            float *gp = (float *)calloc((size_t)r->M * r->tp, sizeof(float));
+            if (!gp) { free(m32); return LLZ_ERR_NOMEM; }
+            for (int k = 0; k < r->Q; k++) gp[(size_t)(k % r->M) * r->tp + k / r->M] = m32[k];
+            if (!r->d_phase) r->d_phase = (float *)llzs_malloc(sizeof(float) * (size_t)r->M * r->tp);
+            rc = r->d_phase ? llzs_h2d(r->d_phase, gp, sizeof(float) * (size_t)r->M * r->tp, NULL) : LLZ_ERR_NOMEM;
+            free(gp);
+        }
+    }
     free(m32);
     return rc;
 }
@@ -419,6 +434,10 @@ long llz_resample_mc(unsigned long handle, const void *in, long n_in, void *out)
             rc = llzs_resample_i16((const short *)d_in, (short *)d_out, (const short *)hist,
                                    (const double *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->L, r->M,
                                    r->Q, r->gain, r->out_count, r->in_count, r->stream);
+        else if (r->d_phase)
+            rc = llzs_resample_dec_f32((const float *)d_in, (float *)d_out, (const float *)hist, r->d_phase,
+                                       r->channels, n_in, n_out, n_in, n_out, r->M, r->Q, r->tp, (float)r->gain,
+                                       r->stream);
         else
             rc = llzs_resample_f32((const float *)d_in, (float *)d_out, (const float *)hist,
                                    (const float *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->L, r->M,

@@ -141,6 +141,111 @@ k_interp_i16(const short *__restrict__ x, short *__restrict__ out, const double 
     out[(size_t)i * L + (L - 1 - m)] = rs_finish(y, gain, (short *)nullptr);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// L = 1 fast path (decimation by M, BASELINE config 5: 48 kHz -> 16 kHz): polyphase in LDS.
+//   y[i] = sum_k g[k] x[iM-k] = sum_{m<M} sum_j g[jM+m] * x_m[i-j],   x_m[n] = x[nM-m]
+// The input tile is de-interleaved into its M phase planes while it is staged (coalesced dword reads, one
+// multiply-high per element to split the index), after which every phase is an ordinary stride-1 FIR and reuses the
+// register sliding window of fir_td.hip: 64 FMAs per two ds_read_b128.  Taps are wave-uniform (scalar cache).
+constexpr int DEC_R = 8;
+constexpr int DEC_TILE = DEC_R * RS_THREADS;        // 2048 outputs per workgroup
+
+__device__ __forceinline__ int dec_phys(int p) { return p + ((p >> 3) << 2); }   // same padding as fir_td.hip
+
+// One workgroup = one channel x 2048 outputs (a persistent, register-prefetching variant was tried and dropped:
+// hipcc spilled the prefetch registers at every launch bound and ran 1.7x slower).
+__global__ void __launch_bounds__(RS_THREADS)
+k_resample_dec_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
+                   const float *__restrict__ gp /* [M][tp] phase taps, zero padded */, long n_in, long n_out,
+                   long in_pitch, long out_pitch, int M, int Q, int tp, float gain, unsigned magic, int plane_pitch)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds_dec[];
+    const int c = blockIdx.y;
+    const int tid = threadIdx.x;
+    const long o0 = (long)blockIdx.x * DEC_TILE;
+    const long base_n = o0 - tp;                               // decimated index of logical position 0
+    const int span = (DEC_TILE + tp) * M;                      // input samples staged
+    const long first = base_n * M - (M - 1);                   // their first index
+    const float *row = in + (size_t)c * in_pitch;
+    const float *hrow = hist ? hist + (size_t)c * (Q - 1) : nullptr;
+    auto scatter = [&](int e, float v) {
+        const int q = (int)__umulhi((unsigned)e, magic);       // e / M  (magic = 2^32/M rounded up, e < 2^16)
+        const int m = M - 1 - (e - q * M);                     // phase of this sample, position q in its plane
+        lds_dec[m * plane_pitch + dec_phys(q)] = v;
+    };
+    if (first >= 0 && first + span <= n_in) {
+        // interior tile: batches of 8 independent, unconditional loads per lane (a load-use-load loop pays the HBM
+        // latency once per element: measured 1.6x slower)
+        const float *src = row + first;
+        for (int e0 = tid; e0 < span; e0 += 8 * RS_THREADS) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = src[min(e0 + u * RS_THREADS, span - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (e0 + u * RS_THREADS < span) scatter(e0 + u * RS_THREADS, v[u]);
+        }
+    } else {
+        for (int e = tid; e < span; e += RS_THREADS) {         // first / last tile of a channel
+            const long idx = first + e;
+            float v = 0.f;
+            if (idx >= 0) {
+                if (idx < n_in) v = row[idx];
+            } else if (hrow && idx >= -(long)(Q - 1)) {
+                v = hrow[(Q - 1) + idx];
+            }
+            scatter(e, v);
+        }
+    }
+    __syncthreads();
+
+    float acc[DEC_R];
+#pragma unroll
+    for (int r = 0; r < DEC_R; r++) acc[r] = 0.f;
+    const int p0 = tp + tid * DEC_R;
+    for (int m = 0; m < M; m++) {
+        const float *plane = lds_dec + m * plane_pitch;
+        const float *taps = gp + m * tp;
+        float wa[8], wb[8];
+        auto load8 = [&](float (&w)[8], int p) {
+            const float4 a = *reinterpret_cast<const float4 *>(&plane[dec_phys(p)]);
+            const float4 b = *reinterpret_cast<const float4 *>(&plane[dec_phys(p + 4)]);
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+            w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        };
+        auto mac8 = [&](const float (&lo)[8], const float (&hi)[8], const float *h8) {
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) {
+                const float h = h8[kk];
+#pragma unroll
+                for (int r = 0; r < DEC_R; r++) {
+                    const int slot = 8 + r - kk;
+                    acc[r] = __builtin_fmaf(h, slot >= 8 ? hi[slot - 8] : lo[slot], acc[r]);
+                }
+            }
+        };
+        load8(wa, p0);
+        for (int kc = 0; kc < tp; kc += 16) {
+            load8(wb, p0 - kc - 8);
+            mac8(wb, wa, taps + kc);
+            load8(wa, p0 - kc - 16);
+            mac8(wa, wb, taps + kc + 8);
+        }
+    }
+    float *orow = out + (size_t)c * out_pitch;
+    const long oi = o0 + (long)tid * DEC_R;
+    if (oi + DEC_R <= n_out && ((out_pitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+        *reinterpret_cast<float4 *>(orow + oi) = make_float4(acc[0] * gain, acc[1] * gain, acc[2] * gain, acc[3] * gain);
+        *reinterpret_cast<float4 *>(orow + oi + 4) =
+            make_float4(acc[4] * gain, acc[5] * gain, acc[6] * gain, acc[7] * gain);
+    } else {
+#pragma unroll
+        for (int r = 0; r < DEC_R; r++)
+            if (oi + r < n_out) orow[oi + r] = acc[r] * gain;
+    }
+}
+
 template <typename T>
 int launch_resample(const T *in, T *out, const T *hist, const typename rs_traits<T>::tap_t *g, int channels,
                     long n_in, long n_out, long in_pitch, long out_pitch, int L, int M, int Q,
@@ -226,4 +331,37 @@ extern "C" int llzs_interp_i16(const short *x, short *out, const double *p, int 
                        x, out, p, L, K, num_in, gain);
     LLZ_LAUNCH_CHECK("k_interp_i16");
     return LLZ_OK;
+}
+
+// phase taps gp[m][j] = g[j*M + m], rows padded with zeros to tp (multiple of 16); see k_resample_dec_f32
+extern "C" int llzs_resample_dec_f32(const float *in, float *out, const float *hist, const float *gp, int channels,
+                                     long n_in, long n_out, long in_pitch, long out_pitch, int M, int Q, int tp,
+                                     float gain, void *stream)
+{
+    if (!in || !out || !gp || channels <= 0 || channels > 65535 || n_in <= 0 || n_out <= 0 || M < 1 || Q < 1 ||
+        tp < 16 || (tp & 15) || in_pitch < n_in || out_pitch < n_out) {
+        llzs_set_error("resample_dec_f32: bad arguments");
+        return LLZ_ERR_ARG;
+    }
+    int plane = DEC_TILE + tp;
+    plane = plane + (plane >> 3) * 4 + 4;                      // dec_phys image of one plane ...
+    while ((plane & 31) != 12) plane += 4;                     // ... phases start 12 banks apart, 16-byte aligned
+    const size_t lds = (size_t)plane * M * sizeof(float);
+    if (lds > 64 * 1024) {
+        llzs_set_error("resample_dec_f32: M=%d needs %zu B of LDS (fast path limit 64 KiB)", M, lds);
+        return LLZ_ERR_RANGE;
+    }
+    const unsigned magic = (unsigned)((0x100000000ull + (unsigned)M - 1) / (unsigned)M);
+    dim3 grid((unsigned)((n_out + DEC_TILE - 1) / DEC_TILE), (unsigned)channels);
+    hipLaunchKernelGGL(k_resample_dec_f32, grid, dim3(RS_THREADS), lds, as_stream(stream), in, out, hist, gp, n_in,
+                       n_out, in_pitch, out_pitch, M, Q, tp, gain, magic, plane);
+    LLZ_LAUNCH_CHECK("k_resample_dec_f32");
+    return LLZ_OK;
+}
+
+extern "C" int llzs_resample_dec_f32_fits(int M, int tp)
+{
+    int plane = DEC_TILE + tp;
+    plane = plane + (plane >> 3) * 4 + 4 + 32;
+    return (size_t)plane * M * sizeof(float) <= 64 * 1024;
 }

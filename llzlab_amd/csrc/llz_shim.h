@@ -62,6 +62,12 @@ int llzs_iir_df1_f64(const double *in, double *out, const double *a, const doubl
 int llzs_resample_f32(const float *in, float *out, const float *hist, const float *g,
                       int channels, long n_in, long n_out, long in_pitch, long out_pitch,
                       int L, int M, int Q, float gain, long long i0, long long in0, void *stream);
+/* L = 1 (decimate by M) float32 fast path: gp = M x tp phase taps gp[m][j] = g[j*M+m], zero padded, tp % 16 == 0;
+ * input index of output i is i*M (calls start on a period boundary); hist as above. */
+int llzs_resample_dec_f32(const float *in, float *out, const float *hist, const float *gp, int channels,
+                          long n_in, long n_out, long in_pitch, long out_pitch, int M, int Q, int tp,
+                          float gain, void *stream);
+int llzs_resample_dec_f32_fits(int M, int tp);     /* 1 when the fast path's LDS image fits */
 /* int16 PCM, double taps, double accumulate in ascending k with separate multiply and add, clamp, truncate */
 int llzs_resample_i16(const short *in, short *out, const short *hist, const double *g,
                       int channels, long n_in, long n_out, long in_pitch, long out_pitch,

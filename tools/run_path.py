@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Run one path a few times (for rocprofv3):  python3 tools/run_path.py {resample|fir_td|fir_ols|iir|resample_i16} [steps]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from llzlab_amd import capi, filters  # noqa: E402
+
+what = sys.argv[1]
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+capi.check(capi.lib().llz_hip_set_device(0), "set_device")
+if what == "resample":
+    ch = 1024
+    n = 3 * (((1 << 22) // 3) // 256 * 256)
+    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+    y = torch.empty(ch, n // 3, dtype=torch.float32, device=dev)
+    filters.synth_f32(x, 1)
+    r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, filters.PCM_F32)
+    for _ in range(steps):
+        r.process(x, y)
+elif what == "resample_i16":
+    ch = 256
+    n = 3 * (((1 << 22) // 3) // 256 * 256)
+    x = torch.empty(ch, n, dtype=torch.int16, device=dev)
+    y = torch.empty(ch, n // 3, dtype=torch.int16, device=dev)
+    filters.synth_i16(x, 1)
+    r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, filters.PCM_I16)
+    for _ in range(steps):
+        r.process(x, y)
+elif what in ("fir_td", "fir_ols"):
+    ch, n = 4096, 1 << 20
+    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    filters.synth_f32(x, 1)
+    f = filters.FirFilterMC(ch, n, filters.fir_design("lpf", 257, 0.1, 0.0, filters.KAISER),
+                            algo=1 if what == "fir_td" else 2)
+    for _ in range(steps):
+        f.filter(x, y)
+elif what == "iir":
+    ch, n = 1024, 1 << 20
+    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    filters.synth_f32(x, 1)
+    coef = np.tile(np.array([0.2066, 0.4131, 0.2066, 1.0, -0.3695, 0.1958]), (8, 1))
+    q = filters.IirCascadeMC(ch, coef)
+    for _ in range(steps):
+        q.filter(x, y)
+torch.cuda.synchronize()
+print("done", what)
