@@ -105,6 +105,7 @@ typedef struct {
     int tag;
     int channels, stages;
     double *d_coef;      /* stages x {b0,b1,b2,a1,a2} */
+    double *d_pd, *d_pl; /* state-transition powers for the pipelined kernel: [S][6][4] and [S][64][4] */
     double *d_state;     /* [channels][stages][x1,x2,y1,y2] */
     void *stream;
     llz_stage_t st_in, st_out;
@@ -113,10 +114,47 @@ typedef struct {
 static void iirm_destroy(iirm_t *f)
 {
     if (!f) return;
-    llzs_free(f->d_coef); llzs_free(f->d_state);
+    llzs_free(f->d_coef); llzs_free(f->d_state); llzs_free(f->d_pd); llzs_free(f->d_pl);
     llz_stage_release(&f->st_in); llz_stage_release(&f->st_out);
     f->tag = 0;
     free(f);
+}
+
+static void mat2_mul(const double *a, const double *b, double *o)
+{
+    const double r0 = a[0] * b[0] + a[1] * b[2], r1 = a[0] * b[1] + a[1] * b[3];
+    const double r2 = a[2] * b[0] + a[3] * b[2], r3 = a[2] * b[1] + a[3] * b[3];
+    o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3;
+}
+
+/* transition matrices of the feedback recurrence (y[n-1], y[n-2]) -> 16 samples later, its powers of two for the
+ * lane scan and its lane-th powers: see k_iir_cascade_pipe_f32 */
+static int iirm_build_powers(iirm_t *f, const double *c5)
+{
+    const int S = f->stages;
+    double *pd = (double *)malloc(sizeof(double) * (size_t)S * 6 * 4);
+    double *pl = (double *)malloc(sizeof(double) * (size_t)S * 64 * 4);
+    int rc = (pd && pl) ? LLZ_OK : LLZ_ERR_NOMEM;
+    if (rc == LLZ_OK) {
+        for (int s = 0; s < S; s++) {
+            const double A[4] = {-c5[5 * s + 3], -c5[5 * s + 4], 1.0, 0.0};
+            double P[4] = {1.0, 0.0, 0.0, 1.0};
+            for (int i = 0; i < 16; i++) mat2_mul(A, P, P);            /* P = A^16 */
+            double *d = pd + (size_t)s * 24;
+            memcpy(d, P, sizeof(P));
+            for (int k = 1; k < 6; k++) mat2_mul(d + 4 * (k - 1), d + 4 * (k - 1), d + 4 * k);
+            double *l = pl + (size_t)s * 256;
+            l[0] = 1.0; l[1] = 0.0; l[2] = 0.0; l[3] = 1.0;
+            for (int k = 1; k < 64; k++) mat2_mul(P, l + 4 * (k - 1), l + 4 * k);
+        }
+        f->d_pd = (double *)llzs_malloc(sizeof(double) * (size_t)S * 24);
+        f->d_pl = (double *)llzs_malloc(sizeof(double) * (size_t)S * 256);
+        rc = (f->d_pd && f->d_pl) ? LLZ_OK : LLZ_ERR_NOMEM;
+        if (rc == LLZ_OK) rc = llzs_h2d(f->d_pd, pd, sizeof(double) * (size_t)S * 24, NULL);
+        if (rc == LLZ_OK) rc = llzs_h2d(f->d_pl, pl, sizeof(double) * (size_t)S * 256, NULL);
+    }
+    free(pd); free(pl);
+    return rc;
 }
 
 unsigned long llz_iir_cascade_mc_init(int channels, int stages, const double *coef)
@@ -143,6 +181,7 @@ unsigned long llz_iir_cascade_mc_init(int channels, int stages, const double *co
     }
     if (rc == LLZ_OK) rc = llzs_h2d(f->d_coef, c5, sizeof(double) * 5 * (size_t)stages, NULL);
     if (rc == LLZ_OK) rc = llzs_memset(f->d_state, 0, st_bytes, NULL);
+    if (rc == LLZ_OK) rc = iirm_build_powers(f, c5);
     if (rc == LLZ_OK) rc = llzs_sync(NULL);
     free(c5);
     if (rc != LLZ_OK) {
@@ -188,9 +227,16 @@ int llz_iir_cascade_mc(unsigned long handle, const float *x, float *y, int frame
         d_out = (float *)llz_stage_reserve(&f->st_out, bytes);
         if (!d_out) return LLZ_ERR_NOMEM;
     }
-    if (rc == LLZ_OK)
-        rc = llzs_iir_cascade_f32(d_in, d_out, f->d_coef, f->d_state, f->channels, frame_len, frame_len,
-                                  frame_len, f->stages, f->stream);
+    /* whole 1024-sample chunks go through the pipelined kernel (needs 16-byte aligned rows), the ragged remainder
+     * through the one-lane-per-channel kernel; both read and write the same per-section state */
+    const int aligned = (frame_len % 4 == 0) && (((size_t)d_in | (size_t)d_out) % 16 == 0);
+    const int n_fast = aligned ? frame_len - frame_len % LLZS_IIR_PIPE_CHUNK : 0;
+    if (rc == LLZ_OK && n_fast > 0)
+        rc = llzs_iir_cascade_pipe_f32(d_in, d_out, f->d_coef, f->d_pd, f->d_pl, f->d_state, f->channels, n_fast,
+                                       frame_len, frame_len, f->stages, f->stream);
+    if (rc == LLZ_OK && n_fast < frame_len)
+        rc = llzs_iir_cascade_f32(d_in + n_fast, d_out + n_fast, f->d_coef, f->d_state, f->channels,
+                                  frame_len - n_fast, frame_len, frame_len, f->stages, f->stream);
     if (rc == LLZ_OK && !out_dev) rc = llzs_d2h(y, d_out, bytes, f->stream);
     return rc == LLZ_OK ? frame_len : rc;
 }

@@ -134,6 +134,154 @@ k_iir_cascade_f32(const float *__restrict__ in, float *__restrict__ out, const d
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_iir_cascade_pipe_f32: the fast path.  A recurrence has no parallelism along time inside one section, and 1024
+// channels x one lane each would leave the chip at 1/64 occupancy.  Two independent sources of parallelism are used:
+//
+//  (1) stage pipeline: a workgroup owns ONE channel, wave s runs biquad section s.  Waves march over 1024-sample
+//      chunks in a software pipeline (wave s works on chunk t-s at step t) and hand chunks to the next section through
+//      LDS ([k][lane] layout: the consumer lane reads back exactly what the same lane of the producer wrote, so the
+//      8 KB slots need neither padding nor a transpose).  Section 0 reads float32 from HBM one chunk ahead, the
+//      last section writes float32 back; each lane owns 16 consecutive samples = one 64-byte segment.
+//  (2) lanes along time: inside a chunk lane l owns samples [16 l, 16 l + 16).  The feed-forward part needs no scan
+//      (the two samples in front of a lane come from lane l-1).  The feedback part is an affine map of the 2-vector
+//      (y[n-1], y[n-2]):  after 16 samples  s' = P s + z  with P = A^16, A = [[-a1,-a2],[1,0]], and z the lane's
+//      zero-state response.  A 6-step Hillis-Steele scan over the z vectors with the host-built powers P^(2^d), plus
+//      P^l applied to the chunk's incoming state, gives every lane its exact start state; the lane then runs the true
+//      recurrence from there.  All of it in double: 7 DFMA per sample and section + ~30 per 16 samples for the scan.
+//
+// Bound: FP64 VALU (56 DFMA per sample for 8 sections) is within a factor ~1 of the HBM time for 8 B/sample; the
+// kernel is compute/latency bound, not a streaming kernel.
+constexpr int PIPE_R = 16;                       // samples per lane and chunk
+constexpr int PIPE_CHUNK = 64 * PIPE_R;          // 1024
+
+__device__ __forceinline__ double shfl_up_f64(double v, int d)
+{
+    return __shfl_up(v, d, 64);
+}
+
+__global__ void __launch_bounds__(1024)
+k_iir_cascade_pipe_f32(const float *__restrict__ in, float *__restrict__ out, const double *__restrict__ coef,
+                       const double *__restrict__ pd /* [S][6][4] */, const double *__restrict__ pl /* [S][64][4] */,
+                       double *__restrict__ state, int nchunks, long in_pitch, long out_pitch, int stages)
+{
+    extern __shared__ __attribute__((aligned(16))) double slots[];        // [stages-1][PIPE_CHUNK]: one per section boundary
+    const int lane = threadIdx.x & 63;
+    const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // this wave's section (wave-uniform)
+    const int c = blockIdx.x;
+    const double b0 = coef[5 * s + 0], b1 = coef[5 * s + 1], b2 = coef[5 * s + 2];
+    const double a1 = coef[5 * s + 3], a2 = coef[5 * s + 4];
+    double P[6][4];
+#pragma unroll
+    for (int d = 0; d < 6; d++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) P[d][j] = pd[(s * 6 + d) * 4 + j];
+    const double L00 = pl[(s * 64 + lane) * 4 + 0], L01 = pl[(s * 64 + lane) * 4 + 1];
+    const double L10 = pl[(s * 64 + lane) * 4 + 2], L11 = pl[(s * 64 + lane) * 4 + 3];
+    double *st = state + ((size_t)c * stages + s) * 4;
+    double su1 = st[0], su2 = st[1], sy1 = st[2], sy2 = st[3];           // x(n-1), x(n-2), y(n-1), y(n-2)
+
+    const float *row = in + (size_t)c * in_pitch + lane * PIPE_R;
+    float *orow = out + (size_t)c * out_pitch + lane * PIPE_R;
+    double *my_in = slots + (size_t)(s > 0 ? s - 1 : 0) * PIPE_CHUNK + lane;    // boundary s-1 | s
+    double *my_out = slots + (size_t)s * PIPE_CHUNK + lane;                      // boundary s | s+1 (unused by the last)
+    const bool first = (s == 0), last = (s == stages - 1);
+
+    float4 pre[4];
+    if (first && nchunks > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) pre[q] = *reinterpret_cast<const float4 *>(row + 4 * q);
+    }
+    const int steps = nchunks + stages - 1;
+    for (int t = 0; t < steps; t++) {
+        const int chunk = t - s;
+        const bool active = chunk >= 0 && chunk < nchunks;
+        double u[PIPE_R];
+        if (active) {
+            if (first) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    u[4 * q + 0] = (double)pre[q].x; u[4 * q + 1] = (double)pre[q].y;
+                    u[4 * q + 2] = (double)pre[q].z; u[4 * q + 3] = (double)pre[q].w;
+                }
+                if (chunk + 1 < nchunks) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        pre[q] = *reinterpret_cast<const float4 *>(row + (size_t)(chunk + 1) * PIPE_CHUNK + 4 * q);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < PIPE_R; k++) u[k] = my_in[k * 64];
+            }
+        }
+        __syncthreads();                           // every section has taken its input: slots may be rewritten
+        if (active) {
+            // the two samples in front of this lane: from lane-1, or from the previous chunk for lane 0
+            double um1 = shfl_up_f64(u[PIPE_R - 1], 1), um2 = shfl_up_f64(u[PIPE_R - 2], 1);
+            if (lane == 0) { um1 = su1; um2 = su2; }
+            const double nu1 = __shfl(u[PIPE_R - 1], 63, 64), nu2 = __shfl(u[PIPE_R - 2], 63, 64);
+            // feed-forward part in place: u[k] <- b0 u[k] + b1 u[k-1] + b2 u[k-2]   (same association as the oracle)
+            {
+                double p1 = um1, p2 = um2;
+#pragma unroll
+                for (int k = 0; k < PIPE_R; k++) {
+                    const double x = u[k];
+                    double acc = b0 * x;
+                    acc = __builtin_fma(b1, p1, acc);
+                    acc = __builtin_fma(b2, p2, acc);
+                    u[k] = acc;
+                    p2 = p1; p1 = x;
+                }
+            }
+            // zero-state response of this lane's 16 samples -> z = (y[15], y[14])
+            double z1 = 0.0, z2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < PIPE_R; k++) {
+                double y = __builtin_fma(-a1, z1, u[k]);
+                y = __builtin_fma(-a2, z2, y);
+                z2 = z1; z1 = y;
+            }
+            // inclusive scan of the affine maps over the lanes: z_l <- z_l + P^(2^d) z_(l - 2^d)
+#pragma unroll
+            for (int d = 0; d < 6; d++) {
+                const double q1 = shfl_up_f64(z1, 1 << d), q2 = shfl_up_f64(z2, 1 << d);
+                if (lane >= (1 << d)) {
+                    z1 = __builtin_fma(P[d][0], q1, __builtin_fma(P[d][1], q2, z1));
+                    z2 = __builtin_fma(P[d][2], q1, __builtin_fma(P[d][3], q2, z2));
+                }
+            }
+            // exact state in front of this lane: exclusive prefix + P^lane applied to the chunk's incoming state
+            double e1 = shfl_up_f64(z1, 1), e2 = shfl_up_f64(z2, 1);
+            if (lane == 0) { e1 = 0.0; e2 = 0.0; }
+            double y1 = __builtin_fma(L00, sy1, __builtin_fma(L01, sy2, e1));
+            double y2 = __builtin_fma(L10, sy1, __builtin_fma(L11, sy2, e2));
+            // the true recurrence from that state
+#pragma unroll
+            for (int k = 0; k < PIPE_R; k++) {
+                double y = __builtin_fma(-a1, y1, u[k]);
+                y = __builtin_fma(-a2, y2, y);
+                u[k] = y;
+                y2 = y1; y1 = y;
+            }
+            su1 = nu1; su2 = nu2;
+            sy1 = __shfl(y1, 63, 64); sy2 = __shfl(y2, 63, 64);
+            if (last) {
+                float *dst = orow + (size_t)chunk * PIPE_CHUNK;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    *reinterpret_cast<float4 *>(dst + 4 * q) = make_float4((float)u[4 * q], (float)u[4 * q + 1],
+                                                                            (float)u[4 * q + 2], (float)u[4 * q + 3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < PIPE_R; k++) my_out[k * 64] = u[k];
+            }
+        }
+        __syncthreads();                           // outputs visible before the next step's reads
+    }
+    if (lane == 0) { st[0] = su1; st[1] = su2; st[2] = sy1; st[3] = sy2; }
+}
+
 } // namespace
 
 extern "C" int llzs_iir_df1_f64(const double *in, double *out, const double *a, const double *b, double *xs,
@@ -170,5 +318,28 @@ extern "C" int llzs_iir_cascade_f32(const float *in, float *out, const double *c
     else LLZ_CAS_LAUNCH(16);
 #undef LLZ_CAS_LAUNCH
     LLZ_LAUNCH_CHECK("k_iir_cascade_f32");
+    return LLZ_OK;
+}
+
+// pd: [stages][6][4] = P^(2^d) row major, P = A^16; pl: [stages][64][4] = P^lane.  n must be a multiple of 1024 and
+// the rows 16-byte aligned (pitches % 4 == 0); the caller runs the remainder through llzs_iir_cascade_f32.
+extern "C" int llzs_iir_cascade_pipe_f32(const float *in, float *out, const double *coef, const double *pd,
+                                         const double *pl, double *state, int channels, int n, long in_pitch,
+                                         long out_pitch, int stages, void *stream)
+{
+    if (!in || !out || !coef || !pd || !pl || !state || channels <= 0 || n <= 0 || (n % PIPE_CHUNK) ||
+        stages < 1 || stages > 16 || in_pitch < n || out_pitch < n || (in_pitch & 3) || (out_pitch & 3) ||
+        (reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) {
+        llzs_set_error("iir_cascade_pipe_f32: bad arguments (n=%d must be a multiple of %d, rows 16-byte aligned)", n,
+                       PIPE_CHUNK);
+        return LLZ_ERR_ARG;
+    }
+    const size_t lds = (size_t)(stages > 1 ? stages - 1 : 1) * PIPE_CHUNK * sizeof(double);
+    if (lds > 64 * 1024)
+        LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_iir_cascade_pipe_f32),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_iir_cascade_pipe_f32, dim3((unsigned)channels), dim3(64 * stages), lds, as_stream(stream),
+                       in, out, coef, pd, pl, state, n / PIPE_CHUNK, in_pitch, out_pitch, stages);
+    LLZ_LAUNCH_CHECK("k_iir_cascade_pipe_f32");
     return LLZ_OK;
 }

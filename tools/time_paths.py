@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Event-timed secondary paths on one GPU: python tools/time_paths.py [iir] [resample] [fir63] [td257]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from llzlab_amd import capi, filters  # noqa: E402
+
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+L = capi.lib()
+capi.check(L.llz_hip_set_device(0), "set_device")
+stream = torch.cuda.current_stream()
+sptr = stream.cuda_stream
+
+
+def timeit(fn, steps):
+    fn()
+    torch.cuda.synchronize()
+    t = L.llz_hip_timer_new()
+    L.llz_hip_timer_start(t, sptr)
+    for _ in range(steps):
+        fn()
+    L.llz_hip_timer_stop(t, sptr)
+    ms = L.llz_hip_timer_ms(t) / steps
+    L.llz_hip_timer_free(t)
+    return ms
+
+
+which = sys.argv[1:] or ["iir", "resample", "fir63", "td257"]
+if "iir" in which:
+    for ch in (1024, 128):
+        n = 1 << 20
+        x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+        y = torch.empty_like(x)
+        filters.synth_f32(x, 1, stream=stream)
+        for name, row in (("r0.44", [0.2066, 0.4131, 0.2066, 1.0, -0.3695, 0.1958]),
+                          ("r0.99", [0.01, 0.0, -0.01, 1.0, -2 * 0.99 * np.cos(0.3), 0.99 ** 2])):
+            q = filters.IirCascadeMC(ch, np.tile(np.array(row), (8, 1)), stream=stream)
+            ms = timeit(lambda: q.filter(x, y), 5)
+            print(f"iir8 {name} {ch}ch x {n}: {ms:.3f} ms  {ch * n / ms / 1e3:.0f} Msamples/s  {8 * ch * n / ms / 1e6:.0f} GB/s "
+                  f"({8 * ch * n / ms / 1e6 / 80:.1f} % of 8 TB/s)")
+            q.close()
+        del x, y
+if "resample" in which:
+    for ch in (8192, 1024):
+        n = 3 * (((1 << 22) // 3) // 256 * 256)
+        x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+        y = torch.empty(ch, n // 3, dtype=torch.float32, device=dev)
+        filters.synth_f32(x, 1, stream=stream)
+        r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, filters.PCM_F32, stream=stream)
+        ms = timeit(lambda: r.process(x, y), 3)
+        gb = (4 + 4 / 3) * ch * n / ms / 1e6
+        print(f"resample 1:3 f32 {ch}ch x {n}: {ms:.3f} ms  {ch * n / ms / 1e3:.0f} Msamples_in/s  {gb:.0f} GB/s ({gb / 80:.1f} %)")
+        r.close()
+        del x, y
+if "fir63" in which:
+    for ch in (64, 4096):
+        n = 1 << 20
+        x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+        y = torch.empty_like(x)
+        filters.synth_f32(x, 1, stream=stream)
+        f = filters.FirFilterMC(ch, n, filters.fir_design("lpf", 63, 0.25, 0.0, filters.HAMMING), stream=stream)
+        ms = timeit(lambda: f.filter(x, y), 10)
+        print(f"fir63 td {ch}ch x {n}: {ms:.3f} ms  {ch * n / ms / 1e3:.0f} Msamples/s  {8 * ch * n / ms / 1e6:.0f} GB/s "
+              f"({8 * ch * n / ms / 1e6 / 80:.1f} %)")
+        f.close()
+        del x, y
+if "td257" in which:
+    ch, n = 4096, 1 << 20
+    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    filters.synth_f32(x, 1, stream=stream)
+    f = filters.FirFilterMC(ch, n, filters.fir_design("lpf", 257, 0.1, 0.0, filters.KAISER), algo=1, stream=stream)
+    ms = timeit(lambda: f.filter(x, y), 3)
+    print(f"fir257 td {ch}ch x {n}: {ms:.3f} ms  {8 * ch * n / ms / 1e6:.0f} GB/s")
+    f.close()
