@@ -161,7 +161,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_fir_ols_f32_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("headline_kernel_bytes_per_launch")
             except Exception:
                 traffic = None
         algo_name = {1: "time-domain", 2: "overlap-save-1024"}[fir.algo]
@@ -176,7 +176,7 @@ def main():
                        "algorithm": algo_name, "per_gpu_Msamples_s": value / world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_fir_ols_f32" if fir.algo == 2 else "k_fir_td_f32",
+                         "kernel": "k_fir_ols_walk_f32" if fir.algo == 2 else "k_fir_td_f32",
                          "kernel_ms_avg": kern_ms, "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * channels * n},
             "cpu_baseline": cpu,
             "parity": parity,

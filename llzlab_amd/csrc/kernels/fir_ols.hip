@@ -368,6 +368,8 @@ __device__ __forceinline__ void walk_load(ols_raw &raw, const float *row, int s,
             raw.b[i] = row[s + OLS_VALID + 32 * i + l5];
         }
     } else {
+        // (also taken by the prefetch past the end of a segment: those loads are issued and discarded on purpose --
+        // skipping them with a wave-uniform branch measured 8 % SLOWER, 7.4 vs 6.8 ms; they cost 1/16 extra reads)
 #pragma unroll
         for (int i = 0; i < 24; i++) {
             const int ia = s + 32 * i + l5, ib = ia + OLS_VALID;

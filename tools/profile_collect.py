@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/profile_<tag>/ into the committed summaries under profiles/ (kernel stats csv, bench line,
+PMC traffic json, SQ counter table)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "profile_" + tag)
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(glob.glob(src + "/stats/*/*_kernel_stats.csv")[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+for name in ("bench.json", "bench_under_rocprof.json"):
+    line = [l for l in open(os.path.join(src, name)) if l.startswith("{")][0]
+    open(os.path.join(dst, f"{tag}_{name}"), "w").write(line)
+bench = json.loads([l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][0])
+kern = bench["roofline"]["kernel"]
+
+
+def counters(sub):
+    f = glob.glob(f"{src}/{sub}/*/*_counter_collection.csv")[0]
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def pick(agg, needle):
+    for k, v in agg.items():
+        if needle in k:
+            return {c: sum(x) / len(x) for c, x in v.items()}, {c: len(x) for c, x in v.items()}
+    return {}, {}
+
+
+fetch, nf = pick(counters("pmc_fetch"), kern)
+write, nw = pick(counters("pmc_write"), kern)
+tailf, _ = pick(counters("pmc_fetch"), "k_fir_tail_f32")
+synw, _ = pick(counters("pmc_write"), "k_synth_f32")
+out = {
+    "kernel": kern,
+    "FETCH_SIZE_KB_per_launch_raw": fetch["FETCH_SIZE"], "FETCH_SIZE_launches": nf["FETCH_SIZE"],
+    "WRITE_SIZE_KB_per_launch_raw": write["WRITE_SIZE"], "WRITE_SIZE_launches": nw["WRITE_SIZE"],
+    "fetch_bytes_per_launch_corrected_x2": 2 * fetch["FETCH_SIZE"] * 1024,
+    "write_bytes_per_launch": write["WRITE_SIZE"] * 1024,
+    "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+    "calibration": {
+        "k_fir_tail_f32_FETCH_SIZE_KB_raw": tailf.get("FETCH_SIZE"),
+        "k_fir_tail_f32_true_read_bytes": 4096 * 256 * 4,
+        "k_synth_f32_WRITE_SIZE_KB_raw": synw.get("WRITE_SIZE"),
+        "k_synth_f32_true_write_bytes": 4096 * (1 << 20) * 4,
+    },
+    "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 3 "
+            "--warmup 1 --no-cpu`; counter unit KB; FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM section) prescribes "
+            "for gfx950 -- the factor is re-checked here on k_fir_tail_f32 (known read bytes, dword-per-lane coalesced "
+            "like the headline kernel) and WRITE_SIZE on k_synth_f32 (known write bytes)",
+}
+out["headline_kernel_bytes_per_launch"] = out["fetch_bytes_per_launch_corrected_x2"] + out["write_bytes_per_launch"]
+json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+sq = {}
+for sub in ("pmc_sq1", "pmc_sq2"):
+    v, _ = pick(counters(sub), kern)
+    sq.update(v)
+with open(os.path.join(dst, f"{tag}_sq_counters.json"), "w") as f:
+    json.dump({"kernel": kern, "per_launch_average": sq,
+               "command": "rocprofv3 --pmc <8 counters> -- python3 bench.py --steps 3 --warmup 1 --no-cpu (two passes)"},
+              f, indent=1)
+print(json.dumps(out, indent=1))
+print(json.dumps(sq, indent=1))
