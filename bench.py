@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--algo", type=int, default=0, help="0 auto (overlap-save), 1 time domain, 2 overlap-save")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--extra", action="store_true", help="also time resample / IIR / 63-tap FIR (reported under 'also')")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="process-group backend; 'gloo' lets several ranks rehearse on ONE GPU (tables travel as CPU tensors)")
     args = ap.parse_args()
 
     import torch
@@ -82,17 +84,29 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    capi.check(capi.lib().llz_hip_set_device(local_rank), "llz_hip_set_device")
+    dev_index = local_rank % torch.cuda.device_count()           # == local_rank on a real multi-GPU node
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    capi.check(capi.lib().llz_hip_set_device(dev_index), "llz_hip_set_device")
+    comm_dev = dev if args.dist_backend == "nccl" else None       # where the tiny setup collectives live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
+
+    def barrier():
+        if world > 1:
+            if args.dist_backend == "nccl":
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
 
     channels, n = args.channels, args.samples
     # rank 0 designs the tap set (host C: llz_fir_lpf_cof(257, 0.1, KAISER)); everyone else receives it over RCCL
     taps = filters.fir_design("lpf", FLT_LEN, 0.1, 0.0, filters.KAISER) if rank == 0 else np.zeros(FLT_LEN)
-    taps = shard.broadcast_table(taps, src=0, device=dev)
+    taps = shard.broadcast_table(taps, src=0, device=comm_dev)
 
     stream = torch.cuda.current_stream()
     x = torch.empty(channels, n, dtype=torch.float32, device=dev)
@@ -105,8 +119,7 @@ def main():
     for _ in range(args.warmup):
         fir.filter(x, y)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
 
     # per-launch device time of the dominant kernel: HIP events on the stream the kernel runs on
@@ -117,11 +130,10 @@ def main():
         fir.filter(x, y)
         L.llz_hip_timer_stop(timers[k], sptr)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    wall = shard.max_over_ranks(wall, device=dev)
+    wall = shard.max_over_ranks(wall, device=comm_dev)
     launch_ms = [L.llz_hip_timer_ms(t) for t in timers]
     for t in timers:
         L.llz_hip_timer_free(t)
@@ -186,7 +198,7 @@ def main():
         print(json.dumps(line), flush=True)
     fir.close()
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 
