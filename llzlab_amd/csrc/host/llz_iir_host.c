@@ -105,7 +105,7 @@ typedef struct {
     int tag;
     int channels, stages;
     double *d_coef;      /* stages x {b0,b1,b2,a1,a2} */
-    double *d_pd, *d_pl; /* state-transition powers for the pipelined kernel: [S][6][4] and [S][64][4] */
+    double *d_pd, *d_pl; /* state-transition powers for the pipelined kernel: [S][6][4] and [S][64][12] */
     double *d_state;     /* [channels][stages][x1,x2,y1,y2] */
     void *stream;
     llz_stage_t st_in, st_out;
@@ -133,7 +133,7 @@ static int iirm_build_powers(iirm_t *f, const double *c5)
 {
     const int S = f->stages;
     double *pd = (double *)malloc(sizeof(double) * (size_t)S * 6 * 4);
-    double *pl = (double *)malloc(sizeof(double) * (size_t)S * 64 * 4);
+    double *pl = (double *)malloc(sizeof(double) * (size_t)S * 64 * 12);
     int rc = (pd && pl) ? LLZ_OK : LLZ_ERR_NOMEM;
     if (rc == LLZ_OK) {
         for (int s = 0; s < S; s++) {
@@ -143,15 +143,21 @@ static int iirm_build_powers(iirm_t *f, const double *c5)
             double *d = pd + (size_t)s * 24;
             memcpy(d, P, sizeof(P));
             for (int k = 1; k < 6; k++) mat2_mul(d + 4 * (k - 1), d + 4 * (k - 1), d + 4 * k);
-            double *l = pl + (size_t)s * 256;
-            l[0] = 1.0; l[1] = 0.0; l[2] = 0.0; l[3] = 1.0;
-            for (int k = 1; k < 64; k++) mat2_mul(P, l + 4 * (k - 1), l + 4 * k);
+            double pw[65][4];                                          /* P^0 .. P^64 */
+            pw[0][0] = 1.0; pw[0][1] = 0.0; pw[0][2] = 0.0; pw[0][3] = 1.0;
+            for (int k = 1; k <= 64; k++) mat2_mul(P, pw[k - 1], pw[k]);
+            for (int lane = 0; lane < 64; lane++) {                    /* per lane: P^lane, P^(lane%16+1), P^(lane%32+1) */
+                double *l = pl + ((size_t)s * 64 + lane) * 12;
+                memcpy(l, pw[lane], sizeof(pw[0]));
+                memcpy(l + 4, pw[lane % 16 + 1], sizeof(pw[0]));
+                memcpy(l + 8, pw[lane % 32 + 1], sizeof(pw[0]));
+            }
         }
         f->d_pd = (double *)llzs_malloc(sizeof(double) * (size_t)S * 24);
-        f->d_pl = (double *)llzs_malloc(sizeof(double) * (size_t)S * 256);
+        f->d_pl = (double *)llzs_malloc(sizeof(double) * (size_t)S * 768);
         rc = (f->d_pd && f->d_pl) ? LLZ_OK : LLZ_ERR_NOMEM;
         if (rc == LLZ_OK) rc = llzs_h2d(f->d_pd, pd, sizeof(double) * (size_t)S * 24, NULL);
-        if (rc == LLZ_OK) rc = llzs_h2d(f->d_pl, pl, sizeof(double) * (size_t)S * 256, NULL);
+        if (rc == LLZ_OK) rc = llzs_h2d(f->d_pl, pl, sizeof(double) * (size_t)S * 768, NULL);
     }
     free(pd); free(pl);
     return rc;

@@ -156,14 +156,31 @@ k_iir_cascade_f32(const float *__restrict__ in, float *__restrict__ out, const d
 constexpr int PIPE_R = 16;                       // samples per lane and chunk
 constexpr int PIPE_CHUNK = 64 * PIPE_R;          // 1024
 
-__device__ __forceinline__ double shfl_up_f64(double v, int d)
+// cross-lane moves of a double as two DPP dword moves (VALU, no LDS round trip). Lanes whose source is out of
+// range, or whose row is masked off, receive 0.0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v)
 {
-    return __shfl_up(v, d, 64);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_ROW_SHR = 0x110;     // + n: shift right by n inside each row of 16 lanes
+constexpr int DPP_WAVE_SHR1 = 0x138;   // whole-wave shift right by one lane
+constexpr int DPP_BCAST15 = 0x142;     // lane 15 of each row -> the next row
+constexpr int DPP_BCAST31 = 0x143;     // lane 31 -> rows 2 and 3
+
+__device__ __forceinline__ double lane63_f64(double v)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
 
 __global__ void __launch_bounds__(1024)
 k_iir_cascade_pipe_f32(const float *__restrict__ in, float *__restrict__ out, const double *__restrict__ coef,
-                       const double *__restrict__ pd /* [S][6][4] */, const double *__restrict__ pl /* [S][64][4] */,
+                       const double *__restrict__ pd /* [S][6][4] */, const double *__restrict__ pl /* [S][64][12] */,
                        double *__restrict__ state, int nchunks, long in_pitch, long out_pitch, int stages)
 {
     extern __shared__ __attribute__((aligned(16))) double slots[];        // [stages-1][PIPE_CHUNK]: one per section boundary
@@ -172,13 +189,16 @@ k_iir_cascade_pipe_f32(const float *__restrict__ in, float *__restrict__ out, co
     const int c = blockIdx.x;
     const double b0 = coef[5 * s + 0], b1 = coef[5 * s + 1], b2 = coef[5 * s + 2];
     const double a1 = coef[5 * s + 3], a2 = coef[5 * s + 4];
-    double P[6][4];
+    double P[4][4];                                                       // P^1, P^2, P^4, P^8 (wave-uniform)
 #pragma unroll
-    for (int d = 0; d < 6; d++)
+    for (int d = 0; d < 4; d++)
 #pragma unroll
         for (int j = 0; j < 4; j++) P[d][j] = pd[(s * 6 + d) * 4 + j];
-    const double L00 = pl[(s * 64 + lane) * 4 + 0], L01 = pl[(s * 64 + lane) * 4 + 1];
-    const double L10 = pl[(s * 64 + lane) * 4 + 2], L11 = pl[(s * 64 + lane) * 4 + 3];
+    // per-lane powers: L = P^lane (chunk state), M1 = P^(lane%16 + 1) (row hand-over), M2 = P^(lane%32 + 1) (half)
+    const double *plane_tab = pl + (size_t)(s * 64 + lane) * 12;
+    const double L00 = plane_tab[0], L01 = plane_tab[1], L10 = plane_tab[2], L11 = plane_tab[3];
+    const double M1a = plane_tab[4], M1b = plane_tab[5], M1c = plane_tab[6], M1d = plane_tab[7];
+    const double M2a = plane_tab[8], M2b = plane_tab[9], M2c = plane_tab[10], M2d = plane_tab[11];
     double *st = state + ((size_t)c * stages + s) * 4;
     double su1 = st[0], su2 = st[1], sy1 = st[2], sy2 = st[3];           // x(n-1), x(n-2), y(n-1), y(n-2)
 
@@ -218,9 +238,9 @@ k_iir_cascade_pipe_f32(const float *__restrict__ in, float *__restrict__ out, co
         __syncthreads();                           // every section has taken its input: slots may be rewritten
         if (active) {
             // the two samples in front of this lane: from lane-1, or from the previous chunk for lane 0
-            double um1 = shfl_up_f64(u[PIPE_R - 1], 1), um2 = shfl_up_f64(u[PIPE_R - 2], 1);
+            double um1 = dpp_f64<DPP_WAVE_SHR1, 0xF>(u[PIPE_R - 1]), um2 = dpp_f64<DPP_WAVE_SHR1, 0xF>(u[PIPE_R - 2]);
             if (lane == 0) { um1 = su1; um2 = su2; }
-            const double nu1 = __shfl(u[PIPE_R - 1], 63, 64), nu2 = __shfl(u[PIPE_R - 2], 63, 64);
+            const double nu1 = lane63_f64(u[PIPE_R - 1]), nu2 = lane63_f64(u[PIPE_R - 2]);
             // feed-forward part in place: u[k] <- b0 u[k] + b1 u[k-1] + b2 u[k-2]   (same association as the oracle)
             {
                 double p1 = um1, p2 = um2;
@@ -238,34 +258,45 @@ k_iir_cascade_pipe_f32(const float *__restrict__ in, float *__restrict__ out, co
             double z1 = 0.0, z2 = 0.0;
 #pragma unroll
             for (int k = 0; k < PIPE_R; k++) {
-                double y = __builtin_fma(-a1, z1, u[k]);
-                y = __builtin_fma(-a2, z2, y);
+                // the term with the OLDER output first: one DFMA latency per sample on the critical path, not two
+                const double y = __builtin_fma(-a1, z1, __builtin_fma(-a2, z2, u[k]));
                 z2 = z1; z1 = y;
             }
-            // inclusive scan of the affine maps over the lanes: z_l <- z_l + P^(2^d) z_(l - 2^d)
-#pragma unroll
-            for (int d = 0; d < 6; d++) {
-                const double q1 = shfl_up_f64(z1, 1 << d), q2 = shfl_up_f64(z2, 1 << d);
-                if (lane >= (1 << d)) {
-                    z1 = __builtin_fma(P[d][0], q1, __builtin_fma(P[d][1], q2, z1));
-                    z2 = __builtin_fma(P[d][2], q1, __builtin_fma(P[d][3], q2, z2));
-                }
+            // inclusive scan of the affine maps over the lanes, all with DPP moves:
+            //   inside each row of 16 lanes: z_l <- z_l + P^d z_(l-d), d = 1,2,4,8 (out-of-row sources read as 0)
+#define LLZ_ROW_STEP(D, SH)                                                                                   \
+            {                                                                                                 \
+                const double q1 = dpp_f64<DPP_ROW_SHR + SH, 0xF>(z1), q2 = dpp_f64<DPP_ROW_SHR + SH, 0xF>(z2);   \
+                z1 = __builtin_fma(P[D][0], q1, __builtin_fma(P[D][1], q2, z1));                              \
+                z2 = __builtin_fma(P[D][2], q1, __builtin_fma(P[D][3], q2, z2));                              \
+            }
+            LLZ_ROW_STEP(0, 1) LLZ_ROW_STEP(1, 2) LLZ_ROW_STEP(2, 4) LLZ_ROW_STEP(3, 8)
+#undef LLZ_ROW_STEP
+            //   rows 1 and 3 take the total of the row before them, advanced by (lane%16 + 1) lanes
+            {
+                const double q1 = dpp_f64<DPP_BCAST15, 0xA>(z1), q2 = dpp_f64<DPP_BCAST15, 0xA>(z2);
+                z1 = __builtin_fma(M1a, q1, __builtin_fma(M1b, q2, z1));
+                z2 = __builtin_fma(M1c, q1, __builtin_fma(M1d, q2, z2));
+            }
+            //   the upper half takes the total of the lower half, advanced by (lane%32 + 1) lanes
+            {
+                const double q1 = dpp_f64<DPP_BCAST31, 0xC>(z1), q2 = dpp_f64<DPP_BCAST31, 0xC>(z2);
+                z1 = __builtin_fma(M2a, q1, __builtin_fma(M2b, q2, z1));
+                z2 = __builtin_fma(M2c, q1, __builtin_fma(M2d, q2, z2));
             }
             // exact state in front of this lane: exclusive prefix + P^lane applied to the chunk's incoming state
-            double e1 = shfl_up_f64(z1, 1), e2 = shfl_up_f64(z2, 1);
-            if (lane == 0) { e1 = 0.0; e2 = 0.0; }
+            const double e1 = dpp_f64<DPP_WAVE_SHR1, 0xF>(z1), e2 = dpp_f64<DPP_WAVE_SHR1, 0xF>(z2);
             double y1 = __builtin_fma(L00, sy1, __builtin_fma(L01, sy2, e1));
             double y2 = __builtin_fma(L10, sy1, __builtin_fma(L11, sy2, e2));
             // the true recurrence from that state
 #pragma unroll
             for (int k = 0; k < PIPE_R; k++) {
-                double y = __builtin_fma(-a1, y1, u[k]);
-                y = __builtin_fma(-a2, y2, y);
+                const double y = __builtin_fma(-a1, y1, __builtin_fma(-a2, y2, u[k]));
                 u[k] = y;
                 y2 = y1; y1 = y;
             }
             su1 = nu1; su2 = nu2;
-            sy1 = __shfl(y1, 63, 64); sy2 = __shfl(y2, 63, 64);
+            sy1 = lane63_f64(y1); sy2 = lane63_f64(y2);
             if (last) {
                 float *dst = orow + (size_t)chunk * PIPE_CHUNK;
 #pragma unroll
@@ -321,7 +352,7 @@ extern "C" int llzs_iir_cascade_f32(const float *in, float *out, const double *c
     return LLZ_OK;
 }
 
-// pd: [stages][6][4] = P^(2^d) row major, P = A^16; pl: [stages][64][4] = P^lane.  n must be a multiple of 1024 and
+// pd: [stages][6][4] = P^(2^d) row major, P = A^16; pl: [stages][64][12] = P^lane, P^(lane%16+1), P^(lane%32+1).  n must be a multiple of 1024 and
 // the rows 16-byte aligned (pitches % 4 == 0); the caller runs the remainder through llzs_iir_cascade_f32.
 extern "C" int llzs_iir_cascade_pipe_f32(const float *in, float *out, const double *coef, const double *pd,
                                          const double *pl, double *state, int channels, int n, long in_pitch,

@@ -51,7 +51,7 @@ int llzs_fir_td_f64(const double *in, double *out, const double *hist, const dou
 int llzs_iir_cascade_f32(const float *in, float *out, const double *coef, double *state,
                          int channels, int n, long in_pitch, long out_pitch, int stages, void *stream);
 /* fast path (stage pipeline + lanes along time): n % 1024 == 0, 16-byte aligned rows.  pd = [stages][6][4] powers
- * P^(2^d) of P = A^16 with A = [[-a1,-a2],[1,0]], pl = [stages][64][4] = P^lane; same coef / state layout as above. */
+ * P^(2^d) of P = A^16 with A = [[-a1,-a2],[1,0]], pl = [stages][64][12] = P^lane, P^(lane%16+1), P^(lane%32+1); same coef / state layout as above. */
 #define LLZS_IIR_PIPE_CHUNK 1024
 int llzs_iir_cascade_pipe_f32(const float *in, float *out, const double *coef, const double *pd, const double *pl,
                               double *state, int channels, int n, long in_pitch, long out_pitch, int stages,

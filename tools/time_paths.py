@@ -31,7 +31,7 @@ def timeit(fn, steps):
     return ms
 
 
-which = sys.argv[1:] or ["iir", "resample", "fir63", "td257"]
+which = sys.argv[1:] or ["iir", "resample", "fir63", "td257", "fft"]
 if "iir" in which:
     for ch in (1024, 128):
         n = 1 << 20
@@ -79,3 +79,19 @@ if "td257" in which:
     ms = timeit(lambda: f.filter(x, y), 3)
     print(f"fir257 td {ch}ch x {n}: {ms:.3f} ms  {8 * ch * n / ms / 1e6:.0f} GB/s")
     f.close()
+
+if "fft" in which:
+    for n in (256, 1024, 4096):
+        count = (1 << 26) // n                                   # 512 MiB of complex64 / int32 pairs
+        z = torch.rand(count, 2 * n, dtype=torch.float32, device=dev) * 2 - 1
+        f = filters.FftBatch(n, stream=stream)
+        ms = timeit(lambda: f.fft(z, count), 3)
+        print(f"fft f32 N={n} x {count}: {ms:.3f} ms  {16 * n * count / ms / 1e6:.0f} GB/s ({16 * n * count / ms / 1e6 / 80:.1f} %)")
+        f.close()
+        q = torch.empty(count, 2 * n, dtype=torch.int32, device=dev)
+        q.copy_((z * 1000).to(torch.int32))
+        fx = filters.FftFixed(n, stream=stream)
+        ms = timeit(lambda: fx.fft_batch(q, count), 3)
+        print(f"fft q15 N={n} x {count}: {ms:.3f} ms  {16 * n * count / ms / 1e6:.0f} GB/s ({16 * n * count / ms / 1e6 / 80:.1f} %)")
+        fx.close()
+        del z, q
