@@ -72,7 +72,12 @@ __device__ constexpr int brev5(int r)
     return ((r & 1) << 4) | ((r & 2) << 2) | (r & 4) | ((r & 8) >> 2) | ((r & 16) >> 4);
 }
 
-// 32-point radix-2 decimation-in-frequency FFT on registers; natural order in, v[r] = X[brev5(r)] out
+#ifndef LLZ_OLS_DIT
+#define LLZ_OLS_DIT 1
+#endif
+
+#if !LLZ_OLS_DIT
+// 32-point radix-2 decimation-in-frequency FFT on registers; natural order in, v[r] = X[brev5(r)] out (456 flop)
 template <bool INV>
 __device__ __forceinline__ void fft32(cf (&v)[32])
 {
@@ -91,6 +96,63 @@ __device__ __forceinline__ void fft32(cf (&v)[32])
         }
     }
 }
+#else
+// One decimation-in-time butterfly (a, b) -> (a + w b, a - w b), w = W32^q (forward) or its conjugate (INV), in the
+// Linzer-Feig form: the twiddle's larger component is factored out so that a general butterfly is 6 FMAs instead of
+// 4 multiplies + 6 adds:  w b = c [(b.x - t b.y) + j (b.y + t b.x)],  t = +-s/c  (or the cotangent form when |s| > |c|).
+template <bool INV>
+__device__ __forceinline__ void bfly_dit(cf &a, cf &b, int q)
+{
+    const cf A = a, B = b;
+    if (q == 0) {
+        a = cadd(A, B); b = csub(A, B);
+        return;
+    }
+    if (q == 8) {                               // w = -j (forward), +j (inverse)
+        const cf wb = INV ? cf{-B.y, B.x} : cf{B.y, -B.x};
+        a = cadd(A, wb); b = csub(A, wb);
+        return;
+    }
+    const float c = q <= 8 ? kCos32[q] : -kCos32[16 - q];       // cos(2 pi q / 32)
+    const float s0 = q <= 8 ? kCos32[8 - q] : kCos32[q - 8];    // sin(2 pi q / 32) > 0
+    const float s = INV ? s0 : -s0;                             // w = c + j s
+    float p, g, f;
+    if (c >= s0 || -c >= s0) {                                  // |c| >= |s|: tangent form
+        const float t = s / c;
+        p = __builtin_fmaf(-t, B.y, B.x);
+        g = __builtin_fmaf(t, B.x, B.y);
+        f = c;
+    } else {                                                    // cotangent form: w b = s [(r b.x - b.y) + j (r b.y + b.x)]
+        const float r = c / s;
+        p = __builtin_fmaf(r, B.x, -B.y);
+        g = __builtin_fmaf(r, B.y, B.x);
+        f = s;
+    }
+    a = cf{__builtin_fmaf(f, p, A.x), __builtin_fmaf(f, g, A.y)};
+    b = cf{__builtin_fmaf(-f, p, A.x), __builtin_fmaf(-f, g, A.y)};
+}
+
+// 32-point radix-2 decimation-in-time FFT on registers (388 flop). Same contract as the DIF form above: natural
+// order in, v[r] = X[brev5(r)] out -- both permutations are register renaming.
+template <bool INV>
+__device__ __forceinline__ void fft32(cf (&v)[32])
+{
+    cf w[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) w[i] = v[brev5(i)];
+#pragma unroll
+    for (int half = 1; half <= 16; half <<= 1) {
+        const int tstep = 16 / half;
+#pragma unroll
+        for (int blk = 0; blk < 32; blk += 2 * half) {
+#pragma unroll
+            for (int q = 0; q < half; q++) bfly_dit<INV>(w[blk + q], w[blk + q + half], q * tstep);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 32; r++) v[r] = w[brev5(r)];
+}
+#endif
 
 constexpr int OLS_N = 1024;
 constexpr int OLS_OVERLAP = 256;
