@@ -148,14 +148,19 @@ k_interp_i16(const short *__restrict__ x, short *__restrict__ out, const double 
 // The input tile is de-interleaved into its M phase planes while it is staged (coalesced dword reads, one
 // multiply-high per element to split the index), after which every phase is an ordinary stride-1 FIR and reuses the
 // register sliding window of fir_td.hip: 64 FMAs per two ds_read_b128.  Taps are wave-uniform (scalar cache).
+#ifndef LLZ_DEC_THREADS
+#define LLZ_DEC_THREADS 256
+#endif
 constexpr int DEC_R = 8;
-constexpr int DEC_TILE = DEC_R * RS_THREADS;        // 2048 outputs per workgroup
+constexpr int DEC_THREADS = LLZ_DEC_THREADS;        // (64- and 128-thread workgroups measured 5 % slower: more halo per tile)
+
+constexpr int DEC_TILE = DEC_R * DEC_THREADS;       // outputs per workgroup
 
 __device__ __forceinline__ int dec_phys(int p) { return p + ((p >> 3) << 2); }   // same padding as fir_td.hip
 
 // One workgroup = one channel x 2048 outputs (a persistent, register-prefetching variant was tried and dropped:
 // hipcc spilled the prefetch registers at every launch bound and ran 1.7x slower).
-__global__ void __launch_bounds__(RS_THREADS)
+__global__ void __launch_bounds__(DEC_THREADS)
 k_resample_dec_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
                    const float *__restrict__ gp /* [M][tp] phase taps, zero padded */, long n_in, long n_out,
                    long in_pitch, long out_pitch, int M, int Q, int tp, float gain, unsigned magic, int plane_pitch)
@@ -178,16 +183,16 @@ k_resample_dec_f32(const float *__restrict__ in, float *__restrict__ out, const 
         // interior tile: batches of 8 independent, unconditional loads per lane (a load-use-load loop pays the HBM
         // latency once per element: measured 1.6x slower)
         const float *src = row + first;
-        for (int e0 = tid; e0 < span; e0 += 8 * RS_THREADS) {
+        for (int e0 = tid; e0 < span; e0 += 8 * DEC_THREADS) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = src[min(e0 + u * RS_THREADS, span - 1)];
+            for (int u = 0; u < 8; u++) v[u] = src[min(e0 + u * DEC_THREADS, span - 1)];
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                if (e0 + u * RS_THREADS < span) scatter(e0 + u * RS_THREADS, v[u]);
+                if (e0 + u * DEC_THREADS < span) scatter(e0 + u * DEC_THREADS, v[u]);
         }
     } else {
-        for (int e = tid; e < span; e += RS_THREADS) {         // first / last tile of a channel
+        for (int e = tid; e < span; e += DEC_THREADS) {         // first / last tile of a channel
             const long idx = first + e;
             float v = 0.f;
             if (idx >= 0) {
@@ -353,7 +358,7 @@ extern "C" int llzs_resample_dec_f32(const float *in, float *out, const float *h
     }
     const unsigned magic = (unsigned)((0x100000000ull + (unsigned)M - 1) / (unsigned)M);
     dim3 grid((unsigned)((n_out + DEC_TILE - 1) / DEC_TILE), (unsigned)channels);
-    hipLaunchKernelGGL(k_resample_dec_f32, grid, dim3(RS_THREADS), lds, as_stream(stream), in, out, hist, gp, n_in,
+    hipLaunchKernelGGL(k_resample_dec_f32, grid, dim3(DEC_THREADS), lds, as_stream(stream), in, out, hist, gp, n_in,
                        n_out, in_pitch, out_pitch, M, Q, tp, gain, magic, plane);
     LLZ_LAUNCH_CHECK("k_resample_dec_f32");
     return LLZ_OK;
