@@ -32,6 +32,12 @@ def build(force=False):
         subprocess.check_call(["make", "-s", "-C", HERE, "liboracle.so"])
     if os.path.isdir("/root/reference/libllzfilter") and (force or not os.path.exists(REF_SO)):
         subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+    # the reference's example CLI, against its own sources and against the GPU library (needs the product .so)
+    hip_so = os.path.join(os.path.dirname(HERE), "llzlab_amd", "libllzfilter_hip.so")
+    cli = os.path.join(HERE, "_ref", "llz_resample_hip")
+    if os.path.isdir("/root/reference/example/llz_resample") and os.path.exists(hip_so) and \
+            (force or not os.path.exists(cli) or os.path.getmtime(cli) < os.path.getmtime(hip_so)):
+        subprocess.check_call(["make", "-s", "-C", HERE, "cli"])
 
 
 def have_ref():
