@@ -67,7 +67,9 @@ def main():
     ap.add_argument("--samples", type=int, default=N_SAMPLES)
     ap.add_argument("--algo", type=int, default=0, help="0 auto (overlap-save), 1 time domain, 2 overlap-save")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--extra", action="store_true", help="also time resample / IIR / 63-tap FIR (reported under 'also')")
+    ap.add_argument("--extra", action="store_true", help="also time the 63-tap time-domain FIR on one GPU (under 'also')")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the channel-sharded resample / IIR configs (BASELINE configs 4 and 5) reported under 'also'")
     ap.add_argument("--dist-backend", default="nccl",
                     help="process-group backend; 'gloo' lets several ranks rehearse on ONE GPU (tables travel as CPU tensors)")
     args = ap.parse_args()
@@ -139,6 +141,7 @@ def main():
         L.llz_hip_timer_free(t)
     kern_ms = float(np.mean(launch_ms))
 
+    fir_algo = fir.algo
     ms_per_step = wall / args.steps * 1e3
     samples_per_step = channels * n * world
     value = samples_per_step / (wall / args.steps) / 1e6                  # Msamples/s, whole job
@@ -164,8 +167,14 @@ def main():
         if world == 1 and not args.no_cpu:
             cpu = cpu_baseline(taps, pyoracle)
 
+    # release the FIR batch before the other configs allocate theirs
+    fir.close()
+    del x, y
+    torch.cuda.empty_cache()
+    if not args.no_also:
+        also = sharded_configs(torch, filters, capi, shard, dev, comm_dev, stream, rank, world, barrier)
     if args.extra and world == 1:
-        also = extra_paths(torch, filters, capi, dev, stream)
+        also.update(extra_paths(torch, filters, capi, dev, stream))
 
     if rank == 0:
         achieved = BYTES_PER_SAMPLE * channels * n / (kern_ms * 1e-3) / 1e9      # GB/s, algorithmic bytes
@@ -176,7 +185,7 @@ def main():
                 traffic = json.load(open(tpath)).get("headline_kernel_bytes_per_launch")
             except Exception:
                 traffic = None
-        algo_name = {1: "time-domain", 2: "overlap-save-1024"}[fir.algo]
+        algo_name = {1: "time-domain", 2: "overlap-save-1024"}[fir_algo]
         line = {
             "metric": "Msamples/s/GPU (float32 FIR 257-tap, 4096 ch) + achieved HBM GB/s vs peak",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -188,7 +197,7 @@ def main():
                        "algorithm": algo_name, "per_gpu_Msamples_s": value / world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_fir_ols_walk_f32" if fir.algo == 2 else "k_fir_td_f32",
+                         "kernel": "k_fir_ols_walk_f32" if fir_algo == 2 else "k_fir_td_f32",
                          "kernel_ms_avg": kern_ms, "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * channels * n},
             "cpu_baseline": cpu,
             "parity": parity,
@@ -196,10 +205,73 @@ def main():
         if also:
             line["also"] = also
         print(json.dumps(line), flush=True)
-    fir.close()
     if world > 1:
         barrier()
         dist.destroy_process_group()
+
+
+def sharded_configs(torch, filters, capi, shard, dev, comm_dev, stream, rank, world, barrier):
+    """BASELINE configs 5 and 4 as the north star states them: a FIXED total channel count sharded over the ranks
+    (strong scaling), coefficient tables designed on rank 0 and broadcast (RCCL when the backend is nccl).
+    Reported under 'also'; the headline 'value' is the FIR above."""
+    L = capi.lib()
+    sptr = stream.cuda_stream
+    out = {}
+
+    def timed(fn, steps):
+        fn()
+        torch.cuda.synchronize()
+        barrier()
+        t = L.llz_hip_timer_new()
+        L.llz_hip_timer_start(t, sptr)
+        for _ in range(steps):
+            fn()
+        L.llz_hip_timer_stop(t, sptr)
+        ms = L.llz_hip_timer_ms(t) / steps
+        L.llz_hip_timer_free(t)
+        return shard.max_over_ranks(ms, device=comm_dev)
+
+    # config 5: 8192-ch polyphase resample 48 kHz -> 16 kHz (L=1, M=3), 4 Mi samples/ch
+    total_ch = 8192
+    lo, hi = shard.channel_range(total_ch, rank, world)
+    ch = hi - lo
+    n = 3 * (((1 << 22) // 3) // 256 * 256)            # 4 Mi rounded down to whole 3:1 periods x 256
+    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+    y = torch.empty(ch, n // 3, dtype=torch.float32, device=dev)
+    filters.synth_f32(x, SEED, chan0=lo, stream=stream)
+    r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, filters.PCM_F32, stream=stream)
+    shape = shard.broadcast_shape((1, r.Q) if rank == 0 else (0, 0), device=comm_dev)
+    mat = shard.broadcast_table(r.matrix() if rank == 0 else np.zeros(shape), device=comm_dev)
+    r.set_matrix(mat)                                   # every rank runs with rank 0's tap matrix
+    ms = timed(lambda: r.process(x, y), 3)
+    out["resample_1to3_f32_8192ch_sharded"] = {
+        "Msamples_in_s": total_ch * n / ms / 1e3, "GBs_per_gpu": (4 + 4 / 3) * ch * n / ms / 1e6,
+        "hbm_frac_per_gpu": (4 + 4 / 3) * ch * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "channels_per_gpu": ch,
+        "scaling": "strong"}
+    r.close()
+    del x, y
+    torch.cuda.empty_cache()
+
+    # config 4: 1024-ch IIR, 8-biquad cascade, 1 Mi samples/ch
+    total_ch = 1024
+    lo, hi = shard.channel_range(total_ch, rank, world)
+    ch = hi - lo
+    n = 1 << 20
+    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    filters.synth_f32(x, SEED, chan0=lo, stream=stream)
+    coef = np.tile(np.array([0.2066, 0.4131, 0.2066, 1.0, -0.3695, 0.1958]), (8, 1)) if rank == 0 else np.zeros((8, 6))
+    coef = shard.broadcast_table(coef, device=comm_dev)
+    q = filters.IirCascadeMC(ch, coef, stream=stream)
+    ms = timed(lambda: q.filter(x, y), 3)
+    out["iir8_1024ch_sharded"] = {
+        "Msamples_s": total_ch * n / ms / 1e3, "GBs_per_gpu": 8 * ch * n / ms / 1e6,
+        "hbm_frac_per_gpu": 8 * ch * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "channels_per_gpu": ch,
+        "scaling": "strong"}
+    q.close()
+    del x, y
+    torch.cuda.empty_cache()
+    return out
 
 
 def extra_paths(torch, filters, capi, dev, stream):
@@ -229,28 +301,6 @@ def extra_paths(torch, filters, capi, dev, stream):
     ms = timeit(lambda: f.filter(x, y), 10)
     out["fir63_64ch"] = {"Msamples_s": ch * n / ms / 1e3, "GBs": 8 * ch * n / ms / 1e6, "ms": ms}
     f.close()
-    # config 5 shape per GPU at 8 GPUs: 1024 ch x 4 Mi, L=1 M=3
-    ch = 1024
-    n = 3 * (((1 << 22) // 3) // 256 * 256)            # 4 Mi rounded down to a whole number of 3:1 periods x 256
-    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
-    y = torch.empty(ch, n // 3, dtype=torch.float32, device=dev)
-    filters.synth_f32(x, SEED, stream=stream)
-    r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, filters.PCM_F32, stream=stream)
-    ms = timeit(lambda: r.process(x, y), 3)
-    out["resample_1to3_f32_1024ch"] = {"Msamples_in_s": ch * n / ms / 1e3, "GBs": (4 + 4 / 3) * ch * n / ms / 1e6,
-                                       "ms": ms}
-    r.close()
-    del x, y
-    # config 4 shape per GPU at 8 GPUs: 128 ch x 1 Mi, 8 biquads
-    ch, n = 128, 1 << 20
-    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
-    y = torch.empty_like(x)
-    filters.synth_f32(x, SEED, stream=stream)
-    coef = np.tile(np.array([0.2066, 0.4131, 0.2066, 1.0, -0.3695, 0.1958]), (8, 1))
-    q = filters.IirCascadeMC(ch, coef, stream=stream)
-    ms = timeit(lambda: q.filter(x, y), 1)
-    out["iir8_128ch"] = {"Msamples_s": ch * n / ms / 1e3, "GBs": 8 * ch * n / ms / 1e6, "ms": ms}
-    q.close()
     return out
 
 
