@@ -11,8 +11,8 @@
 //           bit-identical to llz_fft / llz_ifft for the same host-built twiddle table
 //   int32   Q15 twiddles, (int64 a * b) >> 15 per product, wrapping adds: bit-identical to llz_fft_fixed
 //
-// One workgroup per transform; the whole transform lives in LDS (N <= 4096: 32 KB float / 64 KB double);
-// butterflies of a stage are independent, so only a barrier separates stages. Twiddle tables come from the host
+// A workgroup holds 2048 points in LDS (one 2048/4096-point transform or several smaller ones); the log2 N radix-2
+// stages run as 1-3 passes of up to four stages fused in registers (16 elements per lane), a barrier between passes. Twiddle tables come from the host
 // (never recomputed on the device: SURVEY.md H4/H5).
 #include "common.hpp"
 
@@ -89,65 +89,124 @@ struct arith_q15 {
     static __device__ __forceinline__ int scale_out(int v, int log2n) { return v >> log2n; }   // :212-215
 };
 
+// LDS image of one transform: element i lives at i + i/32 (one pad element per 32) so that the strided walks of the
+// late passes and the bit-reversed gather spread over the banks; transforms of a workgroup follow each other.
+__device__ __forceinline__ int fft_phys(int i) { return i + (i >> 5); }
+
+// One pass = G consecutive radix-2 stages done in registers on E = 2^G elements per work item: G barriers fewer than
+// stage-by-stage, and every butterfly still is the reference's butterfly (same operands, same operation order), so
+// the double and Q15 flavours stay bit-identical to llz_fft / llz_fft_fixed.
+//   forward (DIF): stages with half-span hs0, hs0/2, ...;  inverse (DIT): half-span hs0, 2 hs0, ...
+//   element j of an item sits at  blk * (E * step) + j * step + r,   step = distance between the item's elements
+template <typename A, int G, bool INVERSE>
+__device__ __forceinline__ void fft_pass(cpx<typename A::data_t> *s, int tpw, int size, int log2n, int log2step,
+                                         int tstride, const typename A::tw_t *__restrict__ cs, int tid)
+{
+    typedef typename A::data_t T;
+    constexpr int E = 1 << G;
+    const int step = 1 << log2step;
+    const int log2items = log2n - G;                       // items per transform
+    const int items = tpw << log2items;
+    for (int it = tid; it < items; it += FFT_THREADS) {
+        const int tr = it >> log2items, rem = it & ((1 << log2items) - 1);
+        const int r = rem & (step - 1), blk = rem >> log2step;
+        cpx<T> *base = s + tr * tstride;
+        const int i0 = (blk << (G + log2step)) + r;
+        cpx<T> v[E];
+#pragma unroll
+        for (int j = 0; j < E; j++) v[j] = base[fft_phys(i0 + (j << log2step))];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int hj = INVERSE ? (1 << g) : (E >> (g + 1));          // partner distance in elements of the item
+            const int log2hj = INVERSE ? g : (G - 1 - g);
+            const int tshift = (log2n - 1) - (log2step + log2hj);        // twiddle step = (size/2) / (hj*step)
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                if (j & hj) continue;
+                const int q = ((j & (hj - 1)) << log2step) + r;
+                const int idx = q << tshift;
+                const typename A::tw_t wr = cs[idx];
+                const cpx<T> u = v[j], w = v[j + hj];
+                if (!INVERSE) {
+                    const typename A::tw_t wi = A::neg(cs[size + idx]);
+                    cpx<T> x, y;
+                    x.re = A::add(u.re, w.re); x.im = A::add(u.im, w.im);
+                    A::rot(A::sub(u.re, w.re), A::sub(u.im, w.im), wr, wi, y.re, y.im);
+                    v[j] = x; v[j + hj] = y;
+                } else {
+                    const typename A::tw_t wi = cs[size + idx];
+                    T dr, di;
+                    A::rot(w.re, w.im, wr, wi, dr, di);
+                    cpx<T> x, y;
+                    x.re = A::add(u.re, dr); x.im = A::add(u.im, di);
+                    y.re = A::sub(u.re, dr); y.im = A::sub(u.im, di);
+                    v[j] = x; v[j + hj] = y;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < E; j++) base[fft_phys(i0 + (j << log2step))] = v[j];
+    }
+    __syncthreads();
+}
+
+// groups: up to four passes, G of pass p in bits [4p, 4p+4) (0 = no pass). tpw transforms per workgroup.
 template <typename A, bool INVERSE>
 __global__ void __launch_bounds__(FFT_THREADS)
-k_fft_radix2(typename A::data_t *__restrict__ data, int size, int log2n,
-             const typename A::tw_t *__restrict__ cs /* size cos, then size sin */)
+k_fft_radix2(typename A::data_t *__restrict__ data, int count, int size, int log2n,
+             const typename A::tw_t *__restrict__ cs /* size cos, then size sin */, int tpw, unsigned groups)
 {
     typedef typename A::data_t T;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cpx<T> *s = reinterpret_cast<cpx<T> *>(smem_raw);
-    cpx<T> *g = reinterpret_cast<cpx<T> *>(data) + (size_t)blockIdx.x * size;
     const int tid = threadIdx.x;
-    const int half_n = size >> 1;
+    const int tr0 = blockIdx.x * tpw;
+    const int ntr = min(tpw, count - tr0);                 // transforms this workgroup really has
+    cpx<T> *g = reinterpret_cast<cpx<T> *>(data) + (size_t)tr0 * size;
+    const int tstride = fft_phys(size) + 1;
+    const int total = ntr << log2n;
 
-    if (!INVERSE) {
-        for (int i = tid; i < size; i += FFT_THREADS) s[i] = g[i];
-        __syncthreads();
-        // span = distance between partners; twiddle step doubles as the span halves
-        for (int hs = half_n, tstep = 1; hs >= 1; hs >>= 1, tstep <<= 1) {
-            for (int b = tid; b < half_n; b += FFT_THREADS) {
-                const int q = b & (hs - 1);
-                const int lo = ((b - q) << 1) + q, hi = lo + hs;
-                const typename A::tw_t wr = cs[q * tstep], wi = A::neg(cs[size + q * tstep]);
-                const cpx<T> u = s[lo], v = s[hi];
-                cpx<T> x, y;
-                x.re = A::add(u.re, v.re); x.im = A::add(u.im, v.im);
-                A::rot(A::sub(u.re, v.re), A::sub(u.im, v.im), wr, wi, y.re, y.im);
-                s[lo] = x; s[hi] = y;
-            }
-            __syncthreads();
-        }
-        for (int i = tid; i < size; i += FFT_THREADS)
-            g[i] = s[__brev((unsigned)i) >> (32 - log2n)];
-    } else {
-        for (int i = tid; i < size; i += FFT_THREADS) {
-            cpx<T> v = g[__brev((unsigned)i) >> (32 - log2n)];
+    // load (inverse: through the bit-reversal, float flavour divides by N here: llz_fft.c:187-195)
+    for (int e = tid; e < total; e += FFT_THREADS) {
+        const int tr = e >> log2n, i = e & (size - 1);
+        if (!INVERSE) {
+            s[tr * tstride + fft_phys(i)] = g[e];
+        } else {
+            cpx<T> v = g[(tr << log2n) + (int)(__brev((unsigned)i) >> (32 - log2n))];
             v.re = A::scale_in(v.re, size, log2n);
             v.im = A::scale_in(v.im, size, log2n);
-            s[i] = v;
+            s[tr * tstride + fft_phys(i)] = v;
         }
-        __syncthreads();
-        for (int hs = 1, tstep = half_n; hs <= half_n; hs <<= 1, tstep >>= 1) {
-            for (int b = tid; b < half_n; b += FFT_THREADS) {
-                const int q = b & (hs - 1);
-                const int lo = ((b - q) << 1) + q, hi = lo + hs;
-                const typename A::tw_t wr = cs[q * tstep], wi = cs[size + q * tstep];
-                const cpx<T> u = s[lo], v = s[hi];
-                T dr, di;
-                A::rot(v.re, v.im, wr, wi, dr, di);
-                cpx<T> x, y;
-                x.re = A::add(u.re, dr); x.im = A::add(u.im, di);
-                y.re = A::sub(u.re, dr); y.im = A::sub(u.im, di);
-                s[lo] = x; s[hi] = y;
-            }
-            __syncthreads();
+    }
+    __syncthreads();
+
+    int done = 0;                                          // stages finished so far
+#pragma unroll 1
+    for (int p = 0; p < 4; p++) {
+        const int G = (groups >> (4 * p)) & 15;
+        if (G == 0) break;
+        // forward: first stage of the pass has half-span size >> (done+1), elements step = that >> (G-1)
+        // inverse: first stage has half-span 1 << done = step
+        const int log2step = INVERSE ? done : (log2n - done - G);
+        switch (G) {
+        case 1: fft_pass<A, 1, INVERSE>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
+        case 2: fft_pass<A, 2, INVERSE>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
+        case 3: fft_pass<A, 3, INVERSE>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
+        default: fft_pass<A, 4, INVERSE>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
         }
-        for (int i = tid; i < size; i += FFT_THREADS) {
-            cpx<T> v = s[i];
+        done += G;
+    }
+
+    // store (forward: through the bit-reversal gather, llz_fft.c:155-163; fixed inverse: >> log2 N, :212-215)
+    for (int e = tid; e < total; e += FFT_THREADS) {
+        const int tr = e >> log2n, i = e & (size - 1);
+        if (!INVERSE) {
+            g[e] = s[tr * tstride + fft_phys((int)(__brev((unsigned)i) >> (32 - log2n)))];
+        } else {
+            cpx<T> v = s[tr * tstride + fft_phys(i)];
             v.re = A::scale_out(v.re, log2n);
             v.im = A::scale_out(v.im, log2n);
-            g[i] = v;
+            g[e] = v;
         }
     }
 }
@@ -162,19 +221,33 @@ int launch_fft(typename A::data_t *data, int count, int size, const typename A::
         llzs_set_error("%s: size %d must be a power of two in 2..4096 (count %d)", name, size, count);
         return LLZ_ERR_ARG;
     }
-    const size_t lds = (size_t)size * 2 * sizeof(typename A::data_t);
+    // split the log2n stages into ceil(log2n/4) passes of nearly equal depth (10 -> 4+3+3, 12 -> 4+4+4, 6 -> 3+3)
+    const int passes = (log2n + 3) / 4;
+    unsigned groups = 0;
+    for (int p = 0, left = log2n; p < passes; p++) {
+        const int G = (left + (passes - p) - 1) / (passes - p);
+        groups |= (unsigned)G << (4 * p);
+        left -= G;
+    }
+    // 2048 points per workgroup pass (256 lanes x 8): several small transforms share a workgroup
+    int tpw = 2048 / size;
+    if (tpw < 1) tpw = 1;
+    if (tpw > count) tpw = count;
+    const int tstride = size + (size >> 5) + 1;
+    const size_t lds = (size_t)tpw * tstride * 2 * sizeof(typename A::data_t);
     if (lds >= 64 * 1024) {
         LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_radix2<A, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_radix2<A, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
+    const unsigned blocks = (unsigned)((count + tpw - 1) / tpw);
     if (inverse)
-        hipLaunchKernelGGL((k_fft_radix2<A, true>), dim3((unsigned)count), dim3(FFT_THREADS), lds,
-                           as_stream(stream), data, size, log2n, cs);
+        hipLaunchKernelGGL((k_fft_radix2<A, true>), dim3(blocks), dim3(FFT_THREADS), lds, as_stream(stream), data,
+                           count, size, log2n, cs, tpw, groups);
     else
-        hipLaunchKernelGGL((k_fft_radix2<A, false>), dim3((unsigned)count), dim3(FFT_THREADS), lds,
-                           as_stream(stream), data, size, log2n, cs);
+        hipLaunchKernelGGL((k_fft_radix2<A, false>), dim3(blocks), dim3(FFT_THREADS), lds, as_stream(stream), data,
+                           count, size, log2n, cs, tpw, groups);
     LLZ_LAUNCH_CHECK(name);
     return LLZ_OK;
 }
