@@ -297,10 +297,12 @@ def extra_paths(torch, filters, capi, dev, stream):
     x = torch.empty(ch, n, dtype=torch.float32, device=dev)
     y = torch.empty_like(x)
     filters.synth_f32(x, SEED, stream=stream)
-    f = filters.FirFilterMC(ch, n, filters.fir_design("lpf", 63, 0.25, 0.0, filters.HAMMING), stream=stream)
-    ms = timeit(lambda: f.filter(x, y), 10)
-    out["fir63_64ch"] = {"Msamples_s": ch * n / ms / 1e3, "GBs": 8 * ch * n / ms / 1e6, "ms": ms}
-    f.close()
+    taps63 = filters.fir_design("lpf", 63, 0.25, 0.0, filters.HAMMING)
+    for name, algo in (("fir63_64ch_time_domain", filters.FIR_ALGO_TIME), ("fir63_64ch_overlap_save", filters.FIR_ALGO_OVERLAP_SAVE)):
+        f = filters.FirFilterMC(ch, n, taps63, algo=algo, stream=stream)
+        ms = timeit(lambda: f.filter(x, y), 10)
+        out[name] = {"Msamples_s": ch * n / ms / 1e3, "GBs": 8 * ch * n / ms / 1e6, "ms": ms}
+        f.close()
     return out
 
 

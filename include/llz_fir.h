@@ -61,7 +61,7 @@ double llz_conv(const double *x, const double *h, int h_len);
 /* ---- Part 2: multi-channel float32 batch extension ---------------------------------------------- */
 
 enum {
-    LLZ_FIR_ALGO_AUTO = 0,       /* time domain up to 64 taps, overlap-save above (when it fits) */
+    LLZ_FIR_ALGO_AUTO = 0,       /* time domain up to 32 taps, overlap-save for 33..257 (measured crossover) */
     LLZ_FIR_ALGO_TIME = 1,       /* direct form, taps broadcast, input window staged in LDS */
     LLZ_FIR_ALGO_OVERLAP_SAVE = 2 /* 1024-point in-LDS FFT overlap-save, flt_len <= 257 */
 };

@@ -132,7 +132,7 @@ def test_fir_mc_host_pointers_and_errors(dev, oracle):
     taps = oracle.fir_design(po.LPF, 63, 0.25, 0.0, po.HAMMING)
     x = oracle.synth_f32(4, 2048, 5)
     y = np.zeros_like(x)
-    f = filters.FirFilterMC(4, 2048, taps)
+    f = filters.FirFilterMC(4, 2048, taps, algo=filters.FIR_ALGO_TIME)
     assert f.algo == filters.FIR_ALGO_TIME
     f.filter(x, y)                                                     # numpy = host memory, staged by the library
     rms_check(y, oracle.fir_batch_f32(x, taps.astype(np.float32).astype(np.float64)), "host staging")
@@ -142,6 +142,9 @@ def test_fir_mc_host_pointers_and_errors(dev, oracle):
     with pytest.raises(capi.LlzError):
         filters.FirFilterMC(4, 2048, np.ones(300), algo=filters.FIR_ALGO_OVERLAP_SAVE)
     assert filters.FirFilterMC(2, 64, np.ones(257)).algo == filters.FIR_ALGO_OVERLAP_SAVE
+    assert filters.FirFilterMC(2, 64, np.ones(63)).algo == filters.FIR_ALGO_OVERLAP_SAVE      # AUTO: 33..257 taps
+    assert filters.FirFilterMC(2, 64, np.ones(32)).algo == filters.FIR_ALGO_TIME
+    assert filters.FirFilterMC(2, 64, np.ones(300)).algo == filters.FIR_ALGO_TIME
 
 
 def test_fir_linearity_and_impulse_large(dev):

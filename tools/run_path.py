@@ -42,6 +42,14 @@ elif what in ("fir_td", "fir_ols"):
                             algo=1 if what == "fir_td" else 2)
     for _ in range(steps):
         f.filter(x, y)
+elif what == "fir63":
+    ch, n = 4096, 1 << 20
+    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    filters.synth_f32(x, 1)
+    f = filters.FirFilterMC(ch, n, filters.fir_design("lpf", 63, 0.25, 0.0, filters.HAMMING), algo=1)
+    for _ in range(steps):
+        f.filter(x, y)
 elif what == "iir":
     ch, n = 1024, 1 << 20
     x = torch.empty(ch, n, dtype=torch.float32, device=dev)

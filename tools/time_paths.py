@@ -64,7 +64,7 @@ if "fir63" in which:
         x = torch.empty(ch, n, dtype=torch.float32, device=dev)
         y = torch.empty_like(x)
         filters.synth_f32(x, 1, stream=stream)
-        f = filters.FirFilterMC(ch, n, filters.fir_design("lpf", 63, 0.25, 0.0, filters.HAMMING), stream=stream)
+        f = filters.FirFilterMC(ch, n, filters.fir_design("lpf", 63, 0.25, 0.0, filters.HAMMING), algo=1, stream=stream)
         ms = timeit(lambda: f.filter(x, y), 10)
         print(f"fir63 td {ch}ch x {n}: {ms:.3f} ms  {ch * n / ms / 1e3:.0f} Msamples/s  {8 * ch * n / ms / 1e6:.0f} GB/s "
               f"({8 * ch * n / ms / 1e6 / 80:.1f} %)")
