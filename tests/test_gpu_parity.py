@@ -387,3 +387,71 @@ def test_fft_batch_f32_vs_oracle(dev, oracle, n):
     back = zd.cpu().numpy().view(np.complex64)
     assert np.sqrt(np.mean(np.abs(back - z) ** 2)) < 1e-6
     f.close()
+
+
+@pytest.mark.parametrize("n,count", [(2, 5), (4, 3), (16, 130), (32, 65), (128, 17), (512, 5), (2048, 3), (4096, 2)])
+def test_fft_batch_all_sizes_fixed_and_float(dev, oracle, n, count):
+    """every power of two, batch counts that do not fill the last workgroup: Q15 bit-exact, float within tolerance"""
+    rng = np.random.default_rng(n * 1000 + count)
+    q = rng.integers(-8000, 8001, (count, 2 * n)).astype(np.int32)
+    f = filters.FftFixed(n)
+    qd = torch.from_numpy(q).to(dev)
+    f.fft_batch(qd, count)
+    ref = np.stack([oracle.fft_fixed(row) for row in q])
+    assert np.array_equal(qd.cpu().numpy(), ref)
+    f.ifft_batch(qd, count)
+    assert np.array_equal(qd.cpu().numpy(), np.stack([oracle.fft_fixed(row, inverse=True) for row in ref]))
+    f.close()
+    if n >= 8:
+        z = (rng.uniform(-1, 1, (count, n)) + 1j * rng.uniform(-1, 1, (count, n))).astype(np.complex64)
+        zd = torch.from_numpy(z.view(np.float32).copy()).to(dev)
+        fb = filters.FftBatch(n)
+        fb.fft(zd, count)
+        got = zd.cpu().numpy().view(np.complex64)
+        refz = np.stack([oracle.fft(row.astype(np.complex128)) for row in z])
+        assert np.sqrt(np.mean(np.abs(got - refz) ** 2)) / np.sqrt(np.mean(np.abs(refz) ** 2)) < 1e-6
+        fb.ifft(zd, count)
+        assert np.sqrt(np.mean(np.abs(zd.cpu().numpy().view(np.complex64) - z) ** 2)) < 1e-6
+        fb.close()
+
+
+@pytest.mark.parametrize("n", [2, 4, 16, 32, 128, 512, 2048])
+def test_fft_double_exact_vs_oracle_other_sizes(dev, oracle, n):
+    rng = np.random.default_rng(n)
+    z = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    f = filters.Fft(n)
+    assert np.array_equal(f.fft(z), oracle.fft(z))
+    assert np.array_equal(f.ifft(z), oracle.fft(z, inverse=True))
+    f.close()
+
+
+def test_fft_fixed_wraps_like_the_reference_arithmetic(dev, oracle):
+    """large inputs overflow int32 in the forward transform; the oracle wraps explicitly and so does the kernel"""
+    rng = np.random.default_rng(99)
+    q = rng.integers(-(1 << 30), 1 << 30, (3, 2 * 256)).astype(np.int32)
+    f = filters.FftFixed(256)
+    qd = torch.from_numpy(q).to(dev)
+    f.fft_batch(qd, 3)
+    assert np.array_equal(qd.cpu().numpy(), np.stack([oracle.fft_fixed(row) for row in q]))
+    f.close()
+
+
+@pytest.mark.parametrize("channels,n", [(3, 1024 * 5), (2, 1024 * 3 + 777), (130, 2048)])
+def test_iir_cascade_pipelined_path_long(dev, oracle, channels, n):
+    """whole 1024-sample chunks run through the stage-pipelined kernel, the remainder through the per-channel one;
+    two calls in a row exercise the state hand-over between the two"""
+    d = load("iir.npz")
+    coef = np.stack([np.concatenate([d["b2"], d["a2"]]), np.concatenate([d["bq"], d["aq"]]),
+                     np.concatenate([d["b2"], d["a2"]]), np.concatenate([d["bq"], d["aq"]]),
+                     np.concatenate([d["b2"], d["a2"]])])
+    x = oracle.synth_f32(channels, 2 * n, seed=n)
+    ref = oracle.iir_cascade_batch_f32(x, coef)
+    f = filters.IirCascadeMC(channels, coef)
+    outs = []
+    for o in (0, n):
+        xi = torch.from_numpy(np.ascontiguousarray(x[:, o:o + n])).to(dev)
+        yi = torch.empty_like(xi)
+        f.filter(xi, yi)
+        outs.append(yi.cpu().numpy())
+    f.close()
+    rms_check(np.concatenate(outs, axis=1), ref, "pipelined iir, two frames")

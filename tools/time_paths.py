@@ -58,6 +58,30 @@ if "resample" in which:
         print(f"resample 1:3 f32 {ch}ch x {n}: {ms:.3f} ms  {ch * n / ms / 1e3:.0f} Msamples_in/s  {gb:.0f} GB/s ({gb / 80:.1f} %)")
         r.close()
         del x, y
+if "resample_i16" in which:
+    ch = 1024
+    n = 3 * (((1 << 22) // 3) // 256 * 256)
+    x = torch.empty(ch, n, dtype=torch.int16, device=dev)
+    y = torch.empty(ch, n // 3, dtype=torch.int16, device=dev)
+    filters.synth_i16(x, 1, stream=stream)
+    r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, filters.PCM_I16, stream=stream)
+    ms = timeit(lambda: r.process(x, y), 2)
+    gb = (2 + 2 / 3) * ch * n / ms / 1e6
+    print(f"resample 1:3 i16 exact {ch}ch x {n}: {ms:.3f} ms  {ch * n / ms / 1e3:.0f} Msamples_in/s  {gb:.0f} GB/s ({gb / 80:.1f} %)")
+    r.close()
+    del x, y
+    for (L_, M_) in ((2, 3), (147, 160)):
+        ch = 256
+        n = M_ * 8192
+        x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+        y = torch.empty(ch, n * L_ // M_, dtype=torch.float32, device=dev)
+        filters.synth_f32(x, 1, stream=stream)
+        r = filters.ResampleMC(ch, L_, M_, 1.0, filters.BLACKMAN, filters.PCM_F32, stream=stream)
+        ms = timeit(lambda: r.process(x, y), 3)
+        gb = (4 + 4 * L_ / M_) * ch * n / ms / 1e6
+        print(f"resample {L_}:{M_} f32 generic {ch}ch x {n}: {ms:.3f} ms  {ch * n / ms / 1e3:.0f} Msamples_in/s  {gb:.0f} GB/s ({gb / 80:.1f} %)")
+        r.close()
+        del x, y
 if "fir63" in which:
     for ch in (64, 4096):
         n = 1 << 20
