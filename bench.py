@@ -142,6 +142,20 @@ def main():
     kern_ms = float(np.mean(launch_ms))
 
     fir_algo = fir.algo
+    # the box's own streaming rate for the same 16 GiB -> 16 GiB: a device-to-device memcpy on the same stream
+    memcpy_gbs = None
+    if rank == 0:
+        y.copy_(x)
+        torch.cuda.synchronize()
+        tm = L.llz_hip_timer_new()
+        L.llz_hip_timer_start(tm, sptr)
+        for _ in range(3):
+            y.copy_(x)
+        L.llz_hip_timer_stop(tm, sptr)
+        memcpy_gbs = BYTES_PER_SAMPLE * channels * n / (L.llz_hip_timer_ms(tm) / 3 * 1e-3) / 1e9
+        L.llz_hip_timer_free(tm)
+        fir.filter(x, y)                                                   # restore y for the parity check below
+        torch.cuda.synchronize()
     ms_per_step = wall / args.steps * 1e3
     samples_per_step = channels * n * world
     value = samples_per_step / (wall / args.steps) / 1e6                  # Msamples/s, whole job
@@ -198,7 +212,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_fir_ols_walk_f32" if fir_algo == 2 else "k_fir_td_f32",
-                         "kernel_ms_avg": kern_ms, "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * channels * n},
+                         "kernel_ms_avg": kern_ms, "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * channels * n,
+                         "memcpy_d2d_GBs": memcpy_gbs,
+                         "frac_of_memcpy_d2d": (achieved / memcpy_gbs) if memcpy_gbs else None},
             "cpu_baseline": cpu,
             "parity": parity,
         }

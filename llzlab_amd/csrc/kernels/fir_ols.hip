@@ -518,7 +518,14 @@ k_fir_ols_walk_f32(const float *__restrict__ in, float *__restrict__ out, const 
                 v[8 + i].y = raw.b[i];
             }
             if (PREFETCH) walk_load(raw, row, s + OLS_JOB, l5, n, (jj + 1) < jcount);
+#if LLZ_DIAG == 1    /* memory only: the loaded samples go straight to the stores (wrong results; timing build) */
+#pragma unroll
+            for (int r = 0; r < 32; r++) u[r] = v[brev5(r)];
+#elif LLZ_DIAG == 2  /* compute only: transform the first job's data over and over, no further loads */
             ols_filter(v, u, buf, s_tw, s_h, l5);
+#else
+            ols_filter(v, u, buf, s_tw, s_h, l5);
+#endif
             ols_job jb;
             jb.row = row; jb.orow = orow; jb.hrow = hrow; jb.s = s; jb.live = live;
             ols_store(u, jb, l5, n);
