@@ -160,47 +160,61 @@ __device__ __forceinline__ int dec_phys(int p) { return p + ((p >> 3) << 2); }  
 
 // One workgroup = one channel x 2048 outputs (a persistent, register-prefetching variant was tried and dropped:
 // hipcc spilled the prefetch registers at every launch bound and ran 1.7x slower).
+// Staging: lane t takes the M consecutive samples of decimated positions q = t + 256 j, i.e. input indices
+// first + M*q + r (r = 0..M-1): one contiguous M-dword load per lane (a wave covers 64*M*4 contiguous bytes), sample r
+// belongs to phase M-1-r at plane position q, and since 256 j is a multiple of 8 the padded LDS address is
+// phys(t) + 384 j -- no division, constant offsets (the first version spent 12 VALU instructions per element here).
+template <int M>
 __global__ void __launch_bounds__(DEC_THREADS)
 k_resample_dec_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
                    const float *__restrict__ gp /* [M][tp] phase taps, zero padded */, long n_in, long n_out,
-                   long in_pitch, long out_pitch, int M, int Q, int tp, float gain, unsigned magic, int plane_pitch)
+                   long in_pitch, long out_pitch, int Q, int tp, float gain, int plane_pitch)
 {
     extern __shared__ __attribute__((aligned(16))) float lds_dec[];
     const int c = blockIdx.y;
     const int tid = threadIdx.x;
     const long o0 = (long)blockIdx.x * DEC_TILE;
     const long base_n = o0 - tp;                               // decimated index of logical position 0
-    const int span = (DEC_TILE + tp) * M;                      // input samples staged
-    const long first = base_n * M - (M - 1);                   // their first index
+    const int npos = DEC_TILE + tp;                            // decimated positions staged per phase
+    const long first = base_n * M - (M - 1);                   // input index of (q = 0, r = 0)
     const float *row = in + (size_t)c * in_pitch;
     const float *hrow = hist ? hist + (size_t)c * (Q - 1) : nullptr;
-    auto scatter = [&](int e, float v) {
-        const int q = (int)__umulhi((unsigned)e, magic);       // e / M  (magic = 2^32/M rounded up, e < 2^16)
-        const int m = M - 1 - (e - q * M);                     // phase of this sample, position q in its plane
-        lds_dec[m * plane_pitch + dec_phys(q)] = v;
-    };
-    if (first >= 0 && first + span <= n_in) {
-        // interior tile: batches of 8 independent, unconditional loads per lane (a load-use-load loop pays the HBM
-        // latency once per element: measured 1.6x slower)
-        const float *src = row + first;
-        for (int e0 = tid; e0 < span; e0 += 8 * DEC_THREADS) {
-            float v[8];
+    float *dst = lds_dec + dec_phys(tid);
+    constexpr int NJ = 12;                                     // positions per lane: covers 2048 + tp up to 3072
+    if (first >= 0 && first + (long)npos * M <= n_in) {
+        // interior tile: independent, unconditional loads, 4 positions (4*M dwords) in flight per lane
+        const float *src = row + first + (long)M * tid;
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = src[min(e0 + u * DEC_THREADS, span - 1)];
+        for (int j0 = 0; j0 < NJ; j0 += 4) {
+            if (j0 * DEC_THREADS >= npos) break;
+            float v[4 * M];
 #pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (e0 + u * DEC_THREADS < span) scatter(e0 + u * DEC_THREADS, v[u]);
+            for (int jj = 0; jj < 4; jj++) {
+                const int q = min(tid + (j0 + jj) * DEC_THREADS, npos - 1);      // clamp: re-reads the last position
+#pragma unroll
+                for (int r = 0; r < M; r++) v[jj * M + r] = row[first + (long)M * q + r];
+            }
+            (void)src;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++)
+                if (tid + (j0 + jj) * DEC_THREADS < npos) {
+#pragma unroll
+                    for (int r = 0; r < M; r++) dst[(M - 1 - r) * plane_pitch + 384 * (j0 + jj)] = v[jj * M + r];
+                }
         }
     } else {
-        for (int e = tid; e < span; e += DEC_THREADS) {         // first / last tile of a channel
-            const long idx = first + e;
-            float v = 0.f;
-            if (idx >= 0) {
-                if (idx < n_in) v = row[idx];
-            } else if (hrow && idx >= -(long)(Q - 1)) {
-                v = hrow[(Q - 1) + idx];
+        for (int q = tid; q < npos; q += DEC_THREADS) {         // first / last tile of a channel
+#pragma unroll
+            for (int r = 0; r < M; r++) {
+                const long idx = first + (long)M * q + r;
+                float v = 0.f;
+                if (idx >= 0) {
+                    if (idx < n_in) v = row[idx];
+                } else if (hrow && idx >= -(long)(Q - 1)) {
+                    v = hrow[(Q - 1) + idx];
+                }
+                lds_dec[(M - 1 - r) * plane_pitch + dec_phys(q)] = v;
             }
-            scatter(e, v);
         }
     }
     __syncthreads();
@@ -352,14 +366,27 @@ extern "C" int llzs_resample_dec_f32(const float *in, float *out, const float *h
     plane = plane + (plane >> 3) * 4 + 4;                      // dec_phys image of one plane ...
     while ((plane & 31) != 12) plane += 4;                     // ... phases start 12 banks apart, 16-byte aligned
     const size_t lds = (size_t)plane * M * sizeof(float);
-    if (lds > 64 * 1024) {
-        llzs_set_error("resample_dec_f32: M=%d needs %zu B of LDS (fast path limit 64 KiB)", M, lds);
+    if (lds > 64 * 1024 || M > 8 || DEC_TILE + tp > 12 * DEC_THREADS) {
+        llzs_set_error("resample_dec_f32: M=%d tp=%d needs %zu B of LDS (fast path: 64 KiB, M <= 8)", M, tp, lds);
         return LLZ_ERR_RANGE;
     }
     const unsigned magic = (unsigned)((0x100000000ull + (unsigned)M - 1) / (unsigned)M);
     dim3 grid((unsigned)((n_out + DEC_TILE - 1) / DEC_TILE), (unsigned)channels);
-    hipLaunchKernelGGL(k_resample_dec_f32, grid, dim3(DEC_THREADS), lds, as_stream(stream), in, out, hist, gp, n_in,
-                       n_out, in_pitch, out_pitch, M, Q, tp, gain, magic, plane);
+    (void)magic;
+#define LLZ_DEC_LAUNCH(MM)                                                                                        \
+    hipLaunchKernelGGL(k_resample_dec_f32<MM>, grid, dim3(DEC_THREADS), lds, as_stream(stream), in, out, hist, gp, \
+                       n_in, n_out, in_pitch, out_pitch, Q, tp, gain, plane)
+    switch (M) {
+    case 1: LLZ_DEC_LAUNCH(1); break;
+    case 2: LLZ_DEC_LAUNCH(2); break;
+    case 3: LLZ_DEC_LAUNCH(3); break;
+    case 4: LLZ_DEC_LAUNCH(4); break;
+    case 5: LLZ_DEC_LAUNCH(5); break;
+    case 6: LLZ_DEC_LAUNCH(6); break;
+    case 7: LLZ_DEC_LAUNCH(7); break;
+    default: LLZ_DEC_LAUNCH(8); break;
+    }
+#undef LLZ_DEC_LAUNCH
     LLZ_LAUNCH_CHECK("k_resample_dec_f32");
     return LLZ_OK;
 }
@@ -368,5 +395,5 @@ extern "C" int llzs_resample_dec_f32_fits(int M, int tp)
 {
     int plane = DEC_TILE + tp;
     plane = plane + (plane >> 3) * 4 + 4 + 32;
-    return (size_t)plane * M * sizeof(float) <= 64 * 1024;
+    return (size_t)plane * M * sizeof(float) <= 64 * 1024 && M <= 8 && DEC_TILE + tp <= 12 * DEC_THREADS;
 }
