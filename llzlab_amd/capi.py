@@ -166,6 +166,18 @@ def lib():
     sig("llz_fft_fixed_batch", i, ul, vp, i)
     sig("llz_ifft_fixed_batch", i, ul, vp, i)
     sig("llz_fft_fixed_set_stream", i, ul, vp)
+    # llz_corr.h
+    sig("llz_autocorr", None, dp, i, i, dp)
+    sig("llz_crosscorr", None, dp, dp, i, i, dp)
+    sig("llz_corr_cof", d, dp, dp, i)
+    sig("llz_autocorr_fast_init", ul, i)
+    sig("llz_autocorr_fast_uninit", None, ul)
+    sig("llz_autocorr_fast", None, ul, dp, i, i, dp)
+    sig("llz_autocorr_mc", i, vp, vp, i, i, i, vp)
+    sig("llz_autocorr_fast_mc_init", ul, i, i)
+    sig("llz_autocorr_fast_mc_uninit", None, ul)
+    sig("llz_autocorr_fast_mc", i, ul, vp, vp, i)
+    sig("llz_autocorr_fast_mc_set_stream", i, ul, vp)
     _lib = L
     return L
 

@@ -95,6 +95,16 @@ int llzs_fft_f64(double *data, int size, const double *cs, int inverse, void *st
 /* int32 data, Q15 twiddles (size cos then size sin shorts), bit-exact */
 int llzs_fft_fixed(int *data, int count, int size, const short *cs, int inverse, void *stream);
 
+/* ---- correlation ---- */
+/* r[k] = sum_i x[i]*y[i+k], k = 0..p, one channel, double, the reference's summation order (llz_corr.c:38-58) */
+int llzs_corr_exact_f64(const double *x, const double *y, int n, int p, double *r, void *stream);
+/* frames x n float32 -> frames x (p+1), direct form */
+int llzs_autocorr_mc_f32(const float *x, float *r, int frames, int n, int p, void *stream);
+/* pointwise steps of the FFT form around llzs_fft_f32: real -> zero-padded complex; |X|^2 of the first n bins; 2*Re */
+int llzs_acf_pack(const float *x, float *z, int frames, int n, int F, void *stream);
+int llzs_acf_power(float *z, int frames, int n, int F, void *stream);
+int llzs_acf_extract(const float *z, float *r, int frames, int p, int F, void *stream);
+
 /* ---- synthetic PCM ---- */
 int llzs_synth_f32(float *dst, int channels, long n, long pitch, unsigned seed, int chan0, void *stream);
 int llzs_synth_i16(short *dst, int channels, long n, long pitch, unsigned seed, int chan0, void *stream);

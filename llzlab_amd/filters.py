@@ -385,6 +385,64 @@ class FftFixed:
     __del__ = close
 
 
+# ------------------------------------------------------------------------------------------ correlation
+def autocorr(x, p):
+    """llz_autocorr: host float64, exact."""
+    x = _f64(x)
+    r = np.zeros(p + 1)
+    capi.lib().llz_autocorr(x.ctypes.data_as(_dp), len(x), p, r.ctypes.data_as(_dp))
+    return r
+
+
+def crosscorr(x, y, p):
+    x, y = _f64(x), _f64(y)
+    r = np.zeros(p + 1)
+    capi.lib().llz_crosscorr(x.ctypes.data_as(_dp), y.ctypes.data_as(_dp), len(x), p, r.ctypes.data_as(_dp))
+    return r
+
+
+def corr_cof(a, b):
+    a, b = _f64(a), _f64(b)
+    return capi.lib().llz_corr_cof(a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), len(a))
+
+
+def autocorr_fast(x, p):
+    """llz_autocorr_fast_{init,uninit} around one call: host float64, exact (the reference's definition)."""
+    L = capi.lib()
+    x = _f64(x)
+    h = check_handle(L.llz_autocorr_fast_init(len(x)), "llz_autocorr_fast_init")
+    r = np.zeros(p + 1)
+    L.llz_autocorr_fast(h, x.ctypes.data_as(_dp), len(x), p, r.ctypes.data_as(_dp))
+    L.llz_autocorr_fast_uninit(h)
+    return r
+
+
+def autocorr_mc(x, r, p, stream=None):
+    """x: [frames, n] float32, r: [frames, p+1] float32 (device tensors or numpy)."""
+    frames, n = x.shape
+    check(capi.lib().llz_autocorr_mc(_ptr(x), _ptr(r), frames, n, p, _stream_ptr(stream)), "llz_autocorr_mc")
+    return r
+
+
+class AutocorrFastMC:
+    def __init__(self, frames, n, stream=None):
+        self._L = capi.lib()
+        self.handle = check_handle(self._L.llz_autocorr_fast_mc_init(frames, n), "llz_autocorr_fast_mc_init")
+        if stream is not None:
+            check(self._L.llz_autocorr_fast_mc_set_stream(self.handle, _stream_ptr(stream)), "set_stream")
+
+    def run(self, x, r, p):
+        check(self._L.llz_autocorr_fast_mc(self.handle, _ptr(x), _ptr(r), p), "llz_autocorr_fast_mc")
+        return r
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            self._L.llz_autocorr_fast_mc_uninit(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
 # ------------------------------------------------------------------------------------------ synthetic PCM
 def synth_f32(dst, seed, chan0=0, stream=None):
     """Fill a [channels, n] float32 device tensor with the counter-hash PCM of SURVEY.md 8(d)."""

@@ -173,6 +173,19 @@ def main():
     d["fftx_sin_roundtrip"] = r.fft_fixed(r.fft_fixed(s), inverse=True)
     np.savez_compressed(os.path.join(OUT, "fft.npz"), **d)
 
+    # ---- correlation ----------------------------------------------------------
+    d = {}
+    g = np.random.default_rng(5000)
+    for n, p in ((64, 10), (300, 16), (1024, 32), (2048, 2047)):
+        x = g.uniform(-1, 1, n).astype(np.float32).astype(np.float64)
+        y = g.uniform(-1, 1, n).astype(np.float32).astype(np.float64)
+        d[f"x_{n}"], d[f"y_{n}"] = x, y
+        d[f"auto_{n}_{p}"] = r.autocorr(x, p)
+        d[f"cross_{n}_{p}"] = r.crosscorr(x, y, p)
+        d[f"fast_{n}_{p}"] = r.autocorr_fast(x, p)
+        d[f"cof_{n}"] = np.array([r.corr_cof(x, y)])
+    np.savez_compressed(os.path.join(OUT, "corr.npz"), **d)
+
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden fixtures written to", OUT, "total bytes", tot)
 

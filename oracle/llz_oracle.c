@@ -660,6 +660,80 @@ void orc_fftx_free(void *p)
     free(f->rev); free(f->work); free(f->c); free(f->s); free(f);
 }
 
+/* ------------------------------------------------------------------ correlation (llz_corr.c) */
+
+void orc_autocorr(const double *x, int n, int p, double *r)
+{
+    for (int k = 0; k <= p; k++) {                   /* llz_corr.c:38-47: plain running sums, ascending i */
+        double acc = 0.0;
+        for (int i = 0; i + k < n; i++) acc += x[i] * x[i + k];
+        r[k] = acc;
+    }
+}
+
+void orc_crosscorr(const double *x, const double *y, int n, int p, double *r)
+{
+    for (int k = 0; k <= p; k++) {                   /* llz_corr.c:49-58 */
+        double acc = 0.0;
+        for (int i = 0; i + k < n; i++) acc += x[i] * y[i + k];
+        r[k] = acc;
+    }
+}
+
+double orc_corr_cof(const double *a, const double *b, int len)
+{
+    double ab = 0, aa = 0, bb = 0;                   /* llz_corr.c:61-78 */
+    for (int k = 0; k < len; k++) {
+        ab += a[k] * b[k];
+        aa += a[k] * a[k];
+        bb += b[k] * b[k];
+    }
+    return ab / sqrt(aa * bb);
+}
+
+typedef struct {
+    int fft_len;
+    void *fft;
+    double *b1, *b2;
+} orc_acf_t;
+
+void *orc_acf_new(int n)
+{
+    /* llz_corr.c:81-119: level = (int)log2(2n), bumped when 2^level < 2n */
+    int level = (int)log2((double)(2 * n));
+    if ((1 << level) < 2 * n) level += 1;
+    orc_acf_t *h = (orc_acf_t *)calloc(1, sizeof(*h));
+    h->fft_len = 1 << level;
+    h->fft = orc_fft_new(h->fft_len);
+    h->b1 = (double *)calloc(2 * (size_t)h->fft_len, sizeof(double));
+    h->b2 = (double *)calloc(2 * (size_t)h->fft_len, sizeof(double));
+    return h;
+}
+
+int orc_acf_fft_len(void *p) { return ((orc_acf_t *)p)->fft_len; }
+
+void orc_acf_run(void *p, const double *x, int n, int pord, double *r)
+{
+    orc_acf_t *h = (orc_acf_t *)p;
+    /* llz_corr.c:155-177: zero-padded forward FFT; power spectrum of the FIRST n BINS ONLY (the rest stays zero --
+     * the reference's quirk, kept); inverse FFT; result doubled */
+    memset(h->b1, 0, sizeof(double) * 2 * (size_t)h->fft_len);
+    for (int i = 0; i < n; i++) h->b1[2 * i] = x[i];
+    orc_fft_fwd(h->fft, h->b1);
+    memset(h->b2, 0, sizeof(double) * 2 * (size_t)h->fft_len);
+    for (int i = 0; i < n; i++)
+        h->b2[2 * i] = h->b1[2 * i] * h->b1[2 * i] + h->b1[2 * i + 1] * h->b1[2 * i + 1];
+    orc_fft_inv(h->fft, h->b2);
+    for (int i = 0; i <= pord; i++) r[i] = h->b2[2 * i] * 2;
+}
+
+void orc_acf_free(void *p)
+{
+    orc_acf_t *h = (orc_acf_t *)p;
+    if (!h) return;
+    orc_fft_free(h->fft); free(h->b1); free(h->b2); free(h);
+}
+
 /* ------------------------------------------------------------------ batch drivers */
 
 void orc_fir_batch_f32(const float *in, double *out, int channels, long n, const double *h, int flt_len)

@@ -79,6 +79,15 @@ void   orc_fftx_fwd(void *f, int *data);
 void   orc_fftx_inv(void *f, int *data);
 void   orc_fftx_free(void *f);
 
+/* correlation, reference libllzfilter/llz_corr.c:38-177 */
+void   orc_autocorr(const double *x, int n, int p, double *r);
+void   orc_crosscorr(const double *x, const double *y, int n, int p, double *r);
+double orc_corr_cof(const double *a, const double *b, int len);
+void  *orc_acf_new(int n);                       /* FFT autocorrelation handle: fft_len = 2^ceil(log2(2n)) */
+int    orc_acf_fft_len(void *h);
+void   orc_acf_run(void *h, const double *x, int n, int p, double *r);
+void   orc_acf_free(void *h);
+
 /* ---- batch drivers over the restatement (what the multi-channel GPU path is compared with) ---- */
 
 /* planar [C][n] float input -> planar double output; every channel runs its own orc_fir state machine

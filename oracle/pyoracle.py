@@ -109,6 +109,15 @@ class Oracle:
         L.orc_fftx_cos.argtypes = [vp]
         L.orc_fftx_sin.restype = C.POINTER(C.c_short)
         L.orc_fftx_sin.argtypes = [vp]
+        L.orc_autocorr.argtypes = [_dp, C.c_int, C.c_int, _dp]
+        L.orc_crosscorr.argtypes = [_dp, _dp, C.c_int, C.c_int, _dp]
+        L.orc_corr_cof.restype = C.c_double
+        L.orc_corr_cof.argtypes = [_dp, _dp, C.c_int]
+        L.orc_acf_new.restype = vp
+        L.orc_acf_new.argtypes = [C.c_int]
+        L.orc_acf_fft_len.argtypes = [vp]
+        L.orc_acf_run.argtypes = [vp, _dp, C.c_int, C.c_int, _dp]
+        L.orc_acf_free.argtypes = [vp]
         L.orc_fir_batch_f32.argtypes = [C.c_void_p, _dp, C.c_int, C.c_long, _dp, C.c_int]
         L.orc_iir_cascade_batch_f32.argtypes = [C.c_void_p, _dp, C.c_int, C.c_long, _dp, C.c_int]
         L.orc_rs_batch_f32.restype = C.c_long
@@ -265,6 +274,31 @@ class Oracle:
         self.lib.orc_fftx_free(f)
         return c, s
 
+    # ---- correlation -----------------------------------------------------------------------------
+    def autocorr(self, x, p):
+        x = _f64(x)
+        r = np.zeros(p + 1)
+        self.lib.orc_autocorr(_ptr(x), len(x), p, _ptr(r))
+        return r
+
+    def crosscorr(self, x, y, p):
+        x, y = _f64(x), _f64(y)
+        r = np.zeros(p + 1)
+        self.lib.orc_crosscorr(_ptr(x), _ptr(y), len(x), p, _ptr(r))
+        return r
+
+    def corr_cof(self, a, b):
+        a, b = _f64(a), _f64(b)
+        return self.lib.orc_corr_cof(_ptr(a), _ptr(b), len(a))
+
+    def autocorr_fast(self, x, p):
+        x = _f64(x)
+        h = self.lib.orc_acf_new(len(x))
+        r = np.zeros(p + 1)
+        self.lib.orc_acf_run(h, _ptr(x), len(x), p, _ptr(r))
+        self.lib.orc_acf_free(h)
+        return r
+
     # ---- batch drivers (oracle only) -----------------------------------------------------------
     def fir_batch_f32(self, x, h):
         x = np.ascontiguousarray(x, dtype=np.float32)
@@ -371,6 +405,14 @@ class Ref:
             getattr(L, n).argtypes = [ul, _ip]
         L.llz_fft_uninit.argtypes = [ul]
         L.llz_fft_fixed_uninit.argtypes = [ul]
+        L.llz_autocorr.argtypes = [_dp, C.c_int, C.c_int, _dp]
+        L.llz_crosscorr.argtypes = [_dp, _dp, C.c_int, C.c_int, _dp]
+        L.llz_corr_cof.restype = C.c_double
+        L.llz_corr_cof.argtypes = [_dp, _dp, C.c_int]
+        L.llz_autocorr_fast_init.restype = ul
+        L.llz_autocorr_fast_init.argtypes = [C.c_int]
+        L.llz_autocorr_fast_uninit.argtypes = [ul]
+        L.llz_autocorr_fast.argtypes = [ul, _dp, C.c_int, C.c_int, _dp]
         self._libc = C.CDLL(None)
         self._libc.free.argtypes = [C.c_void_p]
 
@@ -490,6 +532,30 @@ class Ref:
             outs.append(yo[:ob.value // 2].copy())
         un(h)
         return np.concatenate(outs) if outs else np.zeros(0, dtype=np.int16)
+
+    def autocorr(self, x, p):
+        x = _f64(x)
+        r = np.zeros(p + 1)
+        self.lib.llz_autocorr(_ptr(x), len(x), p, _ptr(r))
+        return r
+
+    def crosscorr(self, x, y, p):
+        x, y = _f64(x), _f64(y)
+        r = np.zeros(p + 1)
+        self.lib.llz_crosscorr(_ptr(x), _ptr(y), len(x), p, _ptr(r))
+        return r
+
+    def corr_cof(self, a, b):
+        a, b = _f64(a), _f64(b)
+        return self.lib.llz_corr_cof(_ptr(a), _ptr(b), len(a))
+
+    def autocorr_fast(self, x, p):
+        x = _f64(x)
+        h = self.lib.llz_autocorr_fast_init(len(x))
+        r = np.zeros(p + 1)
+        self.lib.llz_autocorr_fast(h, _ptr(x), len(x), p, _ptr(r))
+        self.lib.llz_autocorr_fast_uninit(h)
+        return r
 
     def fft(self, data, inverse=False):
         z = np.ascontiguousarray(data, dtype=np.complex128).copy()

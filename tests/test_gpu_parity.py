@@ -455,3 +455,49 @@ def test_iir_cascade_pipelined_path_long(dev, oracle, channels, n):
         outs.append(yi.cpu().numpy())
     f.close()
     rms_check(np.concatenate(outs, axis=1), ref, "pipelined iir, two frames")
+
+
+# ------------------------------------------------------------------------------------------------ correlation (8f rank 1)
+def test_correlation_reference_symbols_exact(dev):
+    d = load("corr.npz")
+    for n, p in ((64, 10), (300, 16), (1024, 32), (2048, 2047)):
+        x, y = d[f"x_{n}"], d[f"y_{n}"]
+        assert np.array_equal(filters.autocorr(x, p), d[f"auto_{n}_{p}"])
+        assert np.array_equal(filters.crosscorr(x, y, p), d[f"cross_{n}_{p}"])
+        assert np.array_equal(filters.autocorr_fast(x, p), d[f"fast_{n}_{p}"])
+        assert filters.corr_cof(x, y) == d[f"cof_{n}"][0]
+    with pytest.raises(capi.LlzError):
+        capi.check_handle(capi.lib().llz_autocorr_fast_init(4096), "too long")
+
+
+@pytest.mark.parametrize("frames,n,p", [(7, 300, 16), (3, 1024, 32), (5, 20000, 40), (2, 64, 63), (130, 512, 255)])
+def test_autocorr_mc_direct_vs_oracle(dev, oracle, frames, n, p):
+    x = oracle.synth_f32(frames, n, seed=n + p)
+    ref = np.stack([oracle.autocorr(row.astype(np.float64), p) for row in x])
+    xd = torch.from_numpy(x).to(dev)
+    rd = torch.empty(frames, p + 1, dtype=torch.float32, device=dev)
+    filters.autocorr_mc(xd, rd, p)
+    got = rd.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(got - ref)) <= 1e-5 * ref[:, 0].max()         # relative to the zero-lag energy
+    r2 = np.zeros((frames, p + 1), dtype=np.float32)
+    filters.autocorr_mc(x, r2, p)                                       # host buffers
+    assert np.array_equal(r2, rd.cpu().numpy())
+
+
+@pytest.mark.parametrize("frames,n,p", [(9, 300, 16), (4, 1024, 32), (3, 2048, 100), (70000, 16, 8)])
+def test_autocorr_fast_mc_vs_oracle(dev, oracle, frames, n, p):
+    if frames > 1000:
+        x = np.tile(oracle.synth_f32(8, n, seed=3), (frames // 8, 1))
+        frames = x.shape[0]
+    else:
+        x = oracle.synth_f32(frames, n, seed=n)
+    uniq = x[:8] if frames > 1000 else x
+    ref_u = np.stack([oracle.autocorr_fast(row.astype(np.float64), p) for row in uniq])
+    f = filters.AutocorrFastMC(frames, n)
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    rd = torch.empty(frames, p + 1, dtype=torch.float32, device=dev)
+    f.run(xd, rd, p)
+    f.close()
+    got = rd.cpu().numpy().astype(np.float64)
+    ref = np.tile(ref_u, (frames // 8, 1)) if frames > 1000 else ref_u
+    assert np.max(np.abs(got - ref)) <= 1e-5 * np.abs(ref).max()

@@ -229,3 +229,16 @@ def test_synth_generator_properties(oracle):
     assert np.array_equal(x[2:], y)
     s = oracle.synth_i16(2, 4096, seed=3)
     assert s.min() >= -16384 and s.max() <= 16383
+
+
+def test_correlation(oracle):
+    d = load("corr.npz")
+    for n, p in ((64, 10), (300, 16), (1024, 32), (2048, 2047)):
+        x, y = d[f"x_{n}"], d[f"y_{n}"]
+        assert same(oracle.autocorr(x, p), d[f"auto_{n}_{p}"])
+        assert same(oracle.crosscorr(x, y, p), d[f"cross_{n}_{p}"])
+        assert same(oracle.autocorr_fast(x, p), d[f"fast_{n}_{p}"])
+        assert oracle.corr_cof(x, y) == d[f"cof_{n}"][0]
+    # the FFT form is the reference's own definition (first n bins, doubled), NOT the direct autocorrelation
+    x = d["x_64"]
+    assert not np.allclose(oracle.autocorr_fast(x, 10), oracle.autocorr(x, 10), rtol=1e-3)
