@@ -178,6 +178,9 @@ def lib():
     sig("llz_autocorr_fast_mc_uninit", None, ul)
     sig("llz_autocorr_fast_mc", i, ul, vp, vp, i)
     sig("llz_autocorr_fast_mc_set_stream", i, ul, vp)
+    # llz_pcm.h
+    sig("llz_pcm_deinterleave_i16_f32", i, vp, vp, i, lng, C.c_float, vp)
+    sig("llz_pcm_interleave_f32_i16", i, vp, vp, i, lng, C.c_float, vp)
     _lib = L
     return L
 

@@ -105,6 +105,10 @@ int llzs_acf_pack(const float *x, float *z, int frames, int n, int F, void *stre
 int llzs_acf_power(float *z, int frames, int n, int F, void *stream);
 int llzs_acf_extract(const float *z, float *r, int frames, int p, int F, void *stream);
 
+/* ---- PCM ingest / egress ---- */
+int llzs_pcm_deinterleave_i16_f32(const short *in, float *out, int channels, long n, float scale, void *stream);
+int llzs_pcm_interleave_f32_i16(const float *in, short *out, int channels, long n, float scale, void *stream);
+
 /* ---- synthetic PCM ---- */
 int llzs_synth_f32(float *dst, int channels, long n, long pitch, unsigned seed, int chan0, void *stream);
 int llzs_synth_i16(short *dst, int channels, long n, long pitch, unsigned seed, int chan0, void *stream);

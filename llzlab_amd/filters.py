@@ -443,6 +443,23 @@ class AutocorrFastMC:
     __del__ = close
 
 
+# ------------------------------------------------------------------------------------------ PCM ingest / egress
+def pcm_deinterleave(ileaved, planar, scale=1.0 / 32768.0, stream=None):
+    """ileaved: [n, channels] int16 -> planar: [channels, n] float32."""
+    n, ch = ileaved.shape
+    check(capi.lib().llz_pcm_deinterleave_i16_f32(_ptr(ileaved), _ptr(planar), ch, n, scale, _stream_ptr(stream)),
+          "llz_pcm_deinterleave_i16_f32")
+    return planar
+
+
+def pcm_interleave(planar, ileaved, scale=32768.0, stream=None):
+    """planar: [channels, n] float32 -> ileaved: [n, channels] int16 (clamp, truncate toward zero)."""
+    ch, n = planar.shape
+    check(capi.lib().llz_pcm_interleave_f32_i16(_ptr(planar), _ptr(ileaved), ch, n, scale, _stream_ptr(stream)),
+          "llz_pcm_interleave_f32_i16")
+    return ileaved
+
+
 # ------------------------------------------------------------------------------------------ synthetic PCM
 def synth_f32(dst, seed, chan0=0, stream=None):
     """Fill a [channels, n] float32 device tensor with the counter-hash PCM of SURVEY.md 8(d)."""

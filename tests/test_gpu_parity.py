@@ -501,3 +501,25 @@ def test_autocorr_fast_mc_vs_oracle(dev, oracle, frames, n, p):
     got = rd.cpu().numpy().astype(np.float64)
     ref = np.tile(ref_u, (frames // 8, 1)) if frames > 1000 else ref_u
     assert np.max(np.abs(got - ref)) <= 1e-5 * np.abs(ref).max()
+
+
+# ------------------------------------------------------------------------------------------------ PCM ingest (8f rank 2)
+@pytest.mark.parametrize("channels,n", [(1, 5000), (2, 48000), (6, 1000), (64, 4097), (100, 333), (4096, 70)])
+def test_pcm_deinterleave_and_back_exact(dev, channels, n):
+    """numpy restatement: planar = ileaved.T / 32768 (exact in float32); back: clamp, truncate toward zero
+    (reference llz_resample.c:596-601)"""
+    rng = np.random.default_rng(channels * 7 + n)
+    il = rng.integers(-32768, 32768, (n, channels)).astype(np.int16)
+    ild = torch.from_numpy(il).to(dev)
+    pl = torch.empty(channels, n, dtype=torch.float32, device=dev)
+    filters.pcm_deinterleave(ild, pl)
+    assert np.array_equal(pl.cpu().numpy(), (il.T.astype(np.float32) / np.float32(32768.0)))
+    back = torch.empty(n, channels, dtype=torch.int16, device=dev)
+    filters.pcm_interleave(pl, back)
+    assert np.array_equal(back.cpu().numpy(), il)                      # round trip is the identity
+    # clamp + truncation on out-of-range and fractional values
+    x = rng.uniform(-1.5, 1.5, (channels, n)).astype(np.float32)
+    out = np.zeros((n, channels), dtype=np.int16)
+    filters.pcm_interleave(x, out)                                      # host buffers
+    ref = np.trunc(np.clip(x.astype(np.float32) * np.float32(32768.0), -32768, 32767)).astype(np.int16).T
+    assert np.array_equal(out, ref)

@@ -31,7 +31,7 @@ def timeit(fn, steps):
     return ms
 
 
-which = sys.argv[1:] or ["iir", "resample", "fir63", "td257", "fft"]
+which = sys.argv[1:] or ["iir", "resample", "fir63", "td257", "fft", "corr", "pcm"]
 if "iir" in which:
     for ch in (1024, 128):
         n = 1 << 20
@@ -119,3 +119,31 @@ if "fft" in which:
         print(f"fft q15 N={n} x {count}: {ms:.3f} ms  {16 * n * count / ms / 1e6:.0f} GB/s ({16 * n * count / ms / 1e6 / 80:.1f} %)")
         fx.close()
         del z, q
+
+if "corr" in which:
+    for (frames, n, p) in ((1 << 18, 1024, 16), (1 << 18, 1024, 64), (4096, 1 << 18, 32)):
+        x = torch.rand(frames, n, dtype=torch.float32, device=dev) * 2 - 1
+        r = torch.empty(frames, p + 1, dtype=torch.float32, device=dev)
+        ms = timeit(lambda: filters.autocorr_mc(x, r, p, stream=stream), 3)
+        gb = 4.0 * frames * n / ms / 1e6
+        print(f"autocorr direct {frames} x {n}, p={p}: {ms:.3f} ms  {frames * n / ms / 1e3:.0f} Msamples/s  {gb:.0f} GB/s ({gb / 80:.1f} %)")
+        if n <= 2048:
+            f = filters.AutocorrFastMC(frames, n, stream=stream)
+            ms = timeit(lambda: f.run(x, r, p), 3)
+            gb = 4.0 * frames * n / ms / 1e6
+            print(f"autocorr fft    {frames} x {n}, p={p}: {ms:.3f} ms  {frames * n / ms / 1e3:.0f} Msamples/s  {gb:.0f} GB/s ({gb / 80:.1f} %)")
+            f.close()
+        del x, r
+
+if "pcm" in which:
+    for ch in (2, 64, 4096):
+        n = (1 << 31) // ch // 2                                          # 2 GiB of int16 in, 4 GiB of float32 out
+        il = torch.randint(-32768, 32767, (n, ch), dtype=torch.int16, device=dev)
+        pl = torch.empty(ch, n, dtype=torch.float32, device=dev)
+        ms = timeit(lambda: filters.pcm_deinterleave(il, pl, stream=stream), 3)
+        gb = 6.0 * ch * n / ms / 1e6
+        print(f"pcm deinterleave {ch}ch x {n}: {ms:.3f} ms  {gb:.0f} GB/s ({gb / 80:.1f} %)")
+        ms = timeit(lambda: filters.pcm_interleave(pl, il, stream=stream), 3)
+        gb = 6.0 * ch * n / ms / 1e6
+        print(f"pcm interleave   {ch}ch x {n}: {ms:.3f} ms  {gb:.0f} GB/s ({gb / 80:.1f} %)")
+        del il, pl
