@@ -2,8 +2,8 @@
 //
 //  k_corr_exact_f64    one lane per lag, the reference's running sum in its order (rounded multiply, rounded add):
 //                      bit-identical to llz_autocorr / llz_crosscorr; also the three sums of llz_corr_cof.
-//  k_autocorr_mc_f32   one workgroup per frame; the frame is walked in 8192-sample chunks staged in LDS, every lane keeps
-//                      one accumulator per lag of the current group of 32 lags; HBM sees each sample once.
+//  k_autocorr_mc_f32   one wave per frame, 512-sample chunks in the wave's private LDS, register sliding window
+//                      (64 FMAs per two ds_read_b128), partial sums in registers, one DPP reduction per frame.
 //  k_acf_pack / k_acf_power / k_acf_extract
 //                      the pointwise steps of the FFT form around the batched float32 FFT of fft.hip:
 //                      zero-padded real -> complex, |X|^2 of the FIRST n bins (the reference's definition), 2*Re.
@@ -25,48 +25,78 @@ k_corr_exact_f64(const double *__restrict__ x, const double *__restrict__ y, int
     r[k] = acc;
 }
 
-constexpr int AC_THREADS = 256;
-constexpr int AC_CHUNK = 8192;          // samples staged per pass (+ 255 halo)
-constexpr int AC_LG = 32;               // lags per accumulator group
+// Direct autocorrelation of many frames.  A WAVE owns a frame (frames are dealt round robin to the waves of a
+// persistent grid) and walks it in chunks of 512 samples: the chunk plus p samples of look-ahead is staged in the wave's
+// private LDS (coalesced dword loads, no workgroup barrier), lane l keeps x[8l .. 8l+7] in registers and slides a
+// 15-sample window over the lags, 8 lags at a time: 64 FMAs per two ds_read_b128 -- the register-window scheme of
+// fir_td.hip with the frame itself in the role of the taps.  Per-lane partial sums live in registers for the whole
+// frame and are reduced across the wave once per frame with DPP adds.
+constexpr int AC_WAVES = 4;
+constexpr int AC_CHUNK = 512;                 // samples per wave and step: 8 per lane
+constexpr int AC_MAXLAG = 256;                // p <= 255
+constexpr int AC_LDS = (AC_CHUNK + AC_MAXLAG + 16) + ((AC_CHUNK + AC_MAXLAG + 16) >> 3) * 4;   // padded image
 
-__global__ void __launch_bounds__(AC_THREADS)
-k_autocorr_mc_f32(const float *__restrict__ x, float *__restrict__ r, int n, int p)
+__device__ __forceinline__ int ac_phys(int p) { return p + ((p >> 3) << 2); }
+
+__device__ __forceinline__ float wave_sum(float v)
 {
-    __shared__ float xs[AC_CHUNK + 256];
-    __shared__ float red[AC_THREADS / 64][AC_LG];
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *row = x + (size_t)f * n;
-    for (int g0 = 0; g0 <= p; g0 += AC_LG) {
-        float acc[AC_LG];
 #pragma unroll
-        for (int k = 0; k < AC_LG; k++) acc[k] = 0.f;
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+template <int NG>                               // lag groups of 8 kept in registers: lags 0 .. 8*NG-1
+__global__ void __launch_bounds__(64 * AC_WAVES)
+k_autocorr_mc_f32(const float *__restrict__ x, float *__restrict__ r, int frames, int n, int p, int lag0)
+{
+    __shared__ __attribute__((aligned(16))) float lds_ac[AC_WAVES][AC_LDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *xs = lds_ac[wave];
+    const long waves_total = (long)gridDim.x * AC_WAVES;
+    const int look = lag0 + 8 * NG;                            // look-ahead samples a chunk needs behind its end
+                                                               // (this launch does lags lag0 .. lag0 + 8*NG - 1)
+    for (long f = (long)blockIdx.x * AC_WAVES + wave; f < frames; f += waves_total) {
+        const float *row = x + (size_t)f * n;
+        float acc[8 * NG];
+#pragma unroll
+        for (int k = 0; k < 8 * NG; k++) acc[k] = 0.f;
         for (int c0 = 0; c0 < n; c0 += AC_CHUNK) {
-            const int len = min(AC_CHUNK, n - c0);              // positions i in [c0, c0+len)
-            const int span = min(len + g0 + AC_LG, n - c0);     // samples needed: up to i + k
-            __syncthreads();
-            for (int i = tid; i < span; i += AC_THREADS) xs[i] = row[c0 + i];
-            for (int i = span + tid; i < len + g0 + AC_LG; i += AC_THREADS) xs[i] = 0.f;   // beyond the frame: zero terms
-            __syncthreads();
-            for (int i = tid; i < len; i += AC_THREADS) {
-                const float xi = xs[i];
+            // stage x[c0 .. c0 + 512 + look): zeros behind the end of the frame make those products vanish
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the previous step's reads are done
+            for (int i = lane; i < AC_CHUNK + look; i += 64) {
+                const int idx = c0 + i;
+                xs[ac_phys(i)] = idx < n ? row[idx] : 0.f;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int p0 = lane * 8;
+            float xl[8], wa[8], wb[8];
+            auto load8 = [&](float (&w)[8], int q) {
+                const float4 a = *reinterpret_cast<const float4 *>(&xs[ac_phys(q)]);
+                const float4 b = *reinterpret_cast<const float4 *>(&xs[ac_phys(q + 4)]);
+                w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+                w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+            };
+            load8(xl, p0);
+            load8(wa, p0 + lag0);
+            // lag group g: lags 8g .. 8g+7 need x[p0 + 8g .. p0 + 8g + 14] = (wa | wb) with wb = the next 8 samples
 #pragma unroll
-                for (int k = 0; k < AC_LG; k++) acc[k] = __builtin_fmaf(xi, xs[i + g0 + k], acc[k]);
+            for (int g = 0; g < NG; g++) {
+                load8(wb, p0 + lag0 + 8 * g + 8);
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int slot = j + kk;                           // 0..14
+                        acc[8 * g + kk] = __builtin_fmaf(xl[j], slot < 8 ? wa[slot] : wb[slot - 8], acc[8 * g + kk]);
+                    }
+#pragma unroll
+                for (int j = 0; j < 8; j++) wa[j] = wb[j];
             }
         }
-        // reduce over the lanes of each wave, then over the waves
 #pragma unroll
-        for (int k = 0; k < AC_LG; k++) {
-            float v = acc[k];
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
-            if (lane == 0) red[wave][k] = v;
-        }
-        __syncthreads();
-        if (tid < AC_LG && g0 + tid <= p) {
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < AC_THREADS / 64; w++) v += red[w][tid];
-            r[(size_t)f * (p + 1) + g0 + tid] = v;
+        for (int k = 0; k < 8 * NG; k++) {
+            const float v = wave_sum(acc[k]);
+            if (lane == 0 && lag0 + k <= p) r[(size_t)f * (p + 1) + lag0 + k] = v;
         }
     }
 }
@@ -122,7 +152,22 @@ extern "C" int llzs_autocorr_mc_f32(const float *x, float *r, int frames, int n,
         llzs_set_error("autocorr_mc_f32: bad arguments (frames=%d n=%d p=%d; p < n, p <= 255)", frames, n, p);
         return LLZ_ERR_ARG;
     }
-    hipLaunchKernelGGL(k_autocorr_mc_f32, dim3((unsigned)frames), dim3(AC_THREADS), 0, as_stream(stream), x, r, n, p);
+    long blocks = ((long)frames + AC_WAVES - 1) / AC_WAVES;
+    if (blocks > 256L * 4) blocks = 256L * 4;                       // persistent: frames dealt round robin to the waves
+    // lags are done 64 per launch (8 groups of 8 accumulators per lane); p > 63 re-reads the frames per block of lags
+#define LLZ_AC_LAUNCH(NG, LAG0)                                                                                   \
+    hipLaunchKernelGGL(k_autocorr_mc_f32<NG>, dim3((unsigned)blocks), dim3(64 * AC_WAVES), 0, as_stream(stream), x, r, \
+                       frames, n, p, LAG0)
+    for (int lag0 = 0; lag0 <= p; lag0 += 64) {
+        const int ng = (((p - lag0) < 63 ? (p - lag0) : 63) + 8) / 8;
+        if (ng <= 1) LLZ_AC_LAUNCH(1, lag0);
+        else if (ng <= 2) LLZ_AC_LAUNCH(2, lag0);
+        else if (ng <= 3) LLZ_AC_LAUNCH(3, lag0);
+        else if (ng <= 4) LLZ_AC_LAUNCH(4, lag0);
+        else if (ng <= 5) LLZ_AC_LAUNCH(5, lag0);
+        else LLZ_AC_LAUNCH(8, lag0);
+    }
+#undef LLZ_AC_LAUNCH
     LLZ_LAUNCH_CHECK("k_autocorr_mc_f32");
     return LLZ_OK;
 }
