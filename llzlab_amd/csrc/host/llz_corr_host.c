@@ -142,7 +142,6 @@ int llz_autocorr_mc(const float *x, float *r, int frames, int n, int p, void *st
 
 typedef struct {
     int tag, frames, n, fft_len;
-    float *d_z;             /* frames x fft_len complex */
     float *d_cs;            /* fft_len cos then fft_len sin */
     void *stream;
     llz_stage_t st_in, st_out;
@@ -151,7 +150,7 @@ typedef struct {
 static void acfm_destroy(acfm_t *f)
 {
     if (!f) return;
-    llzs_free(f->d_z); llzs_free(f->d_cs);
+    llzs_free(f->d_cs);
     llz_stage_release(&f->st_in); llz_stage_release(&f->st_out);
     f->tag = 0;
     free(f);
@@ -176,8 +175,7 @@ unsigned long llz_autocorr_fast_mc_init(int frames, int n)
             cs[F + i] = (float)sin(ang);
         }
         f->d_cs = (float *)llzs_malloc(sizeof(float) * 2 * (size_t)F);
-        f->d_z = (float *)llzs_malloc(sizeof(float) * 2 * (size_t)F * (size_t)frames);
-        rc = (f->d_cs && f->d_z) ? llzs_h2d(f->d_cs, cs, sizeof(float) * 2 * (size_t)F, NULL) : LLZ_ERR_NOMEM;
+        rc = f->d_cs ? llzs_h2d(f->d_cs, cs, sizeof(float) * 2 * (size_t)F, NULL) : LLZ_ERR_NOMEM;
     }
     free(cs);
     if (rc != LLZ_OK) {
@@ -226,11 +224,8 @@ int llz_autocorr_fast_mc(unsigned long handle, const float *x, float *r, int p)
         d_r = (float *)llz_stage_reserve(&f->st_out, rb);
         if (!d_r) rc = LLZ_ERR_NOMEM;
     }
-    if (rc == LLZ_OK) rc = llzs_acf_pack(d_x, f->d_z, f->frames, f->n, f->fft_len, f->stream);
-    if (rc == LLZ_OK) rc = llzs_fft_f32(f->d_z, f->frames, f->fft_len, f->d_cs, 0, f->stream);
-    if (rc == LLZ_OK) rc = llzs_acf_power(f->d_z, f->frames, f->n, f->fft_len, f->stream);
-    if (rc == LLZ_OK) rc = llzs_fft_f32(f->d_z, f->frames, f->fft_len, f->d_cs, 1, f->stream);
-    if (rc == LLZ_OK) rc = llzs_acf_extract(f->d_z, d_r, f->frames, p, f->fft_len, f->stream);
+    /* pack -> FFT -> |X|^2 (first n bins) -> IFFT -> 2 Re, fused in LDS */
+    if (rc == LLZ_OK) rc = llzs_acf_fused_f32(d_x, d_r, f->frames, f->n, p, f->fft_len, f->d_cs, f->stream);
     if (rc == LLZ_OK && !r_dev) rc = llzs_d2h(r, d_r, rb, f->stream);
     return rc;
 }

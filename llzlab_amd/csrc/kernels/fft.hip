@@ -211,6 +211,74 @@ k_fft_radix2(typename A::data_t *__restrict__ data, int count, int size, int log
     }
 }
 
+
+// FFT autocorrelation (reference libllzfilter/llz_corr.c:155-177) fused in LDS: real frame -> zero-padded complex ->
+// forward passes (bins end up bit-reversed, which is exactly the order the inverse DIT passes consume) -> power
+// spectrum of the first n bins, everything else zero, 1/F folded in -> inverse passes -> r[k] = 2 Re.  One read of the
+// frame and p+1 floats written per frame instead of five launches over a 2F-float buffer.
+__global__ void __launch_bounds__(FFT_THREADS)
+k_acf_fused_f32(const float *__restrict__ x, float *__restrict__ r, int frames, int n, int p, int size, int log2n,
+                const float *__restrict__ cs, int tpw, unsigned groups)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cpx<float> *s = reinterpret_cast<cpx<float> *>(smem_raw);
+    const int tid = threadIdx.x;
+    const int tr0 = blockIdx.x * tpw;
+    const int ntr = min(tpw, frames - tr0);
+    const int tstride = fft_phys(size) + 1;
+    const int total = ntr << log2n;
+    for (int e = tid; e < total; e += FFT_THREADS) {
+        const int tr = e >> log2n, i = e & (size - 1);
+        cpx<float> v;
+        v.re = i < n ? x[(size_t)(tr0 + tr) * n + i] : 0.f;
+        v.im = 0.f;
+        s[tr * tstride + fft_phys(i)] = v;
+    }
+    __syncthreads();
+    int done = 0;
+#pragma unroll 1
+    for (int pss = 0; pss < 4; pss++) {
+        const int G = (groups >> (4 * pss)) & 15;
+        if (G == 0) break;
+        const int log2step = log2n - done - G;
+        switch (G) {
+        case 1: fft_pass<arith_f32, 1, false>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
+        case 2: fft_pass<arith_f32, 2, false>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
+        case 3: fft_pass<arith_f32, 3, false>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
+        default: fft_pass<arith_f32, 4, false>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
+        }
+        done += G;
+    }
+    // position j holds bin brev(j): keep |X|^2 / F for bins < n (llz_corr.c:165-170; the 1/F of llz_ifft folded in)
+    const float inv = 1.0f / (float)size;
+    for (int e = tid; e < total; e += FFT_THREADS) {
+        const int tr = e >> log2n, j = e & (size - 1);
+        const int bin = (int)(__brev((unsigned)j) >> (32 - log2n));
+        cpx<float> &v = s[tr * tstride + fft_phys(j)];
+        const float pw = bin < n ? __builtin_fmaf(v.re, v.re, v.im * v.im) * inv : 0.f;
+        v.re = pw;
+        v.im = 0.f;
+    }
+    __syncthreads();
+    done = 0;
+#pragma unroll 1
+    for (int pss = 0; pss < 4; pss++) {
+        const int G = (groups >> (4 * pss)) & 15;
+        if (G == 0) break;
+        switch (G) {
+        case 1: fft_pass<arith_f32, 1, true>(s, ntr, size, log2n, done, tstride, cs, tid); break;
+        case 2: fft_pass<arith_f32, 2, true>(s, ntr, size, log2n, done, tstride, cs, tid); break;
+        case 3: fft_pass<arith_f32, 3, true>(s, ntr, size, log2n, done, tstride, cs, tid); break;
+        default: fft_pass<arith_f32, 4, true>(s, ntr, size, log2n, done, tstride, cs, tid); break;
+        }
+        done += G;
+    }
+    for (int e = tid; e < ntr * (p + 1); e += FFT_THREADS) {
+        const int tr = e / (p + 1), k = e - tr * (p + 1);
+        r[(size_t)(tr0 + tr) * (p + 1) + k] = s[tr * tstride + fft_phys(k)].re * 2.f;      // llz_corr.c:173
+    }
+}
+
 template <typename A>
 int launch_fft(typename A::data_t *data, int count, int size, const typename A::tw_t *cs, int inverse,
                void *stream, const char *name)
@@ -267,4 +335,34 @@ extern "C" int llzs_fft_f64(double *data, int size, const double *cs, int invers
 extern "C" int llzs_fft_fixed(int *data, int count, int size, const short *cs, int inverse, void *stream)
 {
     return launch_fft<arith_q15>(data, count, size, cs, inverse, stream, "k_fft_radix2<q15>");
+}
+
+// fused FFT autocorrelation of `frames` frames of n float32 samples: fft length size = 2^ceil(log2(2n)) <= 4096
+extern "C" int llzs_acf_fused_f32(const float *x, float *r, int frames, int n, int p, int size, const float *cs,
+                                  void *stream)
+{
+    int log2n = 0;
+    while ((1 << log2n) < size) log2n++;
+    if (!x || !r || !cs || frames < 1 || n < 1 || p < 0 || p >= size || size < 8 || size > 4096 ||
+        (1 << log2n) != size || 2 * n > size) {
+        llzs_set_error("acf_fused_f32: bad arguments (n=%d p=%d size=%d)", n, p, size);
+        return LLZ_ERR_ARG;
+    }
+    const int passes = (log2n + 3) / 4;
+    unsigned groups = 0;
+    for (int q = 0, left = log2n; q < passes; q++) {
+        const int G = (left + (passes - q) - 1) / (passes - q);
+        groups |= (unsigned)G << (4 * q);
+        left -= G;
+    }
+    int tpw = 2048 / size;
+    if (tpw < 1) tpw = 1;
+    if (tpw > frames) tpw = frames;
+    const int tstride = size + (size >> 5) + 1;
+    const size_t lds = (size_t)tpw * tstride * 2 * sizeof(float);
+    const unsigned blocks = (unsigned)((frames + tpw - 1) / tpw);
+    hipLaunchKernelGGL(k_acf_fused_f32, dim3(blocks), dim3(FFT_THREADS), lds, as_stream(stream), x, r, frames, n, p,
+                       size, log2n, cs, tpw, groups);
+    LLZ_LAUNCH_CHECK("k_acf_fused_f32");
+    return LLZ_OK;
 }

@@ -104,6 +104,8 @@ int llzs_autocorr_mc_f32(const float *x, float *r, int frames, int n, int p, voi
 int llzs_acf_pack(const float *x, float *z, int frames, int n, int F, void *stream);
 int llzs_acf_power(float *z, int frames, int n, int F, void *stream);
 int llzs_acf_extract(const float *z, float *r, int frames, int p, int F, void *stream);
+/* the same five steps fused in LDS (fft.hip): one read of the frames, p+1 floats written per frame */
+int llzs_acf_fused_f32(const float *x, float *r, int frames, int n, int p, int size, const float *cs, void *stream);
 
 /* ---- PCM ingest / egress ---- */
 int llzs_pcm_deinterleave_i16_f32(const short *in, float *out, int channels, long n, float scale, void *stream);
