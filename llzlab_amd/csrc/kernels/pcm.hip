@@ -8,6 +8,7 @@ namespace {
 
 constexpr int PCM_THREADS = 256;
 constexpr int PCM_TILE = 4096;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct pcm_tile {
     int tc, ts;              // channels and samples per tile
@@ -32,32 +33,136 @@ k_pcm_transpose(const short *__restrict__ ileaved_in, float *__restrict__ planar
     const int tc = min(t.tc, channels - c0);
     const int ts = (int)min((long)t.ts, n - i0);
     const int total = t.tc * t.ts;
+    // the interleaved side moves 4 int16 (8 bytes) per lane when the tile's channel run allows it (tc % 4 == 0 and
+    // the rows are 8-byte aligned): a wave then covers 512 contiguous bytes instead of 128
+    const bool vec4 = (t.tc & 3) == 0 && (channels & 3) == 0 && tc == t.tc &&
+                      ((reinterpret_cast<uintptr_t>(DEINTERLEAVE ? (const void *)ileaved_in : (const void *)ileaved_out) & 7) == 0);
+    // whole-row tiles with a channel count that is not a multiple of 4 (stereo, 5.1 ...): the tile's interleaved bytes
+    // are one contiguous run, read 8 bytes at a time and split per element
+    const bool flat4 = !vec4 && t.tc == channels && (total & 3) == 0 && ((i0 * channels) & 3) == 0 &&
+                       ((reinterpret_cast<uintptr_t>(DEINTERLEAVE ? (const void *)ileaved_in : (const void *)ileaved_out) & 7) == 0);
+    // the planar side moves 4 floats per lane when the tile is full along time and the rows are 16-byte aligned
+    const bool pvec4 = (t.ts & 3) == 0 && (n & 3) == 0 && ts == t.ts &&
+                       ((reinterpret_cast<uintptr_t>(DEINTERLEAVE ? (const void *)planar_out : (const void *)planar_in) & 15) == 0);
     if (DEINTERLEAVE) {
-        for (int e = tid; e < total; e += PCM_THREADS) {               // e = s*TC + c: contiguous along channels
-            const int s = div_magic(e, t.tc_magic, t.tc), c = e - s * t.tc;
-            if (s < ts && c < tc) {
-                const int a = c * t.ts + s;
-                tile[a + (a >> 5)] = (float)ileaved_in[(i0 + s) * channels + c0 + c] * scale;
+        if (vec4) {
+            for (int e4 = tid; e4 < total / 4; e4 += PCM_THREADS) {    // e = s*TC + c, 4 consecutive channels
+                const int e = e4 * 4;
+                const int s = div_magic(e, t.tc_magic, t.tc), c = e - s * t.tc;
+                if (s < ts) {
+                    const short4 v = *reinterpret_cast<const short4 *>(&ileaved_in[(i0 + s) * channels + c0 + c]);
+                    const int a = c * t.ts + s;
+                    tile[a + (a >> 5)] = (float)v.x * scale;
+                    tile[(a + t.ts) + ((a + t.ts) >> 5)] = (float)v.y * scale;
+                    tile[(a + 2 * t.ts) + ((a + 2 * t.ts) >> 5)] = (float)v.z * scale;
+                    tile[(a + 3 * t.ts) + ((a + 3 * t.ts) >> 5)] = (float)v.w * scale;
+                }
+            }
+        } else if (flat4) {
+            const int live = ts * t.tc;                                // the tile's rows are one contiguous run
+            const short *src = ileaved_in + i0 * channels;
+            for (int e4 = tid; e4 < total / 4; e4 += PCM_THREADS) {
+                const int e = e4 * 4;
+                if (e + 3 < live) {
+                    const short4 v = *reinterpret_cast<const short4 *>(&src[e]);
+                    const short q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int s = div_magic(e + j, t.tc_magic, t.tc), c = e + j - s * t.tc;
+                        const int a = c * t.ts + s;
+                        tile[a + (a >> 5)] = (float)q[j] * scale;
+                    }
+                } else {
+                    for (int j = 0; j < 4 && e + j < live; j++) {
+                        const int s = div_magic(e + j, t.tc_magic, t.tc), c = e + j - s * t.tc;
+                        const int a = c * t.ts + s;
+                        tile[a + (a >> 5)] = (float)src[e + j] * scale;
+                    }
+                }
+            }
+        } else {
+            for (int e = tid; e < total; e += PCM_THREADS) {           // e = s*TC + c: contiguous along channels
+                const int s = div_magic(e, t.tc_magic, t.tc), c = e - s * t.tc;
+                if (s < ts && c < tc) {
+                    const int a = c * t.ts + s;
+                    tile[a + (a >> 5)] = (float)ileaved_in[(i0 + s) * channels + c0 + c] * scale;
+                }
             }
         }
         __syncthreads();
-        for (int e = tid; e < total; e += PCM_THREADS) {               // e = c*TS + s: contiguous along time
-            const int c = div_magic(e, t.ts_magic, t.ts), s = e - c * t.ts;
-            if (s < ts && c < tc) planar_out[(size_t)(c0 + c) * n + i0 + s] = tile[e + (e >> 5)];
+        if (pvec4) {
+            for (int e4 = tid; e4 < total / 4; e4 += PCM_THREADS) {    // e = c*TS + s, 4 consecutive samples
+                const int e = e4 * 4;
+                const int c = div_magic(e, t.ts_magic, t.ts), s = e - c * t.ts;
+                if (c < tc) {
+                    const int a = e + (e >> 5);
+                    const f32x4 v = {tile[a], tile[a + 1], tile[a + 2], tile[a + 3]};
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(&planar_out[(size_t)(c0 + c) * n + i0 + s]));
+                }
+            }
+        } else {
+            for (int e = tid; e < total; e += PCM_THREADS) {           // e = c*TS + s: contiguous along time
+                const int c = div_magic(e, t.ts_magic, t.ts), s = e - c * t.ts;
+                if (s < ts && c < tc) planar_out[(size_t)(c0 + c) * n + i0 + s] = tile[e + (e >> 5)];
+            }
         }
     } else {
-        for (int e = tid; e < total; e += PCM_THREADS) {
-            const int c = div_magic(e, t.ts_magic, t.ts), s = e - c * t.ts;
-            if (s < ts && c < tc) tile[e + (e >> 5)] = planar_in[(size_t)(c0 + c) * n + i0 + s];
+        if (pvec4) {
+            for (int e4 = tid; e4 < total / 4; e4 += PCM_THREADS) {
+                const int e = e4 * 4;
+                const int c = div_magic(e, t.ts_magic, t.ts), s = e - c * t.ts;
+                if (c < tc) {
+                    const f32x4 v = __builtin_nontemporal_load(
+                        reinterpret_cast<const f32x4 *>(&planar_in[(size_t)(c0 + c) * n + i0 + s]));
+                    const int a = e + (e >> 5);
+                    tile[a] = v.x; tile[a + 1] = v.y; tile[a + 2] = v.z; tile[a + 3] = v.w;
+                }
+            }
+        } else {
+            for (int e = tid; e < total; e += PCM_THREADS) {
+                const int c = div_magic(e, t.ts_magic, t.ts), s = e - c * t.ts;
+                if (s < ts && c < tc) tile[e + (e >> 5)] = planar_in[(size_t)(c0 + c) * n + i0 + s];
+            }
         }
         __syncthreads();
-        for (int e = tid; e < total; e += PCM_THREADS) {
-            const int s = div_magic(e, t.tc_magic, t.tc), c = e - s * t.tc;
-            if (s < ts && c < tc) {
-                const int a = c * t.ts + s;
-                float y = tile[a + (a >> 5)] * scale;
-                y = fminf(fmaxf(y, -32768.f), 32767.f);                // llz_resample.c:596-599
-                ileaved_out[(i0 + s) * channels + c0 + c] = (short)(int)y;   // :601, truncation toward zero
+        auto quant = [&](int a) {
+            float y = tile[a + (a >> 5)] * scale;
+            y = fminf(fmaxf(y, -32768.f), 32767.f);                    // llz_resample.c:596-599
+            return (short)(int)y;                                      // :601, truncation toward zero
+        };
+        if (vec4) {
+            for (int e4 = tid; e4 < total / 4; e4 += PCM_THREADS) {
+                const int e = e4 * 4;
+                const int s = div_magic(e, t.tc_magic, t.tc), c = e - s * t.tc;
+                if (s < ts) {
+                    const int a = c * t.ts + s;
+                    short4 v;
+                    v.x = quant(a); v.y = quant(a + t.ts); v.z = quant(a + 2 * t.ts); v.w = quant(a + 3 * t.ts);
+                    *reinterpret_cast<short4 *>(&ileaved_out[(i0 + s) * channels + c0 + c]) = v;
+                }
+            }
+        } else if (flat4) {
+            const int live = ts * t.tc;
+            short *dst = ileaved_out + i0 * channels;
+            for (int e4 = tid; e4 < total / 4; e4 += PCM_THREADS) {
+                const int e = e4 * 4;
+                short q[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int s = div_magic(e + j, t.tc_magic, t.tc), c = e + j - s * t.tc;
+                    q[j] = quant(c * t.ts + s);
+                }
+                if (e + 3 < live) {
+                    short4 v; v.x = q[0]; v.y = q[1]; v.z = q[2]; v.w = q[3];
+                    *reinterpret_cast<short4 *>(&dst[e]) = v;
+                } else {
+                    for (int j = 0; j < 4 && e + j < live; j++) dst[e + j] = q[j];
+                }
+            }
+        } else {
+            for (int e = tid; e < total; e += PCM_THREADS) {
+                const int s = div_magic(e, t.tc_magic, t.tc), c = e - s * t.tc;
+                if (s < ts && c < tc) ileaved_out[(i0 + s) * channels + c0 + c] = quant(c * t.ts + s);
             }
         }
     }

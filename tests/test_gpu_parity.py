@@ -504,7 +504,8 @@ def test_autocorr_fast_mc_vs_oracle(dev, oracle, frames, n, p):
 
 
 # ------------------------------------------------------------------------------------------------ PCM ingest (8f rank 2)
-@pytest.mark.parametrize("channels,n", [(1, 5000), (2, 48000), (6, 1000), (64, 4097), (100, 333), (4096, 70)])
+@pytest.mark.parametrize("channels,n", [(1, 5000), (1, 4099), (2, 48000), (2, 4099), (3, 1001), (6, 1000), (64, 4097), (64, 4096),
+                                        (100, 333), (4096, 70), (4096, 128)])
 def test_pcm_deinterleave_and_back_exact(dev, channels, n):
     """numpy restatement: planar = ileaved.T / 32768 (exact in float32); back: clamp, truncate toward zero
     (reference llz_resample.c:596-601)"""
