@@ -16,7 +16,7 @@ INCLUDE_DIR = os.path.join(ROOT, "include")
 
 BAD_HANDLE = C.c_ulong(-1).value
 HAMMING, BLACKMAN, KAISER = 0, 1, 2
-FIR_ALGO_AUTO, FIR_ALGO_TIME, FIR_ALGO_OVERLAP_SAVE = 0, 1, 2
+FIR_ALGO_AUTO, FIR_ALGO_TIME, FIR_ALGO_OVERLAP_SAVE, FIR_ALGO_TIME_MFMA = 0, 1, 2, 3
 PCM_F32, PCM_I16 = 0, 1
 
 _lib = None

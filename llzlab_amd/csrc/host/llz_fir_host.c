@@ -212,15 +212,23 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
         llzs_set_error("llz_fir_filter_mc_init: channels %d frame_len %d flt_len %d", channels, frame_len, flt_len);
         return LLZ_BAD_HANDLE;
     }
-    if (algo == LLZ_FIR_ALGO_AUTO)
-        /* measured on 4096 ch x 2^20 (tools/fir_crossover.py): time domain 7.2 / 8.3 / 10.0 ms at 17 / 33 / 63 taps,
-         * overlap-save 7.0 ms at any length up to 257 -> overlap-save from 33 taps on */
-        algo = (flt_len > 32 && flt_len <= LLZS_OLS_MAX_TAPS) ? LLZ_FIR_ALGO_OVERLAP_SAVE : LLZ_FIR_ALGO_TIME;
+    if (algo == LLZ_FIR_ALGO_AUTO) {
+        /* measured on 4096 ch x 2^20 (tools/fir_crossover.py): time domain 6.0 / 6.4 / 7.9 / 9.5 ms at 9 / 17 / 33 / 63
+         * taps, overlap-save 6.7 ms at any length up to 257 -> overlap-save from 33 taps on; beyond 257 taps the
+         * matrix-core form of the time domain (23.7 ms at 257 taps against 31.9 ms on the VALU) */
+        if (flt_len <= 32) algo = LLZ_FIR_ALGO_TIME;
+        else if (flt_len <= LLZS_OLS_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE;
+        else algo = llzs_fir_mfma_f32_fits(flt_len, 1) ? LLZ_FIR_ALGO_TIME_MFMA : LLZ_FIR_ALGO_TIME;
+    }
     if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE && flt_len > LLZS_OLS_MAX_TAPS) {
         llzs_set_error("llz_fir_filter_mc_init: overlap-save supports at most %d taps", LLZS_OLS_MAX_TAPS);
         return LLZ_BAD_HANDLE;
     }
-    if (algo != LLZ_FIR_ALGO_TIME && algo != LLZ_FIR_ALGO_OVERLAP_SAVE) {
+    if (algo == LLZ_FIR_ALGO_TIME_MFMA && !llzs_fir_mfma_f32_fits(flt_len, 1)) {
+        llzs_set_error("llz_fir_filter_mc_init: %d taps do not fit the matrix-core kernel's LDS tile", flt_len);
+        return LLZ_BAD_HANDLE;
+    }
+    if (algo != LLZ_FIR_ALGO_TIME && algo != LLZ_FIR_ALGO_OVERLAP_SAVE && algo != LLZ_FIR_ALGO_TIME_MFMA) {
         llzs_set_error("llz_fir_filter_mc_init: unknown algo %d", algo);
         return LLZ_BAD_HANDLE;
     }
@@ -339,6 +347,9 @@ static int firm_launch(firm_t *f, const float *d_in, float *d_out, int n, long p
     if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE)
         rc = llzs_fir_ols_f32(d_in, d_out, hist, f->d_hfreq, f->d_twid, f->channels, n, pitch_in, pitch_out,
                               f->flt_len, f->stream);
+    else if (algo == LLZ_FIR_ALGO_TIME_MFMA)
+        rc = llzs_fir_mfma_f32(d_in, d_out, hist, f->d_taps, f->channels, n, n, pitch_in, pitch_out, f->flt_len, 1,
+                               1.0f, f->stream);
     else
         rc = llzs_fir_td_f32(d_in, d_out, hist, f->d_taps, f->channels, n, pitch_in, pitch_out, f->flt_len,
                              f->stream);

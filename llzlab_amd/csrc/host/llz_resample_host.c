@@ -258,6 +258,7 @@ typedef struct {
     void *d_mat;                /* float (F32) or double (I16) L x Q */
     float *d_phase;             /* F32, L == 1: M x tp phase taps for the polyphase fast path (NULL otherwise) */
     int tp;
+    int use_mfma;               /* F32, L == 1: decimating FIR on the matrix cores (fir_mfma.hip) */
     void *d_hist[2];            /* [channels][Q-1] samples of the handle's format, ping-pong */
     int cur;
     long long in_count, out_count;   /* samples consumed / produced per channel so far */
@@ -287,6 +288,8 @@ static int rsm_upload_matrix(rsm_t *r)
     for (size_t i = 0; i < count; i++) m32[i] = (float)r->taps.mat[i];
     int rc = llzs_h2d(r->d_mat, m32, sizeof(float) * count, NULL);
     if (rc == LLZ_OK && r->L == 1) {
+        const char *path = getenv("LLZ_RS_DEC_PATH");       /* "valu" selects the LDS polyphase kernel (A/B runs) */
+        r->use_mfma = llzs_fir_mfma_f32_fits(r->Q, r->M) && !(path && strcmp(path, "valu") == 0);
         /* phase taps for the decimator fast path: gp[m][j] = g[0][j*M + m], rows zero padded to tp */
         const int per_phase = (r->Q + r->M - 1) / r->M;
         r->tp = (per_phase + 15) & ~15;
@@ -434,6 +437,9 @@ long llz_resample_mc(unsigned long handle, const void *in, long n_in, void *out)
             rc = llzs_resample_i16((const short *)d_in, (short *)d_out, (const short *)hist,
                                    (const double *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->L, r->M,
                                    r->Q, r->gain, r->out_count, r->in_count, r->stream);
+        else if (r->use_mfma)
+            rc = llzs_fir_mfma_f32((const float *)d_in, (float *)d_out, (const float *)hist, (const float *)r->d_mat,
+                                   r->channels, n_in, n_out, n_in, n_out, r->Q, r->M, (float)r->gain, r->stream);
         else if (r->d_phase)
             rc = llzs_resample_dec_f32((const float *)d_in, (float *)d_out, (const float *)hist, r->d_phase,
                                        r->channels, n_in, n_out, n_in, n_out, r->M, r->Q, r->tp, (float)r->gain,

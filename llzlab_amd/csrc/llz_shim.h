@@ -38,6 +38,12 @@ int llzs_fir_td_f32(const float *in, float *out, const float *hist, const float 
  * W_1024^(a*b).  Requires flt_len <= 257. */
 int llzs_fir_ols_f32(const float *in, float *out, const float *hist, const float *hfreq, const float *twid,
                      int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream);
+/* time domain on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), with optional decimation:
+ * y[c][i] = gain * sum_{k<T} taps[k] * x[c][i*M - k], x[c][<0] = hist[c][T-1+idx] (hist NULL = zeros); n_out outputs
+ * per channel from n_in inputs, (n_out-1)*M < n_in.  taps: T floats (no padding needed). */
+int llzs_fir_mfma_f32(const float *in, float *out, const float *hist, const float *taps, int channels,
+                      long n_in, long n_out, long in_pitch, long out_pitch, int T, int M, float gain, void *stream);
+int llzs_fir_mfma_f32_fits(int T, int M);           /* 1 when the LDS image of one tile fits */
 /* hist_new[c][:] = last (flt_len-1) samples of concat(hist_old[c], in[c][0:n]) */
 int llzs_fir_tail_f32(const float *in, const float *hist_old, float *hist_new,
                       int channels, int n, long in_pitch, int flt_len, void *stream);

@@ -89,8 +89,11 @@ def test_fir_single_channel_rejects_other_frame_len(dev):
 
 @pytest.mark.parametrize("flt_len,algo", [(63, filters.FIR_ALGO_TIME), (257, filters.FIR_ALGO_TIME),
                                           (257, filters.FIR_ALGO_OVERLAP_SAVE), (200, filters.FIR_ALGO_OVERLAP_SAVE),
-                                          (5, filters.FIR_ALGO_OVERLAP_SAVE), (1, filters.FIR_ALGO_TIME)])
-@pytest.mark.parametrize("channels,n", [(3, 4096), (5, 1536 * 3), (2, 1000), (7, 2049)])
+                                          (5, filters.FIR_ALGO_OVERLAP_SAVE), (1, filters.FIR_ALGO_TIME),
+                                          (63, filters.FIR_ALGO_TIME_MFMA), (257, filters.FIR_ALGO_TIME_MFMA),
+                                          (32, filters.FIR_ALGO_TIME_MFMA), (1, filters.FIR_ALGO_TIME_MFMA),
+                                          (2, filters.FIR_ALGO_TIME_MFMA), (601, filters.FIR_ALGO_TIME_MFMA)])
+@pytest.mark.parametrize("channels,n", [(3, 4096), (5, 1536 * 3), (2, 1000), (7, 2049), (2, 20001)])
 def test_fir_mc_vs_oracle(dev, oracle, flt_len, algo, channels, n):
     taps = oracle.fir_design(po.LPF, flt_len, 0.2, 0.0, po.KAISER) if flt_len > 1 else np.array([0.75])
     x = torch.empty(channels, n, dtype=torch.float32, device=dev)
@@ -104,7 +107,7 @@ def test_fir_mc_vs_oracle(dev, oracle, flt_len, algo, channels, n):
     f.close()
 
 
-@pytest.mark.parametrize("algo", [filters.FIR_ALGO_TIME, filters.FIR_ALGO_OVERLAP_SAVE])
+@pytest.mark.parametrize("algo", [filters.FIR_ALGO_TIME, filters.FIR_ALGO_OVERLAP_SAVE, filters.FIR_ALGO_TIME_MFMA])
 def test_fir_mc_streaming_frames_and_flush(dev, oracle, algo):
     """three equal frames == one long frame (history carried on the device), then flush == the filter's tail"""
     d = load("fir_stream.npz")
@@ -144,7 +147,7 @@ def test_fir_mc_host_pointers_and_errors(dev, oracle):
     assert filters.FirFilterMC(2, 64, np.ones(257)).algo == filters.FIR_ALGO_OVERLAP_SAVE
     assert filters.FirFilterMC(2, 64, np.ones(63)).algo == filters.FIR_ALGO_OVERLAP_SAVE      # AUTO: 33..257 taps
     assert filters.FirFilterMC(2, 64, np.ones(32)).algo == filters.FIR_ALGO_TIME
-    assert filters.FirFilterMC(2, 64, np.ones(300)).algo == filters.FIR_ALGO_TIME
+    assert filters.FirFilterMC(2, 64, np.ones(300)).algo == filters.FIR_ALGO_TIME_MFMA
 
 
 def test_fir_linearity_and_impulse_large(dev):

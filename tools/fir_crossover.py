@@ -4,13 +4,13 @@ import torch
 from llzlab_amd import capi, filters
 dev = torch.device("cuda:0"); L = capi.lib(); capi.check(L.llz_hip_set_device(0), "dev")
 s = torch.cuda.current_stream(); sp = s.cuda_stream
-for ch in (64, 4096):
+for ch in (4096,):
     n = 1 << 20
     x = torch.empty(ch, n, dtype=torch.float32, device=dev); y = torch.empty_like(x)
     filters.synth_f32(x, 1, stream=s)
-    for taps_n in (17, 33, 63):
+    for taps_n in (9, 17, 33, 63, 97, 129, 257):
         taps = filters.fir_design("lpf", taps_n, 0.25, 0.0, filters.HAMMING)
-        for algo in (1, 2):
+        for algo in (1, 2, 3):
             f = filters.FirFilterMC(ch, n, taps, algo=algo, stream=s)
             f.filter(x, y); torch.cuda.synchronize()
             t = L.llz_hip_timer_new(); L.llz_hip_timer_start(t, sp)
