@@ -1,0 +1,18 @@
+import sys, os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch
+from llzlab_amd import capi, filters
+dev = torch.device("cuda:0"); L = capi.lib(); capi.check(L.llz_hip_set_device(0), "dev")
+s = torch.cuda.current_stream(); sp = s.cuda_stream
+ch, n = 4096, 1 << 20
+x = torch.empty(ch, n, dtype=torch.float32, device=dev); y = torch.empty_like(x)
+filters.synth_f32(x, 1, stream=s)
+for taps_n in [int(a) for a in sys.argv[1:]] or [9, 257]:
+    taps = filters.fir_design("lpf", taps_n, 0.25, 0.0, filters.HAMMING)
+    f = filters.FirFilterMC(ch, n, taps, algo=3, stream=s)
+    f.filter(x, y); torch.cuda.synchronize()
+    t = L.llz_hip_timer_new(); L.llz_hip_timer_start(t, sp)
+    for _ in range(5): f.filter(x, y)
+    L.llz_hip_timer_stop(t, sp); ms = L.llz_hip_timer_ms(t) / 5
+    print(f"{ch}ch taps={taps_n} mfma: {ms:.3f} ms {8*ch*n/ms/1e6:.0f} GB/s")
+    f.close()
