@@ -14,7 +14,14 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "profile_" + tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-shutil.copy(glob.glob(src + "/stats/*/*_kernel_stats.csv")[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+
+
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: take the latest run's file, not the first match"""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+shutil.copy(newest(src + "/stats/*/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
 for name in ("bench.json", "bench_under_rocprof.json"):
     line = [l for l in open(os.path.join(src, name)) if l.startswith("{")][0]
     open(os.path.join(dst, f"{tag}_{name}"), "w").write(line)
@@ -23,7 +30,7 @@ kern = bench["roofline"]["kernel"]
 
 
 def counters(sub):
-    f = glob.glob(f"{src}/{sub}/*/*_counter_collection.csv")[0]
+    f = newest(f"{src}/{sub}/*/*_counter_collection.csv")
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
