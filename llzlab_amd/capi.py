@@ -17,6 +17,7 @@ INCLUDE_DIR = os.path.join(ROOT, "include")
 BAD_HANDLE = C.c_ulong(-1).value
 HAMMING, BLACKMAN, KAISER = 0, 1, 2
 FIR_ALGO_AUTO, FIR_ALGO_TIME, FIR_ALGO_OVERLAP_SAVE, FIR_ALGO_TIME_MFMA = 0, 1, 2, 3
+OVERLAP_HIGH, OVERLAP_LOW = 0, 1      # llz_asmodel.h: 3/4 and 1/2 overlap
 PCM_F32, PCM_I16 = 0, 1
 
 _lib = None
@@ -178,6 +179,19 @@ def lib():
     sig("llz_autocorr_fast_mc_uninit", None, ul)
     sig("llz_autocorr_fast_mc", i, ul, vp, vp, i)
     sig("llz_autocorr_fast_mc_set_stream", i, ul, vp)
+    # llz_asmodel.h
+    for n in ("llz_analysis_fft_init", "llz_synthesis_fft_init"):
+        sig(n, ul, i, i, i)
+    sig("llz_analysis_fft_uninit", None, ul)
+    sig("llz_synthesis_fft_uninit", None, ul)
+    sig("llz_analysis_fft", None, ul, dp, dp, dp)
+    sig("llz_synthesis_fft", None, ul, dp, dp, dp)
+    sig("llz_stft_mc_init", ul, i, i, i, i)
+    sig("llz_stft_mc_uninit", None, ul)
+    sig("llz_stft_mc_bins", i, ul)
+    sig("llz_stft_mc_set_stream", i, ul, vp)
+    sig("llz_stft_mc_analysis", i, ul, vp, vp, vp, i)
+    sig("llz_stft_mc_synthesis", i, ul, vp, vp, vp, i)
     # llz_pcm.h
     sig("llz_pcm_deinterleave_i16_f32", i, vp, vp, i, lng, C.c_float, vp)
     sig("llz_pcm_interleave_f32_i16", i, vp, vp, i, lng, C.c_float, vp)

@@ -1,0 +1,303 @@
+/*
+ * llz_asmodel_host.c -- handle layer of the windowed-FFT analysis / synthesis frames: the
+ * reference's symbols (reference libllzfilter/llz_asmodel.c:109-310) and the float32 batch extension.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../../include/llz_asmodel.h"
+#include "../../../include/llz_fft.h"
+#include "llz_host.h"
+
+#define LLZ_TAG_ASM1 0x4c5a5331
+#define LLZ_TAG_ASMM 0x4c5a534d
+
+static int asm_shape(int overlap_hint, int frame_len, int *fft_len, double *magic)
+{
+    /* llz_asmodel.c:114-123 */
+    if (overlap_hint == LLZ_OVERLAP_HIGH) { *fft_len = frame_len << 2; *magic = 0.812; }
+    else if (overlap_hint == LLZ_OVERLAP_LOW) { *fft_len = frame_len << 1; *magic = 1; }
+    else return 0;
+    return frame_len >= 1 && *fft_len >= 2 && (*fft_len & (*fft_len - 1)) == 0;
+}
+
+static int asm_window(double *w, int n, win_t win_type)
+{
+    switch (win_type) {                                            /* llz_asmodel.c:133-143 */
+    case HAMMING: llz_hamming(w, n); return 1;
+    case BLACKMAN: llz_blackman(w, n); return 1;
+    case KAISER: llz_kaiser(w, n); return 1;
+    default: return 0;
+    }
+}
+
+/* ---- Part 1: reference symbols ---- */
+
+typedef struct {
+    int tag, frame_len, fft_len;
+    double *x_buf, *fft_buf, *window;
+    unsigned long h_fft;
+    double magic;
+} asm1_t;
+
+static void asm1_destroy(asm1_t *f)
+{
+    if (!f) return;
+    if (f->h_fft && f->h_fft != LLZ_BAD_HANDLE) llz_fft_uninit(f->h_fft);
+    free(f->x_buf); free(f->fft_buf); free(f->window);
+    f->tag = 0;
+    free(f);
+}
+
+static unsigned long asm1_init(int overlap_hint, int frame_len, win_t win_type, const char *who)
+{
+    int fft_len;
+    double magic;
+    if (!asm_shape(overlap_hint, frame_len, &fft_len, &magic) || fft_len > 4096) {
+        llzs_set_error("%s: overlap_hint %d frame_len %d (fft_len must be a power of two <= 4096)", who, overlap_hint,
+                       frame_len);
+        return LLZ_BAD_HANDLE;
+    }
+    asm1_t *f = (asm1_t *)calloc(1, sizeof(*f));
+    if (!f) return LLZ_BAD_HANDLE;
+    f->tag = LLZ_TAG_ASM1; f->frame_len = frame_len; f->fft_len = fft_len; f->magic = magic;
+    f->x_buf = (double *)calloc((size_t)fft_len, sizeof(double));
+    f->fft_buf = (double *)calloc(2 * (size_t)fft_len, sizeof(double));
+    f->window = (double *)calloc((size_t)fft_len, sizeof(double));
+    f->h_fft = llz_fft_init(fft_len);
+    if (!f->x_buf || !f->fft_buf || !f->window || f->h_fft == LLZ_BAD_HANDLE || !asm_window(f->window, fft_len, win_type)) {
+        if (f->window) llzs_set_error("%s: unknown window %d or FFT handle failed", who, (int)win_type);
+        asm1_destroy(f);
+        return LLZ_BAD_HANDLE;
+    }
+    return (unsigned long)f;
+}
+
+unsigned long llz_analysis_fft_init(int overlap_hint, int frame_len, win_t win_type)
+{
+    return asm1_init(overlap_hint, frame_len, win_type, "llz_analysis_fft_init");
+}
+
+unsigned long llz_synthesis_fft_init(int overlap_hint, int frame_len, win_t win_type)
+{
+    return asm1_init(overlap_hint, frame_len, win_type, "llz_synthesis_fft_init");
+}
+
+void llz_analysis_fft_uninit(unsigned long handle)
+{
+    if (LLZ_HANDLE_OK(handle, asm1_t, LLZ_TAG_ASM1)) asm1_destroy((asm1_t *)handle);
+}
+
+void llz_synthesis_fft_uninit(unsigned long handle)
+{
+    if (LLZ_HANDLE_OK(handle, asm1_t, LLZ_TAG_ASM1)) asm1_destroy((asm1_t *)handle);
+}
+
+void llz_analysis_fft(unsigned long handle, double *x, double *re, double *im)
+{
+    if (!LLZ_HANDLE_OK(handle, asm1_t, LLZ_TAG_ASM1) || !x || !re || !im) {
+        llzs_set_error("llz_analysis_fft: bad handle or arguments");
+        return;                                                     /* void in the reference ABI */
+    }
+    asm1_t *f = (asm1_t *)handle;
+    const int F = f->frame_len, N = f->fft_len;
+    /* llz_asmodel.c:188-204, statement for statement; the transform is the product's llz_fft (GPU, exact order) */
+    for (int i = 0; i < N - F; i++) f->x_buf[i] = f->x_buf[i + F];
+    for (int i = 0; i < F; i++) f->x_buf[i + N - F] = x[i];
+    for (int i = 0; i < N; i++) {
+        f->fft_buf[i + i] = f->x_buf[i] * f->window[i];
+        f->fft_buf[i + i + 1] = 0;
+    }
+    llz_fft(f->h_fft, f->fft_buf);
+    for (int i = 0; i < (N >> 1) + 1; i++) {
+        re[i] = f->fft_buf[i + i];
+        im[i] = f->fft_buf[i + i + 1];
+    }
+}
+
+void llz_synthesis_fft(unsigned long handle, double *re, double *im, double *x)
+{
+    if (!LLZ_HANDLE_OK(handle, asm1_t, LLZ_TAG_ASM1) || !x || !re || !im) {
+        llzs_set_error("llz_synthesis_fft: bad handle or arguments");
+        return;
+    }
+    asm1_t *f = (asm1_t *)handle;
+    const int F = f->frame_len, N = f->fft_len;
+    /* llz_asmodel.c:279-304 */
+    for (int i = 0; i < (N >> 1) + 1; i++) {
+        f->fft_buf[i + i] = re[i];
+        f->fft_buf[i + i + 1] = im[i];
+    }
+    for (int i = 0, j = (N >> 1) - 1; i < (N >> 1) - 1; i++, j--) {
+        f->fft_buf[N + 2 + 2 * i] = re[j];
+        f->fft_buf[N + 2 + 2 * i + 1] = -im[j];
+    }
+    llz_ifft(f->h_fft, f->fft_buf);
+    for (int i = 0; i < N; i++) {
+        const double t = f->fft_buf[i + i] * f->window[i];          /* rounded product, then rounded add */
+        f->x_buf[i] = f->x_buf[i] + t;
+    }
+    for (int i = 0; i < F; i++) x[i] = f->magic * f->x_buf[i];
+    for (int i = 0; i < N - F; i++) f->x_buf[i] = f->x_buf[i + F];
+    for (int i = 0; i < F; i++) f->x_buf[i + N - F] = 0;
+}
+
+/* ---- Part 2: batch extension ---- */
+
+typedef struct {
+    int tag, channels, frame_len, fft_len, bins;
+    float magic;
+    float *d_w, *d_cs;
+    float *d_hist[2], *d_ola[2];        /* analysis history / synthesis overlap-add tail: [channels][fft_len-frame_len] */
+    int cur_hist, cur_ola;
+    llz_stage_t st_x, st_re, st_im;
+    void *stream;
+} asmm_t;
+
+static void asmm_destroy(asmm_t *f)
+{
+    if (!f) return;
+    llzs_free(f->d_w); llzs_free(f->d_cs);
+    llzs_free(f->d_hist[0]); llzs_free(f->d_hist[1]); llzs_free(f->d_ola[0]); llzs_free(f->d_ola[1]);
+    llz_stage_release(&f->st_x); llz_stage_release(&f->st_re); llz_stage_release(&f->st_im);
+    f->tag = 0;
+    free(f);
+}
+
+unsigned long llz_stft_mc_init(int channels, int overlap_hint, int frame_len, win_t win_type)
+{
+    int N;
+    double magic;
+    if (channels < 1 || !asm_shape(overlap_hint, frame_len, &N, &magic) || N < 8 || N > 2048) {
+        llzs_set_error("llz_stft_mc_init: channels %d overlap_hint %d frame_len %d (fft_len a power of two in 8..2048)",
+                       channels, overlap_hint, frame_len);
+        return LLZ_BAD_HANDLE;
+    }
+    asmm_t *f = (asmm_t *)calloc(1, sizeof(*f));
+    double *w = (double *)malloc(sizeof(double) * (size_t)N);
+    float *tab = (float *)malloc(sizeof(float) * 3 * (size_t)N);
+    int rc = (f && w && tab) ? LLZ_OK : LLZ_ERR_NOMEM;
+    if (rc == LLZ_OK && !asm_window(w, N, win_type)) {
+        llzs_set_error("llz_stft_mc_init: unknown window %d", (int)win_type);
+        rc = LLZ_ERR_ARG;
+    }
+    if (rc == LLZ_OK) {
+        f->tag = LLZ_TAG_ASMM; f->channels = channels; f->frame_len = frame_len; f->fft_len = N; f->bins = N / 2 + 1;
+        f->magic = (float)magic;
+        for (int i = 0; i < N; i++) {
+            const double ang = (double)(2 * M_PI * i) / N;          /* table of llz_fft_init, llz_fft.c:222-229 */
+            tab[i] = (float)w[i];
+            tab[N + i] = (float)cos(ang);
+            tab[2 * N + i] = (float)sin(ang);
+        }
+        const size_t keep = sizeof(float) * (size_t)channels * (size_t)(N - frame_len);
+        f->d_w = (float *)llzs_malloc(sizeof(float) * (size_t)N);
+        f->d_cs = (float *)llzs_malloc(sizeof(float) * 2 * (size_t)N);
+        for (int k = 0; k < 2; k++) {
+            f->d_hist[k] = (float *)llzs_malloc(keep);
+            f->d_ola[k] = (float *)llzs_malloc(keep);
+        }
+        if (!f->d_w || !f->d_cs || !f->d_hist[0] || !f->d_hist[1] || !f->d_ola[0] || !f->d_ola[1]) rc = LLZ_ERR_NOMEM;
+        if (rc == LLZ_OK) rc = llzs_h2d(f->d_w, tab, sizeof(float) * (size_t)N, NULL);
+        if (rc == LLZ_OK) rc = llzs_h2d(f->d_cs, tab + N, sizeof(float) * 2 * (size_t)N, NULL);
+        for (int k = 0; k < 2 && rc == LLZ_OK; k++) {
+            rc = llzs_memset(f->d_hist[k], 0, keep, NULL);
+            if (rc == LLZ_OK) rc = llzs_memset(f->d_ola[k], 0, keep, NULL);
+        }
+        if (rc == LLZ_OK) rc = llzs_sync(NULL);
+    }
+    free(w); free(tab);
+    if (rc != LLZ_OK) {
+        if (f && f->tag) asmm_destroy(f); else free(f);
+        return LLZ_BAD_HANDLE;
+    }
+    return (unsigned long)f;
+}
+
+void llz_stft_mc_uninit(unsigned long handle)
+{
+    if (LLZ_HANDLE_OK(handle, asmm_t, LLZ_TAG_ASMM)) {
+        llzs_sync(((asmm_t *)handle)->stream);
+        asmm_destroy((asmm_t *)handle);
+    }
+}
+
+int llz_stft_mc_bins(unsigned long handle)
+{
+    return LLZ_HANDLE_OK(handle, asmm_t, LLZ_TAG_ASMM) ? ((asmm_t *)handle)->bins : LLZ_ERR_ARG;
+}
+
+int llz_stft_mc_set_stream(unsigned long handle, void *stream)
+{
+    if (!LLZ_HANDLE_OK(handle, asmm_t, LLZ_TAG_ASMM)) return LLZ_ERR_ARG;
+    ((asmm_t *)handle)->stream = stream;
+    return LLZ_OK;
+}
+
+/* device views of the three caller buffers: x [C][frames*F], re/im [C][frames][bins]; `in` marks which side is input */
+static int asmm_stage(asmm_t *f, const float *x, const float *re, const float *im, int frames, int x_is_input,
+                      float **dx, float **dre, float **dim)
+{
+    const size_t xb = sizeof(float) * (size_t)f->channels * frames * f->frame_len;
+    const size_t sb = sizeof(float) * (size_t)f->channels * frames * f->bins;
+    int rc = LLZ_OK;
+    *dx = (float *)x; *dre = (float *)re; *dim = (float *)im;
+    if (!llzs_is_device_ptr(x)) {
+        *dx = (float *)llz_stage_reserve(&f->st_x, xb);
+        if (!*dx) return LLZ_ERR_NOMEM;
+        if (x_is_input) rc = llzs_h2d(*dx, x, xb, f->stream);
+    }
+    if (rc == LLZ_OK && !llzs_is_device_ptr(re)) {
+        *dre = (float *)llz_stage_reserve(&f->st_re, sb);
+        if (!*dre) return LLZ_ERR_NOMEM;
+        if (!x_is_input) rc = llzs_h2d(*dre, re, sb, f->stream);
+    }
+    if (rc == LLZ_OK && !llzs_is_device_ptr(im)) {
+        *dim = (float *)llz_stage_reserve(&f->st_im, sb);
+        if (!*dim) return LLZ_ERR_NOMEM;
+        if (!x_is_input) rc = llzs_h2d(*dim, im, sb, f->stream);
+    }
+    return rc;
+}
+
+int llz_stft_mc_analysis(unsigned long handle, const float *x, float *re, float *im, int frames)
+{
+    if (!LLZ_HANDLE_OK(handle, asmm_t, LLZ_TAG_ASMM) || !x || !re || !im || frames < 1) {
+        llzs_set_error("llz_stft_mc_analysis: bad handle or arguments");
+        return LLZ_ERR_ARG;
+    }
+    asmm_t *f = (asmm_t *)handle;
+    const long n = (long)frames * f->frame_len;
+    float *dx, *dre, *dim;
+    int rc = asmm_stage(f, x, re, im, frames, 1, &dx, &dre, &dim);
+    if (rc == LLZ_OK)
+        rc = llzs_stft_analysis_f32(dx, f->d_hist[f->cur_hist], dre, dim, f->d_w, f->d_cs, f->channels, frames,
+                                    f->frame_len, f->fft_len, n, f->stream);
+    /* history for the next call: the last fft_len - frame_len samples of concat(history, x) */
+    if (rc == LLZ_OK)
+        rc = llzs_fir_tail_f32(dx, f->d_hist[f->cur_hist], f->d_hist[f->cur_hist ^ 1], f->channels, (int)n, n,
+                               f->fft_len - f->frame_len + 1, f->stream);
+    if (rc == LLZ_OK) f->cur_hist ^= 1;
+    const size_t sb = sizeof(float) * (size_t)f->channels * frames * f->bins;
+    if (rc == LLZ_OK && dre != re) rc = llzs_d2h(re, dre, sb, f->stream);
+    if (rc == LLZ_OK && dim != im) rc = llzs_d2h(im, dim, sb, f->stream);
+    return rc == LLZ_OK ? frames : rc;
+}
+
+int llz_stft_mc_synthesis(unsigned long handle, const float *re, const float *im, float *x, int frames)
+{
+    if (!LLZ_HANDLE_OK(handle, asmm_t, LLZ_TAG_ASMM) || !x || !re || !im || frames < 1) {
+        llzs_set_error("llz_stft_mc_synthesis: bad handle or arguments");
+        return LLZ_ERR_ARG;
+    }
+    asmm_t *f = (asmm_t *)handle;
+    const long n = (long)frames * f->frame_len;
+    float *dx, *dre, *dim;
+    int rc = asmm_stage(f, x, re, im, frames, 0, &dx, &dre, &dim);
+    if (rc == LLZ_OK)
+        rc = llzs_stft_synthesis_f32(dre, dim, dx, f->d_ola[f->cur_ola], f->d_ola[f->cur_ola ^ 1], f->d_w, f->d_cs,
+                                     f->channels, frames, f->frame_len, f->fft_len, n, f->magic, f->stream);
+    if (rc == LLZ_OK) f->cur_ola ^= 1;
+    if (rc == LLZ_OK && dx != x) rc = llzs_d2h(x, dx, sizeof(float) * (size_t)f->channels * n, f->stream);
+    return rc == LLZ_OK ? frames : rc;
+}

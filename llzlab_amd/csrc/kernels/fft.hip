@@ -279,6 +279,151 @@ k_acf_fused_f32(const float *__restrict__ x, float *__restrict__ r, int frames, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Windowed-FFT analysis / synthesis frames (reference libllzfilter/llz_asmodel.c:180-310), many
+// channels and frames per launch.  size = R * frame_len with R = 4 (3/4 overlap) or 2 (1/2 overlap).
+
+// analysis: frame f of channel c is samples [(f+1)F - size, (f+1)F) of concat(hist, x) times the window; bins 0..size/2
+// of its transform go to re/im[(c*frames + f)*bins + b] (llz_asmodel.c:188-204).  tpw frames share a workgroup.
+__global__ void __launch_bounds__(FFT_THREADS)
+k_stft_analysis_f32(const float *__restrict__ x, const float *__restrict__ hist, float *__restrict__ re,
+                    float *__restrict__ im, const float *__restrict__ w, int frames, int F, int size, int log2n,
+                    const float *__restrict__ cs, int tpw, unsigned groups, long x_pitch, long total_tr)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cpx<float> *s = reinterpret_cast<cpx<float> *>(smem_raw);
+    const int tid = threadIdx.x;
+    const long tr0 = (long)blockIdx.x * tpw;
+    const int ntr = (int)min((long)tpw, total_tr - tr0);
+    const int tstride = fft_phys(size) + 1;
+    const int total = ntr << log2n;
+    const int keep = size - F;                                         // history samples in front of a call
+    for (int e = tid; e < total; e += FFT_THREADS) {
+        const int tr = e >> log2n, i = e & (size - 1);
+        const long g = tr0 + tr;
+        const int c = (int)(g / frames), f = (int)(g - (long)c * frames);
+        const long t = (long)(f + 1) * F - size + i;                   // sample index inside this call
+        const float v = t >= 0 ? x[(size_t)c * x_pitch + t] : hist[(size_t)c * keep + (keep + t)];
+        cpx<float> z;
+        z.re = v * w[i];
+        z.im = 0.f;
+        s[tr * tstride + fft_phys(i)] = z;
+    }
+    __syncthreads();
+    int done = 0;
+#pragma unroll 1
+    for (int pss = 0; pss < 4; pss++) {
+        const int G = (groups >> (4 * pss)) & 15;
+        if (G == 0) break;
+        const int log2step = log2n - done - G;
+        switch (G) {
+        case 1: fft_pass<arith_f32, 1, false>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
+        case 2: fft_pass<arith_f32, 2, false>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
+        case 3: fft_pass<arith_f32, 3, false>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
+        default: fft_pass<arith_f32, 4, false>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
+        }
+        done += G;
+    }
+    const int bins = (size >> 1) + 1;                                  // position j holds bin brev(j)
+    for (int tr = 0; tr < ntr; tr++) {
+        const size_t o = (size_t)(tr0 + tr) * bins;
+        for (int b = tid; b < bins; b += FFT_THREADS) {
+            const cpx<float> v = s[tr * tstride + fft_phys((int)(__brev((unsigned)b) >> (32 - log2n)))];
+            re[o + b] = v.re;
+            im[o + b] = v.im;
+        }
+    }
+}
+
+// synthesis: a workgroup owns output blocks [b0, b1) of one channel.  Block t (frame_len samples) is the sum of the
+// windowed inverse transforms of frames t-R+1 .. t (llz_asmodel.c:279-304), so the workgroup walks frames
+// max(0, b0-R+1) .. b1-1 in groups of tpw, keeps the running overlap-add tail (size - F samples) in LDS and drops the
+// blocks in front of b0 (their sums are incomplete; the first run of a channel starts from the handle's tail instead).
+// Accumulation order per sample is the reference's: oldest frame first.
+__global__ void __launch_bounds__(FFT_THREADS)
+k_stft_synthesis_f32(const float *__restrict__ re, const float *__restrict__ im, float *__restrict__ x,
+                     const float *__restrict__ ola_old, float *__restrict__ ola_new, const float *__restrict__ w,
+                     int frames, int F, int size, int log2n, const float *__restrict__ cs, int tpw, unsigned groups,
+                     long x_pitch, int run_len, int runs, float magic)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tstride = fft_phys(size) + 1;
+    cpx<float> *s = reinterpret_cast<cpx<float> *>(smem_raw);
+    float *carry = reinterpret_cast<float *>(s + (size_t)tpw * tstride);   // size - F floats
+    const int tid = threadIdx.x;
+    const int c = blockIdx.x / runs, run = blockIdx.x - c * runs;
+    const int b0 = run * run_len, b1 = min(frames, b0 + run_len);
+    const int R = size / F, keep = size - F, bins = (size >> 1) + 1;
+    const int fs = max(0, b0 - (R - 1));
+    for (int q = tid; q < keep; q += FFT_THREADS) carry[q] = fs == 0 ? ola_old[(size_t)c * keep + q] : 0.f;
+    const float inv = 1.0f / (float)size;                                  // llz_ifft divides by N (llz_fft.c:187-195)
+    for (int g0 = fs; g0 < b1; g0 += tpw) {
+        const int ng = min(tpw, b1 - g0);
+        __syncthreads();                                                   // carry written, s free
+        // spectra into bit-reversed positions: bins 0..size/2 as given, the upper half by Hermitian symmetry
+        for (int tr = 0; tr < ng; tr++) {
+            const size_t o = ((size_t)c * frames + g0 + tr) * bins;
+            for (int b = tid; b < bins; b += FFT_THREADS) {
+                cpx<float> v;
+                v.re = re[o + b] * inv;
+                v.im = im[o + b] * inv;
+                s[tr * tstride + fft_phys((int)(__brev((unsigned)b) >> (32 - log2n)))] = v;
+                if (b > 0 && b < (size >> 1)) {
+                    v.im = -v.im;
+                    s[tr * tstride + fft_phys((int)(__brev((unsigned)(size - b)) >> (32 - log2n)))] = v;
+                }
+            }
+        }
+        __syncthreads();
+        int done = 0;
+#pragma unroll 1
+        for (int pss = 0; pss < 4; pss++) {
+            const int G = (groups >> (4 * pss)) & 15;
+            if (G == 0) break;
+            switch (G) {
+            case 1: fft_pass<arith_f32, 1, true>(s, ng, size, log2n, done, tstride, cs, tid); break;
+            case 2: fft_pass<arith_f32, 2, true>(s, ng, size, log2n, done, tstride, cs, tid); break;
+            case 3: fft_pass<arith_f32, 3, true>(s, ng, size, log2n, done, tstride, cs, tid); break;
+            default: fft_pass<arith_f32, 4, true>(s, ng, size, log2n, done, tstride, cs, tid); break;
+            }
+            done += G;
+        }
+        // overlap-add over the group's span: position p counts from the group's first block
+        const int span = (ng - 1) * F + size;                              // <= 2048
+        float acc[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const int p = tid + m * FFT_THREADS;
+            float a = 0.f;
+            if (p < span) {
+                a = p < keep ? carry[p] : 0.f;
+                const int k_hi = min(ng - 1, p / F);                       // frames k with 0 <= p - kF < size
+                const int k_lo = p < size ? 0 : (p - size) / F + 1;
+                for (int k = k_lo; k <= k_hi; k++) {
+                    const int i = p - k * F;
+                    a += s[k * tstride + fft_phys(i)].re * w[i];
+                }
+            }
+            acc[m] = a;
+        }
+        __syncthreads();                                                   // every read of carry and s is done
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const int p = tid + m * FFT_THREADS;
+            if (p < span) {
+                if (p < ng * F) {
+                    if (g0 + p / F >= b0) x[(size_t)c * x_pitch + (size_t)g0 * F + p] = magic * acc[m];
+                } else {
+                    carry[p - ng * F] = acc[m];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (b1 == frames)
+        for (int q = tid; q < keep; q += FFT_THREADS) ola_new[(size_t)c * keep + q] = carry[q];
+}
+
 template <typename A>
 int launch_fft(typename A::data_t *data, int count, int size, const typename A::tw_t *cs, int inverse,
                void *stream, const char *name)
@@ -364,5 +509,82 @@ extern "C" int llzs_acf_fused_f32(const float *x, float *r, int frames, int n, i
     hipLaunchKernelGGL(k_acf_fused_f32, dim3(blocks), dim3(FFT_THREADS), lds, as_stream(stream), x, r, frames, n, p,
                        size, log2n, cs, tpw, groups);
     LLZ_LAUNCH_CHECK("k_acf_fused_f32");
+    return LLZ_OK;
+}
+
+static unsigned stft_groups(int log2n)
+{
+    const int passes = (log2n + 3) / 4;
+    unsigned groups = 0;
+    for (int q = 0, left = log2n; q < passes; q++) {
+        const int G = (left + (passes - q) - 1) / (passes - q);
+        groups |= (unsigned)G << (4 * q);
+        left -= G;
+    }
+    return groups;
+}
+
+static int stft_check(int channels, int frames, int F, int size, int *log2n, const char *who)
+{
+    *log2n = 0;
+    while ((1 << *log2n) < size) (*log2n)++;
+    if (channels < 1 || frames < 1 || F < 1 || size < 8 || size > 2048 || (1 << *log2n) != size ||
+        (size != 2 * F && size != 4 * F)) {
+        llzs_set_error("%s: bad shape (channels=%d frames=%d frame_len=%d fft_len=%d; fft_len a power of two in 8..2048)",
+                       who, channels, frames, F, size);
+        return LLZ_ERR_ARG;
+    }
+    return LLZ_OK;
+}
+
+extern "C" int llzs_stft_analysis_f32(const float *x, const float *hist, float *re, float *im, const float *w,
+                                      const float *cs, int channels, int frames, int F, int size, long x_pitch,
+                                      void *stream)
+{
+    int log2n;
+    if (!x || !hist || !re || !im || !w || !cs || x_pitch < (long)frames * F) {
+        llzs_set_error("stft_analysis_f32: bad arguments");
+        return LLZ_ERR_ARG;
+    }
+    const int rc = stft_check(channels, frames, F, size, &log2n, "stft_analysis_f32");
+    if (rc != LLZ_OK) return rc;
+    const long total_tr = (long)channels * frames;
+    int tpw = 2048 / size;
+    if (tpw > total_tr) tpw = (int)total_tr;
+    const int tstride = size + (size >> 5) + 1;
+    const size_t lds = (size_t)tpw * tstride * 2 * sizeof(float);
+    const long blocks = (total_tr + tpw - 1) / tpw;
+    hipLaunchKernelGGL(k_stft_analysis_f32, dim3((unsigned)blocks), dim3(FFT_THREADS), lds, as_stream(stream), x, hist,
+                       re, im, w, frames, F, size, log2n, cs, tpw, stft_groups(log2n), x_pitch, total_tr);
+    LLZ_LAUNCH_CHECK("k_stft_analysis_f32");
+    return LLZ_OK;
+}
+
+extern "C" int llzs_stft_synthesis_f32(const float *re, const float *im, float *x, const float *ola_old, float *ola_new,
+                                       const float *w, const float *cs, int channels, int frames, int F, int size,
+                                       long x_pitch, float magic, void *stream)
+{
+    int log2n;
+    if (!re || !im || !x || !ola_old || !ola_new || ola_old == ola_new || !w || !cs || x_pitch < (long)frames * F) {
+        llzs_set_error("stft_synthesis_f32: bad arguments");
+        return LLZ_ERR_ARG;
+    }
+    const int rc = stft_check(channels, frames, F, size, &log2n, "stft_synthesis_f32");
+    if (rc != LLZ_OK) return rc;
+    const int R = size / F;
+    int tpw = 2048 / size;
+    if (tpw > frames) tpw = frames;
+    // blocks per workgroup: enough workgroups to fill the chip, long enough that the R-1 warm-up frames stay cheap
+    long want = ((long)frames * channels + 2047) / 2048;
+    int run_len = (int)(want < 8 * R ? 8 * R : want);
+    if (run_len < tpw) run_len = tpw;
+    if (run_len > frames) run_len = frames;
+    const int runs = (frames + run_len - 1) / run_len;
+    const int tstride = size + (size >> 5) + 1;
+    const size_t lds = (size_t)tpw * tstride * 2 * sizeof(float) + (size_t)(size - F) * sizeof(float);
+    hipLaunchKernelGGL(k_stft_synthesis_f32, dim3((unsigned)((long)channels * runs)), dim3(FFT_THREADS), lds,
+                       as_stream(stream), re, im, x, ola_old, ola_new, w, frames, F, size, log2n, cs, tpw,
+                       stft_groups(log2n), x_pitch, run_len, runs, magic);
+    LLZ_LAUNCH_CHECK("k_stft_synthesis_f32");
     return LLZ_OK;
 }

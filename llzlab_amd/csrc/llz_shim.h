@@ -113,6 +113,15 @@ int llzs_acf_extract(const float *z, float *r, int frames, int p, int F, void *s
 /* the same five steps fused in LDS (fft.hip): one read of the frames, p+1 floats written per frame */
 int llzs_acf_fused_f32(const float *x, float *r, int frames, int n, int p, int size, const float *cs, void *stream);
 
+/* windowed-FFT frames (llz_asmodel.c:180-310), float32 batch: x planar [C][frames*F] (row pitch x_pitch), spectra
+ * [C][frames][size/2+1]; hist / ola: [C][size-F] state carried between calls (ola_old != ola_new); w: size floats;
+ * cs: cos then sin of 2*pi*i/size */
+int llzs_stft_analysis_f32(const float *x, const float *hist, float *re, float *im, const float *w, const float *cs,
+                           int channels, int frames, int F, int size, long x_pitch, void *stream);
+int llzs_stft_synthesis_f32(const float *re, const float *im, float *x, const float *ola_old, float *ola_new,
+                            const float *w, const float *cs, int channels, int frames, int F, int size, long x_pitch,
+                            float magic, void *stream);
+
 /* ---- PCM ingest / egress ---- */
 int llzs_pcm_deinterleave_i16_f32(const short *in, float *out, int channels, long n, float scale, void *stream);
 int llzs_pcm_interleave_f32_i16(const float *in, short *out, int channels, long n, float scale, void *stream);

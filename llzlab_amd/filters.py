@@ -443,6 +443,76 @@ class AutocorrFastMC:
     __del__ = close
 
 
+# ------------------------------------------------------------------------------------------ windowed-FFT frames
+class _FftFrames:
+    """llz_analysis_fft_* / llz_synthesis_fft_* (llz_asmodel.h:36-42): one frame per call, host float64, exact."""
+    _init = _uninit = None
+
+    def __init__(self, overlap_hint, frame_len, win=HAMMING):
+        self._L = capi.lib()
+        self.handle = check_handle(getattr(self._L, self._init)(overlap_hint, frame_len, win), self._init)
+        self.frame_len = frame_len
+        self.fft_len = frame_len << (2 if overlap_hint == capi.OVERLAP_HIGH else 1)
+        self.bins = self.fft_len // 2 + 1
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            getattr(self._L, self._uninit)(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
+class AnalysisFft(_FftFrames):
+    _init, _uninit = "llz_analysis_fft_init", "llz_analysis_fft_uninit"
+
+    def frame(self, x):
+        x = _f64(x)
+        re, im = np.zeros(self.bins), np.zeros(self.bins)
+        self._L.llz_analysis_fft(self.handle, x.ctypes.data_as(_dp), re.ctypes.data_as(_dp), im.ctypes.data_as(_dp))
+        return re, im
+
+
+class SynthesisFft(_FftFrames):
+    _init, _uninit = "llz_synthesis_fft_init", "llz_synthesis_fft_uninit"
+
+    def frame(self, re, im):
+        re, im = _f64(re), _f64(im)
+        x = np.zeros(self.frame_len)
+        self._L.llz_synthesis_fft(self.handle, re.ctypes.data_as(_dp), im.ctypes.data_as(_dp), x.ctypes.data_as(_dp))
+        return x
+
+
+class StftMC:
+    """llz_stft_mc_*: many channels and frames per call, float32; x [channels, frames*frame_len],
+    re/im [channels, frames, bins]; the handle carries both streams' state between calls."""
+
+    def __init__(self, channels, overlap_hint, frame_len, win=HAMMING, stream=None):
+        self._L = capi.lib()
+        self.handle = check_handle(self._L.llz_stft_mc_init(channels, overlap_hint, frame_len, win), "llz_stft_mc_init")
+        self.channels, self.frame_len = channels, frame_len
+        self.bins = self._L.llz_stft_mc_bins(self.handle)
+        if stream is not None:
+            check(self._L.llz_stft_mc_set_stream(self.handle, _stream_ptr(stream)), "set_stream")
+
+    def analysis(self, x, re, im):
+        frames = x.shape[1] // self.frame_len
+        check(self._L.llz_stft_mc_analysis(self.handle, _ptr(x), _ptr(re), _ptr(im), frames), "llz_stft_mc_analysis")
+        return re, im
+
+    def synthesis(self, re, im, x):
+        frames = re.shape[1]
+        check(self._L.llz_stft_mc_synthesis(self.handle, _ptr(re), _ptr(im), _ptr(x), frames), "llz_stft_mc_synthesis")
+        return x
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            self._L.llz_stft_mc_uninit(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
 # ------------------------------------------------------------------------------------------ PCM ingest / egress
 def pcm_deinterleave(ileaved, planar, scale=1.0 / 32768.0, stream=None):
     """ileaved: [n, channels] int16 -> planar: [channels, n] float32."""

@@ -186,6 +186,18 @@ def main():
         d[f"cof_{n}"] = np.array([r.corr_cof(x, y)])
     np.savez_compressed(os.path.join(OUT, "corr.npz"), **d)
 
+    # ---- windowed-FFT analysis / synthesis frames -----------------------------
+    d = {}
+    g = np.random.default_rng(6000)
+    for hint, frame_len, win, frames in ((0, 8, po.HAMMING, 9), (0, 64, po.BLACKMAN, 7), (0, 256, po.KAISER, 6),
+                                         (1, 8, po.KAISER, 9), (1, 128, po.HAMMING, 5), (1, 512, po.BLACKMAN, 4)):
+        x = g.uniform(-1, 1, frame_len * frames).astype(np.float32).astype(np.float64)
+        re, im = r.stft_analysis(hint, frame_len, win, x)
+        key = f"{hint}_{frame_len}_{win}"
+        d["x_" + key], d["re_" + key], d["im_" + key] = x, re, im
+        d["syn_" + key] = r.stft_synthesis(hint, frame_len, win, re, im)
+    np.savez_compressed(os.path.join(OUT, "stft.npz"), **d)
+
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden fixtures written to", OUT, "total bytes", tot)
 

@@ -734,6 +734,84 @@ void orc_acf_free(void *p)
     orc_fft_free(h->fft); free(h->b1); free(h->b2); free(h);
 }
 
+/* ------------------------------------------------------------------ analysis / synthesis by windowed FFT frames
+ * reference libllzfilter/llz_asmodel.c:109-310.  One struct serves both directions, as in the
+ * reference (llz_analysis_fft_init and llz_synthesis_fft_init build the same state). */
+typedef struct {
+    int frame_len, fft_len;
+    double *x_buf, *fft_buf, *window;
+    void *fft;
+    double magic;
+} orc_stft_t;
+
+void *orc_stft_new(int overlap_hint, int frame_len, int win)
+{
+    orc_stft_t *f = (orc_stft_t *)calloc(1, sizeof(*f));
+    f->frame_len = frame_len;
+    /* llz_asmodel.c:114-123: 3/4 overlap -> 4 frames per transform and the empirical 0.812; 1/2 overlap -> 2 and 1 */
+    if (overlap_hint == 0) { f->fft_len = frame_len << 2; f->magic = 0.812; }
+    else                   { f->fft_len = frame_len << 1; f->magic = 1; }
+    f->x_buf = (double *)calloc((size_t)f->fft_len, sizeof(double));
+    f->fft_buf = (double *)calloc(2 * (size_t)f->fft_len, sizeof(double));
+    f->window = (double *)calloc((size_t)f->fft_len, sizeof(double));
+    f->fft = orc_fft_new(f->fft_len);
+    if (win == ORC_HAMMING) orc_hamming(f->window, f->fft_len);            /* llz_asmodel.c:133-143 */
+    else if (win == ORC_BLACKMAN) orc_blackman(f->window, f->fft_len);
+    else orc_kaiser(f->window, f->fft_len);
+    return f;
+}
+
+int orc_stft_fft_len(void *p) { return ((orc_stft_t *)p)->fft_len; }
+
+void orc_stft_analysis(void *p, const double *x, double *re, double *im)
+{
+    orc_stft_t *f = (orc_stft_t *)p;
+    const int F = f->frame_len, N = f->fft_len;
+    /* llz_asmodel.c:188-204: slide the frame in at the end, window, transform, keep bins 0..N/2 */
+    for (int i = 0; i < N - F; i++) f->x_buf[i] = f->x_buf[i + F];
+    for (int i = 0; i < F; i++) f->x_buf[i + N - F] = x[i];
+    for (int i = 0; i < N; i++) {
+        f->fft_buf[2 * i] = f->x_buf[i] * f->window[i];
+        f->fft_buf[2 * i + 1] = 0;
+    }
+    orc_fft_fwd(f->fft, f->fft_buf);
+    for (int i = 0; i < (N >> 1) + 1; i++) {
+        re[i] = f->fft_buf[2 * i];
+        im[i] = f->fft_buf[2 * i + 1];
+    }
+}
+
+void orc_stft_synthesis(void *p, const double *re, const double *im, double *x)
+{
+    orc_stft_t *f = (orc_stft_t *)p;
+    const int F = f->frame_len, N = f->fft_len;
+    /* llz_asmodel.c:279-288: bins 0..N/2 as given, the upper half by Hermitian symmetry */
+    for (int i = 0; i < (N >> 1) + 1; i++) {
+        f->fft_buf[2 * i] = re[i];
+        f->fft_buf[2 * i + 1] = im[i];
+    }
+    for (int i = 0, j = (N >> 1) - 1; i < (N >> 1) - 1; i++, j--) {
+        f->fft_buf[N + 2 + 2 * i] = re[j];
+        f->fft_buf[N + 2 + 2 * i + 1] = -im[j];
+    }
+    orc_fft_inv(f->fft, f->fft_buf);
+    /* llz_asmodel.c:292-304: windowed overlap-add, scaled output of the oldest frame_len samples, slide */
+    for (int i = 0; i < N; i++) {
+        const double t = f->fft_buf[2 * i] * f->window[i];
+        f->x_buf[i] = f->x_buf[i] + t;
+    }
+    for (int i = 0; i < F; i++) x[i] = f->magic * f->x_buf[i];
+    for (int i = 0; i < N - F; i++) f->x_buf[i] = f->x_buf[i + F];
+    for (int i = 0; i < F; i++) f->x_buf[i + N - F] = 0;
+}
+
+void orc_stft_free(void *p)
+{
+    orc_stft_t *f = (orc_stft_t *)p;
+    if (!f) return;
+    orc_fft_free(f->fft); free(f->x_buf); free(f->fft_buf); free(f->window); free(f);
+}
+
 /* ------------------------------------------------------------------ batch drivers */
 
 void orc_fir_batch_f32(const float *in, double *out, int channels, long n, const double *h, int flt_len)

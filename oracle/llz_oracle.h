@@ -88,6 +88,14 @@ int    orc_acf_fft_len(void *h);
 void   orc_acf_run(void *h, const double *x, int n, int p, double *r);
 void   orc_acf_free(void *h);
 
+/* windowed-FFT analysis / synthesis frames, reference libllzfilter/llz_asmodel.c:109-310.
+ * overlap_hint 0 = 3/4 overlap (fft_len = 4 frame_len), 1 = 1/2 overlap (fft_len = 2 frame_len) */
+void  *orc_stft_new(int overlap_hint, int frame_len, int win);
+int    orc_stft_fft_len(void *h);
+void   orc_stft_analysis(void *h, const double *x, double *re, double *im);      /* re, im: fft_len/2 + 1 */
+void   orc_stft_synthesis(void *h, const double *re, const double *im, double *x);
+void   orc_stft_free(void *h);
+
 /* ---- batch drivers over the restatement (what the multi-channel GPU path is compared with) ---- */
 
 /* planar [C][n] float input -> planar double output; every channel runs its own orc_fir state machine

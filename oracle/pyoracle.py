@@ -118,6 +118,12 @@ class Oracle:
         L.orc_acf_fft_len.argtypes = [vp]
         L.orc_acf_run.argtypes = [vp, _dp, C.c_int, C.c_int, _dp]
         L.orc_acf_free.argtypes = [vp]
+        L.orc_stft_new.restype = vp
+        L.orc_stft_new.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.orc_stft_fft_len.argtypes = [vp]
+        L.orc_stft_analysis.argtypes = [vp, _dp, _dp, _dp]
+        L.orc_stft_synthesis.argtypes = [vp, _dp, _dp, _dp]
+        L.orc_stft_free.argtypes = [vp]
         L.orc_fir_batch_f32.argtypes = [C.c_void_p, _dp, C.c_int, C.c_long, _dp, C.c_int]
         L.orc_iir_cascade_batch_f32.argtypes = [C.c_void_p, _dp, C.c_int, C.c_long, _dp, C.c_int]
         L.orc_rs_batch_f32.restype = C.c_long
@@ -299,6 +305,32 @@ class Oracle:
         self.lib.orc_acf_free(h)
         return r
 
+    def stft_analysis(self, overlap_hint, frame_len, win, x):
+        """stream x (a whole number of frames) through one analysis handle -> re, im of shape [frames, fft_len/2+1]"""
+        x = _f64(x)
+        h = self.lib.orc_stft_new(overlap_hint, frame_len, win)
+        bins = self.lib.orc_stft_fft_len(h) // 2 + 1
+        frames = len(x) // frame_len
+        re, im = np.zeros((frames, bins)), np.zeros((frames, bins))
+        for f in range(frames):
+            xi = np.ascontiguousarray(x[f * frame_len:(f + 1) * frame_len])
+            r, i = np.zeros(bins), np.zeros(bins)
+            self.lib.orc_stft_analysis(h, _ptr(xi), _ptr(r), _ptr(i))
+            re[f], im[f] = r, i
+        self.lib.orc_stft_free(h)
+        return re, im
+
+    def stft_synthesis(self, overlap_hint, frame_len, win, re, im):
+        re, im = np.ascontiguousarray(re, dtype=np.float64), np.ascontiguousarray(im, dtype=np.float64)
+        h = self.lib.orc_stft_new(overlap_hint, frame_len, win)
+        x = np.zeros(re.shape[0] * frame_len)
+        for f in range(re.shape[0]):
+            r, i, xo = np.ascontiguousarray(re[f]), np.ascontiguousarray(im[f]), np.zeros(frame_len)
+            self.lib.orc_stft_synthesis(h, _ptr(r), _ptr(i), _ptr(xo))
+            x[f * frame_len:(f + 1) * frame_len] = xo
+        self.lib.orc_stft_free(h)
+        return x
+
     # ---- batch drivers (oracle only) -----------------------------------------------------------
     def fir_batch_f32(self, x, h):
         x = np.ascontiguousarray(x, dtype=np.float32)
@@ -413,6 +445,13 @@ class Ref:
         L.llz_autocorr_fast_init.argtypes = [C.c_int]
         L.llz_autocorr_fast_uninit.argtypes = [ul]
         L.llz_autocorr_fast.argtypes = [ul, _dp, C.c_int, C.c_int, _dp]
+        for n in ("llz_analysis_fft_init", "llz_synthesis_fft_init"):
+            getattr(L, n).restype = ul
+            getattr(L, n).argtypes = [C.c_int, C.c_int, C.c_int]
+        L.llz_analysis_fft.argtypes = [ul, _dp, _dp, _dp]
+        L.llz_synthesis_fft.argtypes = [ul, _dp, _dp, _dp]
+        L.llz_analysis_fft_uninit.argtypes = [ul]
+        L.llz_synthesis_fft_uninit.argtypes = [ul]
         self._libc = C.CDLL(None)
         self._libc.free.argtypes = [C.c_void_p]
 
@@ -496,6 +535,31 @@ class Ref:
             self.lib.llz_iir_filter_flush(f, _ptr(tail))
         self.lib.llz_iir_filter_uninit(f)
         return y, tail[:N]
+
+    def stft_analysis(self, overlap_hint, frame_len, win, x):
+        x = _f64(x)
+        h = self.lib.llz_analysis_fft_init(overlap_hint, frame_len, win)
+        bins = (frame_len << (2 if overlap_hint == 0 else 1)) // 2 + 1
+        frames = len(x) // frame_len
+        re, im = np.zeros((frames, bins)), np.zeros((frames, bins))
+        for f in range(frames):
+            xi = np.ascontiguousarray(x[f * frame_len:(f + 1) * frame_len])
+            r, i = np.zeros(bins), np.zeros(bins)
+            self.lib.llz_analysis_fft(h, _ptr(xi), _ptr(r), _ptr(i))
+            re[f], im[f] = r, i
+        self.lib.llz_analysis_fft_uninit(h)
+        return re, im
+
+    def stft_synthesis(self, overlap_hint, frame_len, win, re, im):
+        re, im = np.ascontiguousarray(re, dtype=np.float64), np.ascontiguousarray(im, dtype=np.float64)
+        h = self.lib.llz_synthesis_fft_init(overlap_hint, frame_len, win)
+        x = np.zeros(re.shape[0] * frame_len)
+        for f in range(re.shape[0]):
+            r, i, xo = np.ascontiguousarray(re[f]), np.ascontiguousarray(im[f]), np.zeros(frame_len)
+            self.lib.llz_synthesis_fft(h, _ptr(r), _ptr(i), _ptr(xo))
+            x[f * frame_len:(f + 1) * frame_len] = xo
+        self.lib.llz_synthesis_fft_uninit(h)
+        return x
 
     def _rs_open(self, mode, L, M, gain, win):
         if mode == 0:

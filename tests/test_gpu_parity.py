@@ -527,3 +527,93 @@ def test_pcm_deinterleave_and_back_exact(dev, channels, n):
     filters.pcm_interleave(x, out)                                      # host buffers
     ref = np.trunc(np.clip(x.astype(np.float32) * np.float32(32768.0), -32768, 32767)).astype(np.int16).T
     assert np.array_equal(out, ref)
+
+
+# ------------------------------------------------------------------------------------------------ windowed-FFT frames (8f rank 3)
+STFT_CASES = ((0, 8, po.HAMMING), (0, 64, po.BLACKMAN), (0, 256, po.KAISER), (1, 8, po.KAISER), (1, 128, po.HAMMING),
+              (1, 512, po.BLACKMAN))
+
+
+def test_stft_reference_symbols_exact(dev):
+    """llz_analysis_fft / llz_synthesis_fft through the product library, frame by frame, against the fixtures generated
+    from the compiled reference: bit-identical (framing on the host in the reference's statement order, transforms by the
+    exact-order double kernel)"""
+    d = load("stft.npz")
+    for hint, frame_len, win in STFT_CASES:
+        key = f"{hint}_{frame_len}_{win}"
+        x = d["x_" + key]
+        a = filters.AnalysisFft(hint, frame_len, win)
+        s = filters.SynthesisFft(hint, frame_len, win)
+        for f in range(len(x) // frame_len):
+            re, im = a.frame(x[f * frame_len:(f + 1) * frame_len])
+            assert np.array_equal(re, d["re_" + key][f]) and np.array_equal(im, d["im_" + key][f]), (key, f)
+            xo = s.frame(re, im)
+            assert np.array_equal(xo, d["syn_" + key][f * frame_len:(f + 1) * frame_len]), (key, f)
+        a.close()
+        s.close()
+    with pytest.raises(capi.LlzError):
+        filters.AnalysisFft(0, 48)                                      # fft_len 192 is not a power of two
+    with pytest.raises(capi.LlzError):
+        filters.SynthesisFft(7, 64)
+
+
+@pytest.mark.parametrize("hint,frame_len,win", [(0, 2, po.HAMMING), (0, 64, po.BLACKMAN), (0, 512, po.KAISER),
+                                                (1, 4, po.KAISER), (1, 128, po.HAMMING), (1, 1024, po.BLACKMAN)])
+@pytest.mark.parametrize("channels,frames", [(3, 7), (2, 70), (5, 1)])
+def test_stft_mc_vs_oracle_streaming(dev, oracle, hint, frame_len, win, channels, frames):
+    """batch analysis and synthesis against the oracle run channel by channel, in TWO calls so that the history and the
+    overlap-add tail carried by the handle are exercised; the synthesis input is the oracle's own spectra"""
+    rng = np.random.default_rng(hint * 1000 + frame_len + channels)
+    n = frames * frame_len
+    x = rng.uniform(-1, 1, (channels, 2 * n)).astype(np.float32)
+    ref = [oracle.stft_analysis(hint, frame_len, win, row.astype(np.float64)) for row in x]
+    ref_re = np.stack([r[0] for r in ref])
+    ref_im = np.stack([r[1] for r in ref])
+    ref_x = np.stack([oracle.stft_synthesis(hint, frame_len, win, ref_re[c].astype(np.float32), ref_im[c].astype(np.float32))
+                      for c in range(channels)])
+    f = filters.StftMC(channels, hint, frame_len, win)
+    bins = f.bins
+    assert bins == (frame_len << (2 if hint == 0 else 1)) // 2 + 1
+    got_re, got_im, got_x = [], [], []
+    for half in range(2):
+        xd = torch.from_numpy(np.ascontiguousarray(x[:, half * n:(half + 1) * n])).to(dev)
+        re = torch.empty(channels, frames, bins, dtype=torch.float32, device=dev)
+        im = torch.empty_like(re)
+        f.analysis(xd, re, im)
+        got_re.append(re.cpu().numpy())
+        got_im.append(im.cpu().numpy())
+        sre = torch.from_numpy(np.ascontiguousarray(ref_re[:, half * frames:(half + 1) * frames]).astype(np.float32)).to(dev)
+        sim = torch.from_numpy(np.ascontiguousarray(ref_im[:, half * frames:(half + 1) * frames]).astype(np.float32)).to(dev)
+        xo = torch.empty(channels, n, dtype=torch.float32, device=dev)
+        f.synthesis(sre, sim, xo)
+        got_x.append(xo.cpu().numpy())
+    got_re, got_im = np.concatenate(got_re, axis=1), np.concatenate(got_im, axis=1)
+    got_x = np.concatenate(got_x, axis=1)
+    scale = max(np.sqrt(np.mean(ref_re ** 2 + ref_im ** 2)), 1e-30)
+    err = np.sqrt(np.mean((got_re - ref_re) ** 2 + (got_im - ref_im) ** 2))
+    assert err <= 1e-5 * max(scale, 1.0) and err / scale <= 1e-5, (err, scale)
+    # with one or two frames the overlap-add sum sits on the window's edge (output ~1e-9 of the input): measure the error
+    # against the larger of the output and a -26 dB floor of the unit-scale input, not against a vanishing output
+    err_x = float(np.sqrt(np.mean((got_x - ref_x) ** 2)))
+    assert err_x <= TOL and err_x / max(float(np.sqrt(np.mean(ref_x ** 2))), 0.05) <= TOL, err_x
+    f.close()
+
+
+def test_stft_mc_host_buffers_and_many_runs(dev, oracle):
+    """host numpy buffers, and enough frames that one channel is split over several workgroup runs (warm-up frames and
+    dropped blocks in the synthesis kernel)"""
+    hint, frame_len, win, channels, frames = 0, 16, po.BLACKMAN, 2, 700
+    rng = np.random.default_rng(77)
+    x = rng.uniform(-1, 1, (channels, frames * frame_len)).astype(np.float32)
+    f = filters.StftMC(channels, hint, frame_len, win)
+    re = np.zeros((channels, frames, f.bins), dtype=np.float32)
+    im = np.zeros_like(re)
+    f.analysis(x, re, im)
+    ref = [oracle.stft_analysis(hint, frame_len, win, row.astype(np.float64)) for row in x]
+    assert np.abs(re - np.stack([r[0] for r in ref])).max() <= 2e-5
+    assert np.abs(im - np.stack([r[1] for r in ref])).max() <= 2e-5
+    xo = np.zeros_like(x)
+    f.synthesis(re, im, xo)
+    ref_x = np.stack([oracle.stft_synthesis(hint, frame_len, win, re[c], im[c]) for c in range(channels)])
+    rms_check(xo, ref_x, "stft synthesis, 700 frames")
+    f.close()

@@ -242,3 +242,16 @@ def test_correlation(oracle):
     # the FFT form is the reference's own definition (first n bins, doubled), NOT the direct autocorrelation
     x = d["x_64"]
     assert not np.allclose(oracle.autocorr_fast(x, 10), oracle.autocorr(x, 10), rtol=1e-3)
+
+
+def test_stft_frames(oracle):
+    """llz_analysis_fft / llz_synthesis_fft (llz_asmodel.c:180-310): spectra and overlap-add output, streamed frame by
+    frame, identical to the compiled reference"""
+    d = load("stft.npz")
+    for hint, frame_len, win in ((0, 8, po.HAMMING), (0, 64, po.BLACKMAN), (0, 256, po.KAISER), (1, 8, po.KAISER),
+                                 (1, 128, po.HAMMING), (1, 512, po.BLACKMAN)):
+        key = f"{hint}_{frame_len}_{win}"
+        re, im = oracle.stft_analysis(hint, frame_len, win, d["x_" + key])
+        assert same(re, d["re_" + key]) and same(im, d["im_" + key])
+        assert re.shape[1] == (frame_len << (2 if hint == 0 else 1)) // 2 + 1
+        assert same(oracle.stft_synthesis(hint, frame_len, win, re, im), d["syn_" + key])

@@ -31,7 +31,7 @@ def timeit(fn, steps):
     return ms
 
 
-which = sys.argv[1:] or ["iir", "resample", "fir63", "td257", "fft", "corr", "pcm"]
+which = sys.argv[1:] or ["iir", "resample", "fir63", "td257", "fft", "corr", "pcm", "stft"]
 if "iir" in which:
     for ch in (1024, 128):
         n = 1 << 20
@@ -147,3 +147,19 @@ if "pcm" in which:
         gb = 6.0 * ch * n / ms / 1e6
         print(f"pcm interleave   {ch}ch x {n}: {ms:.3f} ms  {gb:.0f} GB/s ({gb / 80:.1f} %)")
         del il, pl
+
+if "stft" in which:
+    for hint, F, ch, frames in ((0, 256, 1024, 256), (1, 512, 1024, 128), (0, 64, 4096, 256), (0, 256, 8, 32768)):
+        n = F * frames
+        x = torch.rand(ch, n, dtype=torch.float32, device=dev) * 2 - 1
+        q = filters.StftMC(ch, hint, F, filters.BLACKMAN, stream=stream)
+        re = torch.empty(ch, frames, q.bins, dtype=torch.float32, device=dev)
+        im = torch.empty_like(re)
+        y = torch.empty_like(x)
+        ms_a = timeit(lambda: q.analysis(x, re, im), 5)
+        ms_s = timeit(lambda: q.synthesis(re, im, y), 5)
+        spec = 8 * ch * frames * q.bins
+        print(f"stft {'3/4' if hint == 0 else '1/2'} overlap F={F} {ch}ch x {frames} frames: analysis {ms_a:.3f} ms "
+              f"{(4 * ch * n + spec) / ms_a / 1e6:.0f} GB/s, synthesis {ms_s:.3f} ms {(4 * ch * n + spec) / ms_s / 1e6:.0f} GB/s")
+        q.close()
+        del x, y, re, im
