@@ -15,6 +15,8 @@
 // stages run as 1-3 passes of up to four stages fused in registers (16 elements per lane), a barrier between passes. Twiddle tables come from the host
 // (never recomputed on the device: SURVEY.md H4/H5).
 #include "common.hpp"
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -93,6 +95,25 @@ struct arith_q15 {
 // late passes and the bit-reversed gather spread over the banks; transforms of a workgroup follow each other.
 __device__ __forceinline__ int fft_phys(int i) { return i + (i >> 5); }
 
+// The twiddle table (cos, sin of 2 pi i / size, i < size/2: the values of llz_fft_init / llz_fft_fixed_init, built on
+// the host) is copied into LDS once per workgroup: a butterfly's twiddle is then one LDS read instead of two dword
+// gathers through the vector memory path, which is what the first version of these kernels was bound by (a 1024-point
+// transform made ~10,000 such gathers).  Lanes of a pass read entries a power-of-two stride apart: one pad entry per 32
+// keeps strides up to 32 conflict-free.
+__device__ __forceinline__ int tw_phys(int i) { return i + (i >> 5); }
+__host__ __device__ constexpr int tw_entries(int size) { return (size >> 1) + (size >> 6) + 1; }
+
+template <typename TW>
+__device__ __forceinline__ void fft_load_twiddles(cpx<TW> *tw, const TW *__restrict__ cs, int size, int tid)
+{
+    for (int e = tid; e < (size >> 1); e += FFT_THREADS) {
+        cpx<TW> t;
+        t.re = cs[e];
+        t.im = cs[size + e];
+        tw[tw_phys(e)] = t;
+    }
+}
+
 // One pass = G consecutive radix-2 stages done in registers on E = 2^G elements per work item: G barriers fewer than
 // stage-by-stage, and every butterfly still is the reference's butterfly (same operands, same operation order), so
 // the double and Q15 flavours stay bit-identical to llz_fft / llz_fft_fixed.
@@ -100,7 +121,7 @@ __device__ __forceinline__ int fft_phys(int i) { return i + (i >> 5); }
 //   element j of an item sits at  blk * (E * step) + j * step + r,   step = distance between the item's elements
 template <typename A, int G, bool INVERSE>
 __device__ __forceinline__ void fft_pass(cpx<typename A::data_t> *s, int tpw, int size, int log2n, int log2step,
-                                         int tstride, const typename A::tw_t *__restrict__ cs, int tid)
+                                         int tstride, const cpx<typename A::tw_t> *tw, int tid)
 {
     typedef typename A::data_t T;
     constexpr int E = 1 << G;
@@ -125,16 +146,17 @@ __device__ __forceinline__ void fft_pass(cpx<typename A::data_t> *s, int tpw, in
                 if (j & hj) continue;
                 const int q = ((j & (hj - 1)) << log2step) + r;
                 const int idx = q << tshift;
-                const typename A::tw_t wr = cs[idx];
+                const cpx<typename A::tw_t> t = tw[tw_phys(idx)];       // (cos, sin) of 2 pi idx / size
+                const typename A::tw_t wr = t.re;
                 const cpx<T> u = v[j], w = v[j + hj];
                 if (!INVERSE) {
-                    const typename A::tw_t wi = A::neg(cs[size + idx]);
+                    const typename A::tw_t wi = A::neg(t.im);
                     cpx<T> x, y;
                     x.re = A::add(u.re, w.re); x.im = A::add(u.im, w.im);
                     A::rot(A::sub(u.re, w.re), A::sub(u.im, w.im), wr, wi, y.re, y.im);
                     v[j] = x; v[j + hj] = y;
                 } else {
-                    const typename A::tw_t wi = cs[size + idx];
+                    const typename A::tw_t wi = t.im;
                     T dr, di;
                     A::rot(w.re, w.im, wr, wi, dr, di);
                     cpx<T> x, y;
@@ -148,6 +170,131 @@ __device__ __forceinline__ void fft_pass(cpx<typename A::data_t> *s, int tpw, in
         for (int j = 0; j < E; j++) base[fft_phys(i0 + (j << log2step))] = v[j];
     }
     __syncthreads();
+}
+
+// float32 flavour of a pass (tolerance, not bit-exact).  G radix-2 stages with their stage twiddles factor into an
+// E-point transform whose internal twiddles are the CONSTANTS W_16^t plus ONE multiplication per element by
+// W_(E*step)^(r*k) (k = the element's frequency index inside the item, r = the item's offset inside its block):
+//   forward DIF:  v <- DFT_E(v) (natural in, bit-reversed out), then v[p] *= W^(r * brev(p))
+//   inverse DIT:  v[p] *= conj(W)^(r * brev(p)), then inverse DFT_E (bit-reversed in, natural out)
+// which is the same linear map as fft_pass (so passes of both kinds may be mixed) at a third of the instructions:
+// E - 1 table reads per item instead of G*E/2, no multiplications by 1 and -i, no index arithmetic per butterfly.
+template <int T16, bool INVERSE>
+__device__ __forceinline__ cpx<float> mul_w16(cpx<float> d)
+{
+    // d * W_16^T16, W_16 = exp(-2 pi i / 16) (conjugated for the inverse)
+    constexpr float R = 0.70710678118654752440f, C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f;
+    cpx<float> y;
+    if (T16 == 0) return d;
+    if (T16 == 4) {                                   // -i (forward), +i (inverse)
+        y.re = INVERSE ? -d.im : d.im;
+        y.im = INVERSE ? d.re : -d.re;
+        return y;
+    }
+    if (T16 == 2) {                                   // (1 - i)/sqrt2 forward
+        y.re = INVERSE ? (d.re - d.im) * R : (d.re + d.im) * R;
+        y.im = INVERSE ? (d.re + d.im) * R : (d.im - d.re) * R;
+        return y;
+    }
+    if (T16 == 6) {                                   // (-1 - i)/sqrt2 forward
+        y.re = INVERSE ? (-d.re - d.im) * R : (d.im - d.re) * R;
+        y.im = INVERSE ? (d.re - d.im) * R : (-d.re - d.im) * R;
+        return y;
+    }
+    const float c = (T16 == 1) ? C1 : (T16 == 3) ? S1 : (T16 == 5) ? -S1 : -C1;     // cos(2 pi T16 / 16)
+    const float sn = (T16 == 1 || T16 == 7) ? S1 : C1;                               // sin(2 pi T16 / 16)
+    const float wi = INVERSE ? sn : -sn;
+    y.re = __builtin_fmaf(d.re, c, -(d.im * wi));
+    y.im = __builtin_fmaf(d.re, wi, d.im * c);
+    return y;
+}
+
+template <int E, int g, int j, bool INVERSE>
+__device__ __forceinline__ void small_bfly(cpx<float> (&v)[E])
+{
+    constexpr int hj = INVERSE ? (1 << g) : (E >> (g + 1));
+    if constexpr ((j & hj) == 0) {
+        constexpr int t16 = (j & (hj - 1)) * (8 / hj);                  // W_(2hj)^(j mod hj) in sixteenths of a turn
+        const cpx<float> u = v[j], w = v[j + hj];
+        if (!INVERSE) {
+            cpx<float> d;
+            d.re = u.re - w.re; d.im = u.im - w.im;
+            v[j].re = u.re + w.re; v[j].im = u.im + w.im;
+            v[j + hj] = mul_w16<t16, false>(d);
+        } else {
+            const cpx<float> d = mul_w16<t16, true>(w);
+            v[j].re = u.re + d.re; v[j].im = u.im + d.im;
+            v[j + hj].re = u.re - d.re; v[j + hj].im = u.im - d.im;
+        }
+    }
+}
+
+template <int E, int g, bool INVERSE, int... J>
+__device__ __forceinline__ void small_stage(cpx<float> (&v)[E], std::integer_sequence<int, J...>)
+{
+    (small_bfly<E, g, J, INVERSE>(v), ...);
+}
+
+template <int E, bool INVERSE, int... Gs>
+__device__ __forceinline__ void small_fft(cpx<float> (&v)[E], std::integer_sequence<int, Gs...>)
+{
+    (small_stage<E, Gs, INVERSE>(v, std::make_integer_sequence<int, E>{}), ...);
+}
+
+template <int G, bool INVERSE>
+__device__ __forceinline__ void fft_pass_f32(cpx<float> *s, int tpw, int size, int log2n, int log2step, int tstride,
+                                             const cpx<float> *tw, int tid)
+{
+    constexpr int E = 1 << G;
+    const int step = 1 << log2step;
+    const int log2items = log2n - G;
+    const int items = tpw << log2items;
+    const int tshift = log2n - G - log2step;               // W_(E*step)^m = W_size^(m << tshift)
+    const int half = size >> 1;
+    for (int it = tid; it < items; it += FFT_THREADS) {
+        const int tr = it >> log2items, rem = it & ((1 << log2items) - 1);
+        const int r = rem & (step - 1), blk = rem >> log2step;
+        cpx<float> *base = s + tr * tstride;
+        const int i0 = (blk << (G + log2step)) + r;
+        cpx<float> v[E];
+#pragma unroll
+        for (int j = 0; j < E; j++) v[j] = base[fft_phys(i0 + (j << log2step))];
+        const int m = r << tshift;                         // W_(E*step)^(r k) = W_size^(k m), k m < size
+        auto twiddle = [&](int p) {                        // v[p] *= W^(r * brev_G(p)), conjugated for the inverse
+            const int k = (int)(__brev((unsigned)p) >> (32 - G));
+            int idx = k * m;
+            const bool wrap = idx >= half;                 // W^(idx) = -W^(idx - size/2): the table holds half a turn
+            idx = wrap ? idx - half : idx;                 // (a whole-turn table cost more in LDS than it saved: measured)
+            const cpx<float> t = tw[tw_phys(idx)];
+            const float c = wrap ? -t.re : t.re;
+            const float sn = wrap ? -t.im : t.im;
+            const float wi = INVERSE ? sn : -sn;
+            const cpx<float> d = v[p];
+            v[p].re = __builtin_fmaf(d.re, c, -(d.im * wi));
+            v[p].im = __builtin_fmaf(d.re, wi, d.im * c);
+        };
+        if (INVERSE && step > 1) {
+#pragma unroll
+            for (int p = 1; p < E; p++) twiddle(p);
+        }
+        small_fft<E, INVERSE>(v, std::make_integer_sequence<int, G>{});
+        if (!INVERSE && step > 1) {
+#pragma unroll
+            for (int p = 1; p < E; p++) twiddle(p);
+        }
+#pragma unroll
+        for (int j = 0; j < E; j++) base[fft_phys(i0 + (j << log2step))] = v[j];
+    }
+    __syncthreads();
+}
+
+// the float32 flavour takes the factored pass, the exact flavours the reference's butterflies
+template <typename A, int G, bool INVERSE>
+__device__ __forceinline__ void fft_pass_any(cpx<typename A::data_t> *s, int tpw, int size, int log2n, int log2step,
+                                             int tstride, const cpx<typename A::tw_t> *tw, int tid)
+{
+    if constexpr (std::is_same<A, arith_f32>::value) fft_pass_f32<G, INVERSE>(s, tpw, size, log2n, log2step, tstride, tw, tid);
+    else fft_pass<A, G, INVERSE>(s, tpw, size, log2n, log2step, tstride, tw, tid);
 }
 
 // groups: up to four passes, G of pass p in bits [4p, 4p+4) (0 = no pass). tpw transforms per workgroup.
@@ -165,6 +312,8 @@ k_fft_radix2(typename A::data_t *__restrict__ data, int count, int size, int log
     cpx<T> *g = reinterpret_cast<cpx<T> *>(data) + (size_t)tr0 * size;
     const int tstride = fft_phys(size) + 1;
     const int total = ntr << log2n;
+    cpx<typename A::tw_t> *tw = reinterpret_cast<cpx<typename A::tw_t> *>(s + (size_t)tpw * tstride);
+    fft_load_twiddles(tw, cs, size, tid);
 
     // load (inverse: through the bit-reversal, float flavour divides by N here: llz_fft.c:187-195)
     for (int e = tid; e < total; e += FFT_THREADS) {
@@ -189,10 +338,10 @@ k_fft_radix2(typename A::data_t *__restrict__ data, int count, int size, int log
         // inverse: first stage has half-span 1 << done = step
         const int log2step = INVERSE ? done : (log2n - done - G);
         switch (G) {
-        case 1: fft_pass<A, 1, INVERSE>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
-        case 2: fft_pass<A, 2, INVERSE>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
-        case 3: fft_pass<A, 3, INVERSE>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
-        default: fft_pass<A, 4, INVERSE>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
+        case 1: fft_pass_any<A, 1, INVERSE>(s, ntr, size, log2n, log2step, tstride, tw, tid); break;
+        case 2: fft_pass_any<A, 2, INVERSE>(s, ntr, size, log2n, log2step, tstride, tw, tid); break;
+        case 3: fft_pass_any<A, 3, INVERSE>(s, ntr, size, log2n, log2step, tstride, tw, tid); break;
+        default: fft_pass_any<A, 4, INVERSE>(s, ntr, size, log2n, log2step, tstride, tw, tid); break;
         }
         done += G;
     }
@@ -227,6 +376,8 @@ k_acf_fused_f32(const float *__restrict__ x, float *__restrict__ r, int frames, 
     const int ntr = min(tpw, frames - tr0);
     const int tstride = fft_phys(size) + 1;
     const int total = ntr << log2n;
+    cpx<float> *tw = s + (size_t)tpw * tstride;
+    fft_load_twiddles(tw, cs, size, tid);
     for (int e = tid; e < total; e += FFT_THREADS) {
         const int tr = e >> log2n, i = e & (size - 1);
         cpx<float> v;
@@ -242,10 +393,10 @@ k_acf_fused_f32(const float *__restrict__ x, float *__restrict__ r, int frames, 
         if (G == 0) break;
         const int log2step = log2n - done - G;
         switch (G) {
-        case 1: fft_pass<arith_f32, 1, false>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
-        case 2: fft_pass<arith_f32, 2, false>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
-        case 3: fft_pass<arith_f32, 3, false>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
-        default: fft_pass<arith_f32, 4, false>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
+        case 1: fft_pass_f32<1, false>(s, ntr, size, log2n, log2step, tstride, tw, tid); break;
+        case 2: fft_pass_f32<2, false>(s, ntr, size, log2n, log2step, tstride, tw, tid); break;
+        case 3: fft_pass_f32<3, false>(s, ntr, size, log2n, log2step, tstride, tw, tid); break;
+        default: fft_pass_f32<4, false>(s, ntr, size, log2n, log2step, tstride, tw, tid); break;
         }
         done += G;
     }
@@ -266,10 +417,10 @@ k_acf_fused_f32(const float *__restrict__ x, float *__restrict__ r, int frames, 
         const int G = (groups >> (4 * pss)) & 15;
         if (G == 0) break;
         switch (G) {
-        case 1: fft_pass<arith_f32, 1, true>(s, ntr, size, log2n, done, tstride, cs, tid); break;
-        case 2: fft_pass<arith_f32, 2, true>(s, ntr, size, log2n, done, tstride, cs, tid); break;
-        case 3: fft_pass<arith_f32, 3, true>(s, ntr, size, log2n, done, tstride, cs, tid); break;
-        default: fft_pass<arith_f32, 4, true>(s, ntr, size, log2n, done, tstride, cs, tid); break;
+        case 1: fft_pass_f32<1, true>(s, ntr, size, log2n, done, tstride, tw, tid); break;
+        case 2: fft_pass_f32<2, true>(s, ntr, size, log2n, done, tstride, tw, tid); break;
+        case 3: fft_pass_f32<3, true>(s, ntr, size, log2n, done, tstride, tw, tid); break;
+        default: fft_pass_f32<4, true>(s, ntr, size, log2n, done, tstride, tw, tid); break;
         }
         done += G;
     }
@@ -298,6 +449,8 @@ k_stft_analysis_f32(const float *__restrict__ x, const float *__restrict__ hist,
     const int tstride = fft_phys(size) + 1;
     const int total = ntr << log2n;
     const int keep = size - F;                                         // history samples in front of a call
+    cpx<float> *tw = s + (size_t)tpw * tstride;
+    fft_load_twiddles(tw, cs, size, tid);
     for (int e = tid; e < total; e += FFT_THREADS) {
         const int tr = e >> log2n, i = e & (size - 1);
         const long g = tr0 + tr;
@@ -317,10 +470,10 @@ k_stft_analysis_f32(const float *__restrict__ x, const float *__restrict__ hist,
         if (G == 0) break;
         const int log2step = log2n - done - G;
         switch (G) {
-        case 1: fft_pass<arith_f32, 1, false>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
-        case 2: fft_pass<arith_f32, 2, false>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
-        case 3: fft_pass<arith_f32, 3, false>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
-        default: fft_pass<arith_f32, 4, false>(s, ntr, size, log2n, log2step, tstride, cs, tid); break;
+        case 1: fft_pass_f32<1, false>(s, ntr, size, log2n, log2step, tstride, tw, tid); break;
+        case 2: fft_pass_f32<2, false>(s, ntr, size, log2n, log2step, tstride, tw, tid); break;
+        case 3: fft_pass_f32<3, false>(s, ntr, size, log2n, log2step, tstride, tw, tid); break;
+        default: fft_pass_f32<4, false>(s, ntr, size, log2n, log2step, tstride, tw, tid); break;
         }
         done += G;
     }
@@ -349,12 +502,14 @@ k_stft_synthesis_f32(const float *__restrict__ re, const float *__restrict__ im,
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tstride = fft_phys(size) + 1;
     cpx<float> *s = reinterpret_cast<cpx<float> *>(smem_raw);
-    float *carry = reinterpret_cast<float *>(s + (size_t)tpw * tstride);   // size - F floats
+    cpx<float> *tw = s + (size_t)tpw * tstride;
+    float *carry = reinterpret_cast<float *>(tw + tw_entries(size));      // size - F floats
     const int tid = threadIdx.x;
     const int c = blockIdx.x / runs, run = blockIdx.x - c * runs;
     const int b0 = run * run_len, b1 = min(frames, b0 + run_len);
     const int R = size / F, keep = size - F, bins = (size >> 1) + 1;
     const int fs = max(0, b0 - (R - 1));
+    fft_load_twiddles(tw, cs, size, tid);
     for (int q = tid; q < keep; q += FFT_THREADS) carry[q] = fs == 0 ? ola_old[(size_t)c * keep + q] : 0.f;
     const float inv = 1.0f / (float)size;                                  // llz_ifft divides by N (llz_fft.c:187-195)
     for (int g0 = fs; g0 < b1; g0 += tpw) {
@@ -381,10 +536,10 @@ k_stft_synthesis_f32(const float *__restrict__ re, const float *__restrict__ im,
             const int G = (groups >> (4 * pss)) & 15;
             if (G == 0) break;
             switch (G) {
-            case 1: fft_pass<arith_f32, 1, true>(s, ng, size, log2n, done, tstride, cs, tid); break;
-            case 2: fft_pass<arith_f32, 2, true>(s, ng, size, log2n, done, tstride, cs, tid); break;
-            case 3: fft_pass<arith_f32, 3, true>(s, ng, size, log2n, done, tstride, cs, tid); break;
-            default: fft_pass<arith_f32, 4, true>(s, ng, size, log2n, done, tstride, cs, tid); break;
+            case 1: fft_pass_f32<1, true>(s, ng, size, log2n, done, tstride, tw, tid); break;
+            case 2: fft_pass_f32<2, true>(s, ng, size, log2n, done, tstride, tw, tid); break;
+            case 3: fft_pass_f32<3, true>(s, ng, size, log2n, done, tstride, tw, tid); break;
+            default: fft_pass_f32<4, true>(s, ng, size, log2n, done, tstride, tw, tid); break;
             }
             done += G;
         }
@@ -447,7 +602,8 @@ int launch_fft(typename A::data_t *data, int count, int size, const typename A::
     if (tpw < 1) tpw = 1;
     if (tpw > count) tpw = count;
     const int tstride = size + (size >> 5) + 1;
-    const size_t lds = (size_t)tpw * tstride * 2 * sizeof(typename A::data_t);
+    const size_t lds = (size_t)tpw * tstride * 2 * sizeof(typename A::data_t) +
+                       (size_t)tw_entries(size) * 2 * sizeof(typename A::tw_t);
     if (lds >= 64 * 1024) {
         LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fft_radix2<A, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -504,8 +660,11 @@ extern "C" int llzs_acf_fused_f32(const float *x, float *r, int frames, int n, i
     if (tpw < 1) tpw = 1;
     if (tpw > frames) tpw = frames;
     const int tstride = size + (size >> 5) + 1;
-    const size_t lds = (size_t)tpw * tstride * 2 * sizeof(float);
+    const size_t lds = (size_t)tpw * tstride * 2 * sizeof(float) + (size_t)tw_entries(size) * 2 * sizeof(float);
     const unsigned blocks = (unsigned)((frames + tpw - 1) / tpw);
+    if (lds >= 64 * 1024)
+        LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_acf_fused_f32),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_acf_fused_f32, dim3(blocks), dim3(FFT_THREADS), lds, as_stream(stream), x, r, frames, n, p,
                        size, log2n, cs, tpw, groups);
     LLZ_LAUNCH_CHECK("k_acf_fused_f32");
@@ -552,7 +711,7 @@ extern "C" int llzs_stft_analysis_f32(const float *x, const float *hist, float *
     int tpw = 2048 / size;
     if (tpw > total_tr) tpw = (int)total_tr;
     const int tstride = size + (size >> 5) + 1;
-    const size_t lds = (size_t)tpw * tstride * 2 * sizeof(float);
+    const size_t lds = (size_t)tpw * tstride * 2 * sizeof(float) + (size_t)tw_entries(size) * 2 * sizeof(float);
     const long blocks = (total_tr + tpw - 1) / tpw;
     hipLaunchKernelGGL(k_stft_analysis_f32, dim3((unsigned)blocks), dim3(FFT_THREADS), lds, as_stream(stream), x, hist,
                        re, im, w, frames, F, size, log2n, cs, tpw, stft_groups(log2n), x_pitch, total_tr);
@@ -581,7 +740,8 @@ extern "C" int llzs_stft_synthesis_f32(const float *re, const float *im, float *
     if (run_len > frames) run_len = frames;
     const int runs = (frames + run_len - 1) / run_len;
     const int tstride = size + (size >> 5) + 1;
-    const size_t lds = (size_t)tpw * tstride * 2 * sizeof(float) + (size_t)(size - F) * sizeof(float);
+    const size_t lds = (size_t)tpw * tstride * 2 * sizeof(float) + (size_t)tw_entries(size) * 2 * sizeof(float) +
+                       (size_t)(size - F) * sizeof(float);
     hipLaunchKernelGGL(k_stft_synthesis_f32, dim3((unsigned)((long)channels * runs)), dim3(FFT_THREADS), lds,
                        as_stream(stream), re, im, x, ola_old, ola_new, w, frames, F, size, log2n, cs, tpw,
                        stft_groups(log2n), x_pitch, run_len, runs, magic);

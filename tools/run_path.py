@@ -50,6 +50,12 @@ elif what == "fir63":
     f = filters.FirFilterMC(ch, n, filters.fir_design("lpf", 63, 0.25, 0.0, filters.HAMMING), algo=1)
     for _ in range(steps):
         f.filter(x, y)
+elif what == "fft":
+    N, count = 1024, 65536
+    data = torch.rand(count, 2 * N, dtype=torch.float32, device=dev)
+    f = filters.FftBatch(N)
+    for _ in range(steps):
+        f.fft(data, count)
 elif what == "iir":
     ch, n = 1024, 1 << 20
     x = torch.empty(ch, n, dtype=torch.float32, device=dev)
