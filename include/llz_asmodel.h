@@ -5,12 +5,14 @@
  *         call on host `double` buffers, the transform on the GPU in the reference's operation order and the framing on
  *         the host in the reference's statement order: bit-identical results.
  * Part 2: many channels and frames per call, float32.
- * The MDCT half of the reference header (llz_analysis_mdct_* / llz_synthesis_mdct_*) is SURVEY.md 8(f) rank 4: not built.
+ * The MDCT half of the reference header (llz_analysis_mdct_* / llz_synthesis_mdct_*) sits on
+ * llz_mdct.h the same way.
  */
 #ifndef LLZ_ASMODEL_H
 #define LLZ_ASMODEL_H
 
 #include "llz_fir.h"     /* win_t */
+#include "llz_mdct.h"    /* mdct_win_t */
 
 #ifdef __cplusplus
 extern "C" {
@@ -34,6 +36,16 @@ void          llz_synthesis_fft_uninit(unsigned long handle);
 /* inverse transform of the Hermitian extension of bins 0..fft_len/2, windowed overlap-add; x receives the oldest
  * frame_len samples of the running sum times the scale (a delay of fft_len - frame_len samples against the analysis) */
 void          llz_synthesis_fft(unsigned long handle, double *re, double *im, double *x);
+
+/* windowed MDCT frames with 50 % overlap (time-domain alias cancellation), llz_asmodel.h:45-51, llz_asmodel.c:313-463:
+ * the transform is MDCT_FFT4 of length 2*frame_len; analysis followed by synthesis returns the input delayed by one
+ * frame.  frame_len a power of two, 4..8192. */
+unsigned long llz_analysis_mdct_init(int frame_len, mdct_win_t win_type);
+void          llz_analysis_mdct_uninit(unsigned long handle);
+void          llz_analysis_mdct(unsigned long handle, double *x, double *X);     /* frame_len in, frame_len coefficients */
+unsigned long llz_synthesis_mdct_init(int frame_len, mdct_win_t win_type);
+void          llz_synthesis_mdct_uninit(unsigned long handle);
+void          llz_synthesis_mdct(unsigned long handle, double *X, double *x);
 
 /* ---- Part 2: batch extension, float32 ---- */
 /* One handle serves both directions and keeps the streaming state of each per channel (analysis: the last

@@ -18,6 +18,8 @@ BAD_HANDLE = C.c_ulong(-1).value
 HAMMING, BLACKMAN, KAISER = 0, 1, 2
 FIR_ALGO_AUTO, FIR_ALGO_TIME, FIR_ALGO_OVERLAP_SAVE, FIR_ALGO_TIME_MFMA = 0, 1, 2, 3
 OVERLAP_HIGH, OVERLAP_LOW = 0, 1      # llz_asmodel.h: 3/4 and 1/2 overlap
+MDCT_ORIGIN, MDCT_FFT, MDCT_FFT4 = 0, 1, 2
+MDCT_SINE, MDCT_KBD = 0, 1
 PCM_F32, PCM_I16 = 0, 1
 
 _lib = None
@@ -192,6 +194,24 @@ def lib():
     sig("llz_stft_mc_set_stream", i, ul, vp)
     sig("llz_stft_mc_analysis", i, ul, vp, vp, vp, i)
     sig("llz_stft_mc_synthesis", i, ul, vp, vp, vp, i)
+    for n in ("llz_analysis_mdct_init", "llz_synthesis_mdct_init"):
+        sig(n, ul, i, i)
+    sig("llz_analysis_mdct_uninit", None, ul)
+    sig("llz_synthesis_mdct_uninit", None, ul)
+    sig("llz_analysis_mdct", None, ul, dp, dp)
+    sig("llz_synthesis_mdct", None, ul, dp, dp)
+    # llz_mdct.h
+    sig("llz_mdct_init", ul, i, i)
+    sig("llz_mdct_uninit", None, ul)
+    sig("llz_mdct", None, ul, dp, dp)
+    sig("llz_imdct", None, ul, dp, dp)
+    sig("llz_mdct_sine", i, dp, i)
+    sig("llz_mdct_kbd", i, dp, i, d)
+    sig("llz_mdct_batch_init", ul, i)
+    sig("llz_mdct_batch_uninit", None, ul)
+    sig("llz_mdct_batch_set_stream", i, ul, vp)
+    sig("llz_mdct_batch", i, ul, vp, vp, i)
+    sig("llz_imdct_batch", i, ul, vp, vp, i)
     # llz_pcm.h
     sig("llz_pcm_deinterleave_i16_f32", i, vp, vp, i, lng, C.c_float, vp)
     sig("llz_pcm_interleave_f32_i16", i, vp, vp, i, lng, C.c_float, vp)

@@ -7,6 +7,7 @@
 #include <string.h>
 #include "../../../include/llz_asmodel.h"
 #include "../../../include/llz_fft.h"
+#include "../../../include/llz_mdct.h"
 #include "llz_host.h"
 
 #define LLZ_TAG_ASM1 0x4c5a5331
@@ -140,6 +141,100 @@ void llz_synthesis_fft(unsigned long handle, double *re, double *im, double *x)
     for (int i = 0; i < F; i++) x[i] = f->magic * f->x_buf[i];
     for (int i = 0; i < N - F; i++) f->x_buf[i] = f->x_buf[i + F];
     for (int i = 0; i < F; i++) f->x_buf[i + N - F] = 0;
+}
+
+/* ---- Part 1b: MDCT frames (llz_asmodel.c:313-463) ---- */
+
+#define LLZ_TAG_ASMD 0x4c5a5344
+
+typedef struct {
+    int tag, frame_len, mdct_len;
+    double *x_buf, *mdct_buf, *window;
+    unsigned long h_mdct;
+} asmd_t;
+
+static void asmd_destroy(asmd_t *f)
+{
+    if (!f) return;
+    if (f->h_mdct && f->h_mdct != LLZ_BAD_HANDLE) llz_mdct_uninit(f->h_mdct);
+    free(f->x_buf); free(f->mdct_buf); free(f->window);
+    f->tag = 0;
+    free(f);
+}
+
+static unsigned long asmd_init(int frame_len, mdct_win_t win_type, const char *who)
+{
+    if (frame_len < 4 || frame_len > 8192 || (frame_len & (frame_len - 1)) ||
+        (win_type != MDCT_SINE && win_type != MDCT_KBD)) {
+        llzs_set_error("%s: frame_len %d (a power of two in 4..8192) window %d", who, frame_len, (int)win_type);
+        return LLZ_BAD_HANDLE;
+    }
+    asmd_t *f = (asmd_t *)calloc(1, sizeof(*f));
+    if (!f) return LLZ_BAD_HANDLE;
+    f->tag = LLZ_TAG_ASMD; f->frame_len = frame_len; f->mdct_len = frame_len << 1;
+    f->x_buf = (double *)calloc((size_t)f->mdct_len, sizeof(double));
+    f->mdct_buf = (double *)calloc((size_t)f->mdct_len, sizeof(double));
+    f->window = (double *)calloc((size_t)f->mdct_len, sizeof(double));
+    f->h_mdct = llz_mdct_init(MDCT_FFT4, f->mdct_len);             /* llz_asmodel.c:323 */
+    if (!f->x_buf || !f->mdct_buf || !f->window || f->h_mdct == LLZ_BAD_HANDLE) {
+        asmd_destroy(f);
+        return LLZ_BAD_HANDLE;
+    }
+    if (win_type == MDCT_SINE) llz_mdct_sine(f->window, f->mdct_len);
+    else llz_mdct_kbd(f->window, f->mdct_len, 6);                   /* llz_asmodel.c:330-331 */
+    return (unsigned long)f;
+}
+
+unsigned long llz_analysis_mdct_init(int frame_len, mdct_win_t win_type)
+{
+    return asmd_init(frame_len, win_type, "llz_analysis_mdct_init");
+}
+
+unsigned long llz_synthesis_mdct_init(int frame_len, mdct_win_t win_type)
+{
+    return asmd_init(frame_len, win_type, "llz_synthesis_mdct_init");
+}
+
+void llz_analysis_mdct_uninit(unsigned long handle)
+{
+    if (LLZ_HANDLE_OK(handle, asmd_t, LLZ_TAG_ASMD)) asmd_destroy((asmd_t *)handle);
+}
+
+void llz_synthesis_mdct_uninit(unsigned long handle)
+{
+    if (LLZ_HANDLE_OK(handle, asmd_t, LLZ_TAG_ASMD)) asmd_destroy((asmd_t *)handle);
+}
+
+void llz_analysis_mdct(unsigned long handle, double *x, double *X)
+{
+    if (!LLZ_HANDLE_OK(handle, asmd_t, LLZ_TAG_ASMD) || !x || !X) {
+        llzs_set_error("llz_analysis_mdct: bad handle or arguments");
+        return;
+    }
+    asmd_t *f = (asmd_t *)handle;
+    const int F = f->frame_len;
+    for (int i = 0; i < F; i++) f->x_buf[i] = f->x_buf[i + F];      /* llz_asmodel.c:365-376 */
+    for (int i = 0; i < F; i++) f->x_buf[i + F] = x[i];
+    for (int i = 0; i < f->mdct_len; i++) f->mdct_buf[i] = f->x_buf[i] * f->window[i];
+    llz_mdct(f->h_mdct, f->mdct_buf, X);
+}
+
+void llz_synthesis_mdct(unsigned long handle, double *X, double *x)
+{
+    if (!LLZ_HANDLE_OK(handle, asmd_t, LLZ_TAG_ASMD) || !x || !X) {
+        llzs_set_error("llz_synthesis_mdct: bad handle or arguments");
+        return;
+    }
+    asmd_t *f = (asmd_t *)handle;
+    const int F = f->frame_len;
+    llz_imdct(f->h_mdct, X, f->mdct_buf);                           /* llz_asmodel.c:446-461 */
+    for (int i = 0; i < f->mdct_len; i++) {
+        const double t = f->mdct_buf[i] * f->window[i];
+        f->x_buf[i] = f->x_buf[i] + t;
+    }
+    for (int i = 0; i < F; i++) x[i] = f->x_buf[i];
+    for (int i = 0; i < F; i++) f->x_buf[i] = f->x_buf[i + F];
+    for (int i = 0; i < F; i++) f->x_buf[i + F] = 0;
 }
 
 /* ---- Part 2: batch extension ---- */

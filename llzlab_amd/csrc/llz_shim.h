@@ -122,6 +122,13 @@ int llzs_stft_synthesis_f32(const float *re, const float *im, float *x, const fl
                             const float *w, const float *cs, int channels, int frames, int F, int size, long x_pitch,
                             float magic, void *stream);
 
+/* MDCT (llz_mdct.c): y[r] = sum_c x[c]*A[r][c] in ascending c, separately rounded multiply and add (device doubles) */
+int llzs_matvec_exact_f64(const double *A, const double *x, double *y, int rows, int cols, void *stream);
+/* N/4-point-FFT MDCT / IMDCT of `count` float32 frames: forward [count][N] -> [count][N/2], inverse the other way;
+ * tc/ts: cos/sin of -2*pi*(k+1/8)/N, k < N/4; cs: cos then sin of 2*pi*i/(N/4) */
+int llzs_mdct4_f32(const float *in, float *out, int count, int N, const float *tc, const float *ts, const float *cs,
+                   int inverse, void *stream);
+
 /* ---- PCM ingest / egress ---- */
 int llzs_pcm_deinterleave_i16_f32(const short *in, float *out, int channels, long n, float scale, void *stream);
 int llzs_pcm_interleave_f32_i16(const float *in, short *out, int channels, long n, float scale, void *stream);

@@ -513,6 +513,100 @@ class StftMC:
     __del__ = close
 
 
+# ------------------------------------------------------------------------------------------ MDCT
+def mdct_window(win, n, alpha=6.0):
+    w = np.zeros(n)
+    if win == capi.MDCT_SINE:
+        capi.lib().llz_mdct_sine(w.ctypes.data_as(_dp), n)
+    else:
+        capi.lib().llz_mdct_kbd(w.ctypes.data_as(_dp), n, alpha)
+    return w
+
+
+class Mdct:
+    """llz_mdct_init / llz_mdct / llz_imdct (llz_mdct.h:37-41): one frame per call, host float64, exact."""
+
+    def __init__(self, type_, length):
+        self._L = capi.lib()
+        self.handle = check_handle(self._L.llz_mdct_init(type_, length), "llz_mdct_init")
+        self.length = length
+
+    def forward(self, x):
+        x = _f64(x)
+        X = np.zeros(self.length // 2)
+        self._L.llz_mdct(self.handle, x.ctypes.data_as(_dp), X.ctypes.data_as(_dp))
+        return X
+
+    def inverse(self, X):
+        X = _f64(X)
+        x = np.zeros(self.length)
+        self._L.llz_imdct(self.handle, X.ctypes.data_as(_dp), x.ctypes.data_as(_dp))
+        return x
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            self._L.llz_mdct_uninit(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
+class _MdctFrames:
+    _init = _uninit = _run = None
+
+    def __init__(self, frame_len, win=0):
+        self._L = capi.lib()
+        self.handle = check_handle(getattr(self._L, self._init)(frame_len, win), self._init)
+        self.frame_len = frame_len
+
+    def frame(self, a):
+        a = _f64(a)
+        b = np.zeros(self.frame_len)
+        getattr(self._L, self._run)(self.handle, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp))
+        return b
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            getattr(self._L, self._uninit)(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
+class AnalysisMdct(_MdctFrames):
+    _init, _uninit, _run = "llz_analysis_mdct_init", "llz_analysis_mdct_uninit", "llz_analysis_mdct"
+
+
+class SynthesisMdct(_MdctFrames):
+    _init, _uninit, _run = "llz_synthesis_mdct_init", "llz_synthesis_mdct_uninit", "llz_synthesis_mdct"
+
+
+class MdctBatch:
+    """llz_mdct_batch_*: many float32 frames per call, N/4-point-FFT algorithm; x [count, len], X [count, len/2]."""
+
+    def __init__(self, length, stream=None):
+        self._L = capi.lib()
+        self.handle = check_handle(self._L.llz_mdct_batch_init(length), "llz_mdct_batch_init")
+        self.length = length
+        if stream is not None:
+            check(self._L.llz_mdct_batch_set_stream(self.handle, _stream_ptr(stream)), "set_stream")
+
+    def forward(self, x, X):
+        check(self._L.llz_mdct_batch(self.handle, _ptr(x), _ptr(X), x.shape[0]), "llz_mdct_batch")
+        return X
+
+    def inverse(self, X, x):
+        check(self._L.llz_imdct_batch(self.handle, _ptr(X), _ptr(x), X.shape[0]), "llz_imdct_batch")
+        return x
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            self._L.llz_mdct_batch_uninit(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
 # ------------------------------------------------------------------------------------------ PCM ingest / egress
 def pcm_deinterleave(ileaved, planar, scale=1.0 / 32768.0, stream=None):
     """ileaved: [n, channels] int16 -> planar: [channels, n] float32."""

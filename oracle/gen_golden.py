@@ -198,6 +198,26 @@ def main():
         d["syn_" + key] = r.stft_synthesis(hint, frame_len, win, re, im)
     np.savez_compressed(os.path.join(OUT, "stft.npz"), **d)
 
+    # ---- MDCT -----------------------------------------------------------------
+    d = {}
+    g = np.random.default_rng(7000)
+    for n in (16, 64, 256, 2048):
+        d[f"sine_{n}"] = r.mdct_window(0, n)
+        d[f"kbd_{n}"] = r.mdct_window(1, n)
+        x = g.uniform(-1, 1, n).astype(np.float32).astype(np.float64)
+        d[f"x_{n}"] = x
+        for t in (0, 1, 2):
+            if t == 0 and n > 256:
+                continue
+            X = r.mdct(t, x)
+            d[f"mdct{t}_{n}"] = X
+            d[f"imdct{t}_{n}"] = r.imdct(t, X)
+    for frame_len, win in ((8, 0), (64, 1), (512, 0)):
+        x = g.uniform(-1, 1, frame_len * 6).astype(np.float32).astype(np.float64)
+        X, y = r.mdct_frames(frame_len, win, x)
+        d[f"fx_{frame_len}_{win}"], d[f"fX_{frame_len}_{win}"], d[f"fy_{frame_len}_{win}"] = x, X, y
+    np.savez_compressed(os.path.join(OUT, "mdct.npz"), **d)
+
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden fixtures written to", OUT, "total bytes", tot)
 

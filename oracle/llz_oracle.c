@@ -812,6 +812,269 @@ void orc_stft_free(void *p)
     orc_fft_free(f->fft); free(f->x_buf); free(f->fft_buf); free(f->window); free(f);
 }
 
+/* ------------------------------------------------------------------ MDCT
+ * reference libllzfilter/llz_mdct.c:97-620: three algorithms behind one handle.
+ *   type 0 (MDCT_ORIGIN) the defining sums, type 1 (MDCT_FFT) one N-point FFT, type 2 (MDCT_FFT4) one N/4-point FFT. */
+int orc_mdct_sine(double *w, int N)
+{
+    for (int n = 0; n < N; n++) {                       /* llz_mdct.c:97-108 */
+        const double tmp = (M_PI / N) * (n + 0.5);
+        w[n] = sin(tmp);
+    }
+    return N;
+}
+
+static double mdct_bessel(double x)                    /* llz_mdct.c:110-129 (same series as llz_fir.c's) */
+{
+    double xh = (double)0.5 * x, sum = 1.0, pw = 1.0, ds = 1.0;
+    int k = 0;
+    while (ds > sum * 1E-16) {
+        ++k;
+        pw = pw * (xh / k);
+        ds = pw * pw;
+        sum = sum + ds;
+    }
+    return sum;
+}
+
+int orc_mdct_kbd(double *w, int N, double alpha)
+{
+    /* llz_mdct.c:131-182: Kaiser window of N/2+1 points with beta = alpha*pi, cumulative sums, square root */
+    const int N2 = N >> 1;
+    double *w1 = (double *)malloc(sizeof(double) * (size_t)(N2 + 1));
+    const double beta = alpha * M_PI;
+    for (int i = 0; i < N2 + 1; i++) {
+        const double Ib = mdct_bessel(beta);
+        const double x = (double)((2. * i / (N2 + 1 - 1)) - 1);
+        const double Ia = mdct_bessel(beta * (double)sqrt(1. - x * x));
+        w1[i] = (double)(Ia / Ib);
+    }
+    double sum = 0.0, tmp = 0.0;
+    for (int i = 0; i < N2 + 1; i++) sum += w1[i];
+    sum = 1.0 / sum;
+    for (int i = 0, j = N - 1; i < N2; i++, j--) {
+        tmp += w1[i];
+        w[i] = w[j] = sqrt(tmp * sum);
+    }
+    free(w1);
+    return N;
+}
+
+typedef struct {
+    int type, length;
+    void *fft;
+    double *fft_buf;
+    double *cos_pos, *cos_inv;                          /* type 0: [N/2][N] and [N][N/2] */
+    double *pre_c_pos, *pre_s_pos, *c_pos, *s_pos, *pre_c_inv, *pre_s_inv, *c_inv, *s_inv;   /* type 1 */
+    double *tw_c, *tw_s, *rot, sqrt_cof;                /* type 2 */
+} orc_mdct_t;
+
+void *orc_mdct_new(int type, int size)
+{
+    orc_mdct_t *f = (orc_mdct_t *)calloc(1, sizeof(*f));
+    int base = (int)(log(size) / log(2));               /* llz_mdct.c:375-379 */
+    if ((1 << base) < size) base += 1;
+    const int length = 1 << base;
+    f->length = length;
+    f->type = type;
+    if (type == 0) {                                    /* llz_mdct.c:384-403 */
+        f->cos_pos = (double *)calloc((size_t)(length >> 1) * length, sizeof(double));
+        f->cos_inv = (double *)calloc((size_t)length * (length >> 1), sizeof(double));
+        for (int k = 0; k < (length >> 1); k++)
+            for (int n = 0; n < length; n++) {
+                const double tmp = (M_PI / (2 * length)) * (2 * n + 1 + (length >> 1)) * (2 * k + 1);
+                f->cos_pos[(size_t)k * length + n] = f->cos_inv[(size_t)n * (length >> 1) + k] = cos(tmp);
+            }
+    } else if (type == 1) {                             /* llz_mdct.c:404-448 */
+        const double n0 = ((double)length / 2 + 1) / 2;
+        f->fft = orc_fft_new(length);
+        f->fft_buf = (double *)calloc(2 * (size_t)length, sizeof(double));
+        f->pre_c_pos = (double *)malloc(sizeof(double) * length); f->pre_s_pos = (double *)malloc(sizeof(double) * length);
+        f->c_pos = (double *)malloc(sizeof(double) * (length >> 1)); f->s_pos = (double *)malloc(sizeof(double) * (length >> 1));
+        f->pre_c_inv = (double *)malloc(sizeof(double) * length); f->pre_s_inv = (double *)malloc(sizeof(double) * length);
+        f->c_inv = (double *)malloc(sizeof(double) * length); f->s_inv = (double *)malloc(sizeof(double) * length);
+        for (int k = 0; k < length; k++) {
+            f->pre_c_pos[k] = cos(-(M_PI * k) / length);
+            f->pre_s_pos[k] = sin(-(M_PI * k) / length);
+        }
+        for (int k = 0; k < (length >> 1); k++) {
+            f->c_pos[k] = cos(-2 * M_PI * n0 * (k + 0.5) / length);
+            f->s_pos[k] = sin(-2 * M_PI * n0 * (k + 0.5) / length);
+        }
+        for (int k = 0; k < length; k++) {
+            f->pre_c_inv[k] = cos((2 * M_PI * k * n0) / length);
+            f->pre_s_inv[k] = sin((2 * M_PI * k * n0) / length);
+        }
+        for (int k = 0; k < length; k++) {
+            f->c_inv[k] = cos(M_PI * (k + n0) / length);
+            f->s_inv[k] = sin(M_PI * (k + n0) / length);
+        }
+    } else {                                            /* llz_mdct.c:449-467 */
+        f->fft = orc_fft_new(length >> 2);
+        f->fft_buf = (double *)calloc((size_t)(length >> 1), sizeof(double));
+        f->sqrt_cof = 1. / sqrt(length);
+        f->rot = (double *)calloc((size_t)length, sizeof(double));
+        f->tw_c = (double *)malloc(sizeof(double) * (length >> 2));
+        f->tw_s = (double *)malloc(sizeof(double) * (length >> 2));
+        for (int k = 0; k < (length >> 2); k++) {
+            f->tw_c[k] = cos(-2 * M_PI * (k + 0.125) / length);
+            f->tw_s[k] = sin(-2 * M_PI * (k + 0.125) / length);
+        }
+    }
+    return f;
+}
+
+int orc_mdct_length(void *p) { return ((orc_mdct_t *)p)->length; }
+
+void orc_mdct_fwd(void *p, const double *x, double *X)
+{
+    orc_mdct_t *f = (orc_mdct_t *)p;
+    const int N = f->length, N2 = N >> 1, N4 = N >> 2;
+    if (f->type == 0) {                                 /* llz_mdct.c:185-202 */
+        for (int k = 0; k < N2; k++) {
+            double Xk = 0;
+            for (int n = 0; n < N; n++) Xk += x[n] * f->cos_pos[(size_t)k * N + n];
+            X[k] = Xk;
+        }
+    } else if (f->type == 1) {                          /* llz_mdct.c:225-241 */
+        for (int k = 0; k < N; k++) {
+            f->fft_buf[k + k] = x[k] * f->pre_c_pos[k];
+            f->fft_buf[k + k + 1] = x[k] * f->pre_s_pos[k];
+        }
+        orc_fft_fwd(f->fft, f->fft_buf);
+        for (int k = 0; k < N2; k++)
+            X[k] = f->fft_buf[k + k] * f->c_pos[k] - f->fft_buf[k + k + 1] * f->s_pos[k];
+    } else {                                            /* llz_mdct.c:266-303 */
+        double *rot = f->rot;
+        memset(rot, 0, sizeof(double) * (size_t)f->length);
+        for (int k = 0; k < N4; k++) rot[k] = -x[k + 3 * N4];
+        for (int k = N4; k < N; k++) rot[k] = x[k - N4];
+        for (int k = 0; k < N4; k++) {
+            const double re = rot[2 * k] - rot[N - 1 - 2 * k];
+            const double im = rot[N2 - 1 - 2 * k] - rot[N2 + 2 * k];
+            f->fft_buf[k + k] = 0.5 * (re * f->tw_c[k] - im * f->tw_s[k]);
+            f->fft_buf[k + k + 1] = 0.5 * (re * f->tw_s[k] + im * f->tw_c[k]);
+        }
+        orc_fft_fwd(f->fft, f->fft_buf);
+        for (int k = 0; k < N4; k++) {
+            const double re = f->fft_buf[k + k], im = f->fft_buf[k + k + 1];
+            X[2 * k] = 2 * (re * f->tw_c[k] - im * f->tw_s[k]);
+            X[N2 - 1 - 2 * k] = -2 * (re * f->tw_s[k] + im * f->tw_c[k]);
+        }
+    }
+}
+
+void orc_mdct_inv(void *p, const double *X, double *x)
+{
+    orc_mdct_t *f = (orc_mdct_t *)p;
+    const int N = f->length, N2 = N >> 1, N4 = N >> 2;
+    if (f->type == 0) {                                 /* llz_mdct.c:204-222 */
+        for (int n = 0; n < N; n++) {
+            double xn = 0;
+            for (int k = 0; k < N2; k++) xn += X[k] * f->cos_inv[(size_t)n * N2 + k];
+            x[n] = (xn * 4) / N;
+        }
+    } else if (f->type == 1) {                          /* llz_mdct.c:243-264 */
+        for (int k = 0; k < N2; k++) {
+            f->fft_buf[k + k] = X[k] * f->pre_c_inv[k];
+            f->fft_buf[k + k + 1] = X[k] * f->pre_s_inv[k];
+        }
+        for (int k = N2, i = N2 - 1; k < N; k++, i--) {
+            f->fft_buf[k + k] = -X[i] * f->pre_c_inv[k];
+            f->fft_buf[k + k + 1] = -X[i] * f->pre_s_inv[k];
+        }
+        orc_fft_inv(f->fft, f->fft_buf);
+        for (int k = 0; k < N; k++)
+            x[k] = 2 * (f->fft_buf[k + k] * f->c_inv[k] - f->fft_buf[k + k + 1] * f->s_inv[k]);
+    } else {                                            /* llz_mdct.c:305-353; NOTE the forward llz_fft here too */
+        double *rot = f->rot;
+        const double cof = f->sqrt_cof;
+        memset(rot, 0, sizeof(double) * (size_t)f->length);
+        for (int k = 0; k < N4; k++) {
+            const double re = X[2 * k], im = X[N2 - 1 - 2 * k];
+            f->fft_buf[k + k] = 0.5 * (re * f->tw_c[k] - im * f->tw_s[k]);
+            f->fft_buf[k + k + 1] = 0.5 * (re * f->tw_s[k] + im * f->tw_c[k]);
+        }
+        orc_fft_fwd(f->fft, f->fft_buf);
+        for (int k = 0; k < N4; k++) {
+            const double re = f->fft_buf[k + k], im = f->fft_buf[k + k + 1];
+            f->fft_buf[k + k] = 8 * cof * (re * f->tw_c[k] - im * f->tw_s[k]);
+            f->fft_buf[k + k + 1] = 8 * cof * (re * f->tw_s[k] + im * f->tw_c[k]);
+        }
+        for (int k = 0; k < N4; k++) {
+            rot[2 * k] = f->fft_buf[k + k];
+            rot[N2 + 2 * k] = f->fft_buf[k + k + 1];
+        }
+        for (int k = 1; k < N; k += 2) rot[k] = -rot[N - 1 - k];
+        for (int k = 0; k < 3 * N4; k++) x[k] = rot[N4 + k] * cof;
+        for (int k = 3 * N4; k < N; k++) x[k] = -rot[k - 3 * N4] * cof;
+    }
+}
+
+void orc_mdct_free(void *p)
+{
+    orc_mdct_t *f = (orc_mdct_t *)p;
+    if (!f) return;
+    if (f->fft) orc_fft_free(f->fft);
+    free(f->fft_buf); free(f->cos_pos); free(f->cos_inv);
+    free(f->pre_c_pos); free(f->pre_s_pos); free(f->c_pos); free(f->s_pos);
+    free(f->pre_c_inv); free(f->pre_s_inv); free(f->c_inv); free(f->s_inv);
+    free(f->tw_c); free(f->tw_s); free(f->rot); free(f);
+}
+
+/* analysis / synthesis by windowed MDCT frames with 50 % overlap (TDAC), reference llz_asmodel.c:313-463; the
+ * transform is always type 2 (MDCT_FFT4) of length 2*frame_len; win 0 = sine, 1 = KBD with alpha 6 */
+typedef struct {
+    int frame_len, mdct_len;
+    double *x_buf, *mdct_buf, *window;
+    void *mdct;
+} orc_amdct_t;
+
+void *orc_amdct_new(int frame_len, int win)
+{
+    orc_amdct_t *f = (orc_amdct_t *)calloc(1, sizeof(*f));
+    f->frame_len = frame_len;
+    f->mdct_len = frame_len << 1;
+    f->x_buf = (double *)calloc((size_t)f->mdct_len, sizeof(double));
+    f->mdct_buf = (double *)calloc((size_t)f->mdct_len, sizeof(double));
+    f->window = (double *)calloc((size_t)f->mdct_len, sizeof(double));
+    f->mdct = orc_mdct_new(2, f->mdct_len);
+    if (win == 0) orc_mdct_sine(f->window, f->mdct_len);
+    else orc_mdct_kbd(f->window, f->mdct_len, 6);
+    return f;
+}
+
+void orc_amdct_analysis(void *p, const double *x, double *X)
+{
+    orc_amdct_t *f = (orc_amdct_t *)p;
+    const int F = f->frame_len;
+    for (int i = 0; i < F; i++) f->x_buf[i] = f->x_buf[i + F];          /* llz_asmodel.c:365-376 */
+    for (int i = 0; i < F; i++) f->x_buf[i + F] = x[i];
+    for (int i = 0; i < f->mdct_len; i++) f->mdct_buf[i] = f->x_buf[i] * f->window[i];
+    orc_mdct_fwd(f->mdct, f->mdct_buf, X);
+}
+
+void orc_amdct_synthesis(void *p, const double *X, double *x)
+{
+    orc_amdct_t *f = (orc_amdct_t *)p;
+    const int F = f->frame_len;
+    orc_mdct_inv(f->mdct, X, f->mdct_buf);                               /* llz_asmodel.c:446-461 */
+    for (int i = 0; i < f->mdct_len; i++) {
+        const double t = f->mdct_buf[i] * f->window[i];
+        f->x_buf[i] = f->x_buf[i] + t;
+    }
+    for (int i = 0; i < F; i++) x[i] = f->x_buf[i];
+    for (int i = 0; i < F; i++) f->x_buf[i] = f->x_buf[i + F];
+    for (int i = 0; i < F; i++) f->x_buf[i + F] = 0;
+}
+
+void orc_amdct_free(void *p)
+{
+    orc_amdct_t *f = (orc_amdct_t *)p;
+    if (!f) return;
+    orc_mdct_free(f->mdct); free(f->x_buf); free(f->mdct_buf); free(f->window); free(f);
+}
+
 /* ------------------------------------------------------------------ batch drivers */
 
 void orc_fir_batch_f32(const float *in, double *out, int channels, long n, const double *h, int flt_len)

@@ -96,6 +96,22 @@ void   orc_stft_analysis(void *h, const double *x, double *re, double *im);     
 void   orc_stft_synthesis(void *h, const double *re, const double *im, double *x);
 void   orc_stft_free(void *h);
 
+/* MDCT, reference libllzfilter/llz_mdct.c:97-620. type 0 = defining sums, 1 = N-point FFT,
+ * 2 = N/4-point FFT; size is rounded up to a power of two as in llz_mdct_init */
+int    orc_mdct_sine(double *w, int N);
+int    orc_mdct_kbd(double *w, int N, double alpha);
+void  *orc_mdct_new(int type, int size);
+int    orc_mdct_length(void *h);
+void   orc_mdct_fwd(void *h, const double *x, double *X);          /* x: length, X: length/2 */
+void   orc_mdct_inv(void *h, const double *X, double *x);
+void   orc_mdct_free(void *h);
+
+/* windowed MDCT frames with 50 % overlap (TDAC), reference llz_asmodel.c:313-463; win 0 = sine, 1 = KBD(alpha 6) */
+void  *orc_amdct_new(int frame_len, int win);
+void   orc_amdct_analysis(void *h, const double *x, double *X);    /* x: frame_len in, X: frame_len coefficients */
+void   orc_amdct_synthesis(void *h, const double *X, double *x);
+void   orc_amdct_free(void *h);
+
 /* ---- batch drivers over the restatement (what the multi-channel GPU path is compared with) ---- */
 
 /* planar [C][n] float input -> planar double output; every channel runs its own orc_fir state machine

@@ -124,6 +124,19 @@ class Oracle:
         L.orc_stft_analysis.argtypes = [vp, _dp, _dp, _dp]
         L.orc_stft_synthesis.argtypes = [vp, _dp, _dp, _dp]
         L.orc_stft_free.argtypes = [vp]
+        L.orc_mdct_sine.argtypes = [_dp, C.c_int]
+        L.orc_mdct_kbd.argtypes = [_dp, C.c_int, C.c_double]
+        L.orc_mdct_new.restype = vp
+        L.orc_mdct_new.argtypes = [C.c_int, C.c_int]
+        L.orc_mdct_length.argtypes = [vp]
+        L.orc_mdct_fwd.argtypes = [vp, _dp, _dp]
+        L.orc_mdct_inv.argtypes = [vp, _dp, _dp]
+        L.orc_mdct_free.argtypes = [vp]
+        L.orc_amdct_new.restype = vp
+        L.orc_amdct_new.argtypes = [C.c_int, C.c_int]
+        L.orc_amdct_analysis.argtypes = [vp, _dp, _dp]
+        L.orc_amdct_synthesis.argtypes = [vp, _dp, _dp]
+        L.orc_amdct_free.argtypes = [vp]
         L.orc_fir_batch_f32.argtypes = [C.c_void_p, _dp, C.c_int, C.c_long, _dp, C.c_int]
         L.orc_iir_cascade_batch_f32.argtypes = [C.c_void_p, _dp, C.c_int, C.c_long, _dp, C.c_int]
         L.orc_rs_batch_f32.restype = C.c_long
@@ -331,6 +344,45 @@ class Oracle:
         self.lib.orc_stft_free(h)
         return x
 
+    def mdct_window(self, win, n, alpha=6.0):
+        w = np.zeros(n)
+        if win == 0:
+            self.lib.orc_mdct_sine(_ptr(w), n)
+        else:
+            self.lib.orc_mdct_kbd(_ptr(w), n, alpha)
+        return w
+
+    def mdct(self, type_, x):
+        x = _f64(x)
+        h = self.lib.orc_mdct_new(type_, len(x))
+        X = np.zeros(self.lib.orc_mdct_length(h) // 2)
+        self.lib.orc_mdct_fwd(h, _ptr(x), _ptr(X))
+        self.lib.orc_mdct_free(h)
+        return X
+
+    def imdct(self, type_, X):
+        X = _f64(X)
+        h = self.lib.orc_mdct_new(type_, 2 * len(X))
+        x = np.zeros(2 * len(X))
+        self.lib.orc_mdct_inv(h, _ptr(X), _ptr(x))
+        self.lib.orc_mdct_free(h)
+        return x
+
+    def mdct_frames(self, frame_len, win, x):
+        """stream x through one analysis and one synthesis handle -> (coefficients [frames, frame_len], output)"""
+        x = _f64(x)
+        a, s = self.lib.orc_amdct_new(frame_len, win), self.lib.orc_amdct_new(frame_len, win)
+        frames = len(x) // frame_len
+        X, y = np.zeros((frames, frame_len)), np.zeros(frames * frame_len)
+        for f in range(frames):
+            xi, Xi, yi = np.ascontiguousarray(x[f * frame_len:(f + 1) * frame_len]), np.zeros(frame_len), np.zeros(frame_len)
+            self.lib.orc_amdct_analysis(a, _ptr(xi), _ptr(Xi))
+            self.lib.orc_amdct_synthesis(s, _ptr(Xi), _ptr(yi))
+            X[f], y[f * frame_len:(f + 1) * frame_len] = Xi, yi
+        self.lib.orc_amdct_free(a)
+        self.lib.orc_amdct_free(s)
+        return X, y
+
     # ---- batch drivers (oracle only) -----------------------------------------------------------
     def fir_batch_f32(self, x, h):
         x = np.ascontiguousarray(x, dtype=np.float32)
@@ -452,6 +504,20 @@ class Ref:
         L.llz_synthesis_fft.argtypes = [ul, _dp, _dp, _dp]
         L.llz_analysis_fft_uninit.argtypes = [ul]
         L.llz_synthesis_fft_uninit.argtypes = [ul]
+        L.llz_mdct_sine.argtypes = [_dp, C.c_int]
+        L.llz_mdct_kbd.argtypes = [_dp, C.c_int, C.c_double]
+        L.llz_mdct_init.restype = ul
+        L.llz_mdct_init.argtypes = [C.c_int, C.c_int]
+        L.llz_mdct.argtypes = [ul, _dp, _dp]
+        L.llz_imdct.argtypes = [ul, _dp, _dp]
+        L.llz_mdct_uninit.argtypes = [ul]
+        for n in ("llz_analysis_mdct_init", "llz_synthesis_mdct_init"):
+            getattr(L, n).restype = ul
+            getattr(L, n).argtypes = [C.c_int, C.c_int]
+        L.llz_analysis_mdct.argtypes = [ul, _dp, _dp]
+        L.llz_synthesis_mdct.argtypes = [ul, _dp, _dp]
+        L.llz_analysis_mdct_uninit.argtypes = [ul]
+        L.llz_synthesis_mdct_uninit.argtypes = [ul]
         self._libc = C.CDLL(None)
         self._libc.free.argtypes = [C.c_void_p]
 
@@ -560,6 +626,45 @@ class Ref:
             x[f * frame_len:(f + 1) * frame_len] = xo
         self.lib.llz_synthesis_fft_uninit(h)
         return x
+
+    def mdct_window(self, win, n, alpha=6.0):
+        w = np.zeros(n)
+        if win == 0:
+            self.lib.llz_mdct_sine(_ptr(w), n)
+        else:
+            self.lib.llz_mdct_kbd(_ptr(w), n, alpha)
+        return w
+
+    def mdct(self, type_, x):
+        x = _f64(x)
+        h = self.lib.llz_mdct_init(type_, len(x))
+        X = np.zeros(len(x) // 2)
+        self.lib.llz_mdct(h, _ptr(x), _ptr(X))
+        self.lib.llz_mdct_uninit(h)
+        return X
+
+    def imdct(self, type_, X):
+        X = _f64(X)
+        h = self.lib.llz_mdct_init(type_, 2 * len(X))
+        x = np.zeros(2 * len(X))
+        self.lib.llz_imdct(h, _ptr(X), _ptr(x))
+        self.lib.llz_mdct_uninit(h)
+        return x
+
+    def mdct_frames(self, frame_len, win, x):
+        x = _f64(x)
+        a = self.lib.llz_analysis_mdct_init(frame_len, win)
+        s = self.lib.llz_synthesis_mdct_init(frame_len, win)
+        frames = len(x) // frame_len
+        X, y = np.zeros((frames, frame_len)), np.zeros(frames * frame_len)
+        for f in range(frames):
+            xi, Xi, yi = np.ascontiguousarray(x[f * frame_len:(f + 1) * frame_len]), np.zeros(frame_len), np.zeros(frame_len)
+            self.lib.llz_analysis_mdct(a, _ptr(xi), _ptr(Xi))
+            self.lib.llz_synthesis_mdct(s, _ptr(Xi), _ptr(yi))
+            X[f], y[f * frame_len:(f + 1) * frame_len] = Xi, yi
+        self.lib.llz_analysis_mdct_uninit(a)
+        self.lib.llz_synthesis_mdct_uninit(s)
+        return X, y
 
     def _rs_open(self, mode, L, M, gain, win):
         if mode == 0:

@@ -617,3 +617,69 @@ def test_stft_mc_host_buffers_and_many_runs(dev, oracle):
     ref_x = np.stack([oracle.stft_synthesis(hint, frame_len, win, re[c], im[c]) for c in range(channels)])
     rms_check(xo, ref_x, "stft synthesis, 700 frames")
     f.close()
+
+
+# ------------------------------------------------------------------------------------------------ MDCT (8f rank 4)
+def test_mdct_reference_symbols_exact(dev):
+    """llz_mdct / llz_imdct (three algorithms), the two windows and the TDAC frames through the product library against
+    the fixtures generated from the compiled reference: bit-identical"""
+    d = load("mdct.npz")
+    for n in (16, 64, 256, 2048):
+        assert np.array_equal(filters.mdct_window(capi.MDCT_SINE, n), d[f"sine_{n}"])
+        assert np.array_equal(filters.mdct_window(capi.MDCT_KBD, n), d[f"kbd_{n}"])
+        x = d[f"x_{n}"]
+        for t in (capi.MDCT_ORIGIN, capi.MDCT_FFT, capi.MDCT_FFT4):
+            if t == capi.MDCT_ORIGIN and n > 256:
+                continue
+            m = filters.Mdct(t, n)
+            X = m.forward(x)
+            assert np.array_equal(X, d[f"mdct{t}_{n}"]), (n, t)
+            assert np.array_equal(m.inverse(X), d[f"imdct{t}_{n}"]), (n, t)
+            m.close()
+    for frame_len, win in ((8, 0), (64, 1), (512, 0)):
+        x = d[f"fx_{frame_len}_{win}"]
+        a, s = filters.AnalysisMdct(frame_len, win), filters.SynthesisMdct(frame_len, win)
+        for f in range(len(x) // frame_len):
+            X = a.frame(x[f * frame_len:(f + 1) * frame_len])
+            assert np.array_equal(X, d[f"fX_{frame_len}_{win}"][f])
+            assert np.array_equal(s.frame(X), d[f"fy_{frame_len}_{win}"][f * frame_len:(f + 1) * frame_len])
+        a.close()
+        s.close()
+    with pytest.raises(capi.LlzError):
+        filters.Mdct(capi.MDCT_ORIGIN, 4096)                            # the O(N^2) type is capped at 2048
+    with pytest.raises(capi.LlzError):
+        filters.Mdct(5, 64)
+
+
+@pytest.mark.parametrize("n,count", [(32, 5), (64, 1000), (256, 33), (2048, 9), (8192, 3)])
+def test_mdct_batch_vs_oracle(dev, oracle, n, count):
+    rng = np.random.default_rng(n + count)
+    x = rng.uniform(-1, 1, (count, n)).astype(np.float32)
+    uniq = min(count, 6)
+    ref = np.stack([oracle.mdct(2, row.astype(np.float64)) for row in x[:uniq]])
+    m = filters.MdctBatch(n)
+    xd = torch.from_numpy(x).to(dev)
+    Xd = torch.empty(count, n // 2, dtype=torch.float32, device=dev)
+    m.forward(xd, Xd)
+    got = Xd.cpu().numpy()
+    scale = float(np.sqrt(np.mean(ref ** 2)))
+    err = float(np.sqrt(np.mean((got[:uniq] - ref) ** 2)))
+    assert err / scale <= TOL, (err, scale)
+    # inverse of the oracle's coefficients, and the frames beyond the checked ones through the round trip property:
+    # imdct(mdct(x)) is x plus its time-domain alias, i.e. a fixed linear map -> compare against the oracle on a few rows
+    Xin = torch.from_numpy(ref.astype(np.float32)).to(dev)
+    xo = torch.empty(uniq, n, dtype=torch.float32, device=dev)
+    m.inverse(Xin, xo)
+    ref_x = np.stack([oracle.imdct(2, row.astype(np.float32)) for row in ref])
+    rms_check(xo.cpu().numpy(), ref_x, f"imdct batch n={n}")
+    # every frame: the same map applied to all rows (rows are independent)
+    full = torch.empty(count, n, dtype=torch.float32, device=dev)
+    m.inverse(Xd, full)
+    y = full.cpu().numpy()
+    alias = np.concatenate([x[:, :n // 2] - x[:, n // 2 - 1::-1][:, :n // 2], x[:, n // 2:] + x[:, :n // 2 - 1:-1]], axis=1)
+    assert np.abs(y - alias).max() <= 2e-5 * max(1.0, np.abs(alias).max()), "imdct(mdct(x)) must be x with its time alias"
+    # host buffers
+    Xh = np.zeros((count, n // 2), dtype=np.float32)
+    m.forward(x, Xh)
+    assert np.array_equal(Xh, got)
+    m.close()

@@ -255,3 +255,23 @@ def test_stft_frames(oracle):
         assert same(re, d["re_" + key]) and same(im, d["im_" + key])
         assert re.shape[1] == (frame_len << (2 if hint == 0 else 1)) // 2 + 1
         assert same(oracle.stft_synthesis(hint, frame_len, win, re, im), d["syn_" + key])
+
+
+def test_mdct(oracle):
+    """llz_mdct.c: both windows, the three algorithms forward and inverse, and the TDAC frames of llz_asmodel.c:313-463,
+    identical to the compiled reference"""
+    d = load("mdct.npz")
+    for n in (16, 64, 256, 2048):
+        assert same(oracle.mdct_window(0, n), d[f"sine_{n}"]) and same(oracle.mdct_window(1, n), d[f"kbd_{n}"])
+        x = d[f"x_{n}"]
+        for t in (0, 1, 2):
+            if t == 0 and n > 256:
+                continue
+            X = oracle.mdct(t, x)
+            assert same(X, d[f"mdct{t}_{n}"]) and same(oracle.imdct(t, X), d[f"imdct{t}_{n}"]), (n, t)
+    for frame_len, win in ((8, 0), (64, 1), (512, 0)):
+        x = d[f"fx_{frame_len}_{win}"]
+        X, y = oracle.mdct_frames(frame_len, win, x)
+        assert same(X, d[f"fX_{frame_len}_{win}"]) and same(y, d[f"fy_{frame_len}_{win}"])
+        # time-domain alias cancellation: the input comes back one frame late
+        assert np.abs(y[frame_len:] - x[:-frame_len]).max() < 1e-13

@@ -31,7 +31,7 @@ def timeit(fn, steps):
     return ms
 
 
-which = sys.argv[1:] or ["iir", "resample", "fir63", "td257", "fft", "corr", "pcm", "stft"]
+which = sys.argv[1:] or ["iir", "resample", "fir63", "td257", "fft", "corr", "pcm", "stft", "mdct"]
 if "iir" in which:
     for ch in (1024, 128):
         n = 1 << 20
@@ -163,3 +163,16 @@ if "stft" in which:
               f"{(4 * ch * n + spec) / ms_a / 1e6:.0f} GB/s, synthesis {ms_s:.3f} ms {(4 * ch * n + spec) / ms_s / 1e6:.0f} GB/s")
         q.close()
         del x, y, re, im
+
+if "mdct" in which:
+    for n, count in ((256, 1 << 20), (2048, 1 << 17), (8192, 1 << 15)):
+        x = torch.rand(count, n, dtype=torch.float32, device=dev) * 2 - 1
+        X = torch.empty(count, n // 2, dtype=torch.float32, device=dev)
+        q = filters.MdctBatch(n, stream=stream)
+        ms_f = timeit(lambda: q.forward(x, X), 5)
+        ms_i = timeit(lambda: q.inverse(X, x), 5)
+        gb = 6 * count * n
+        print(f"mdct N={n} x {count}: forward {ms_f:.3f} ms {gb / ms_f / 1e6:.0f} GB/s ({gb / ms_f / 1e6 / 80:.1f} %), "
+              f"inverse {ms_i:.3f} ms {gb / ms_i / 1e6:.0f} GB/s")
+        q.close()
+        del x, X
