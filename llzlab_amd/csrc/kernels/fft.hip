@@ -14,7 +14,9 @@
 // A workgroup holds 2048 points in LDS (one 2048/4096-point transform or several smaller ones); the log2 N radix-2
 // stages run as 1-3 passes of up to four stages fused in registers (16 elements per lane), a barrier between passes. Twiddle tables come from the host
 // (never recomputed on the device: SURVEY.md H4/H5).
+#include <stdlib.h>
 #include "fft_core.hpp"
+#include "fft32.hpp"
 
 namespace {
 
@@ -300,6 +302,41 @@ k_stft_synthesis_f32(const float *__restrict__ re, const float *__restrict__ im,
         for (int q = tid; q < keep; q += FFT_THREADS) ola_new[(size_t)c * keep + q] = carry[q];
 }
 
+// 1024-point float32 transforms, the overlap-save size: one HALF-WAVE per transform, two in-register 32-point passes and
+// one LDS transpose between them (fft32.hpp, the machinery of K4).  Input goes from HBM straight into registers (lane l
+// takes x[l + 32 j]: 256-byte runs) and the result straight back (X[l + 32 k2]), so a transform costs ~600 vector
+// instructions per lane pair instead of the ~1550 of the staged radix-2 passes, which are bound by instruction issue.
+template <bool INV>
+__global__ void __launch_bounds__(256)
+k_fft1024_f32(float *__restrict__ data, int count, const float *__restrict__ cs /* 1024 cos, then 1024 sin */)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    __shared__ float2 s_tw[1024];                                  // W_1024^(a*b) = exp(-2 pi j a b / 1024), [a][b]
+    __shared__ float bufs[8][OLS_XBUF];
+    const int tid = threadIdx.x, hw = tid >> 5, l5 = tid & 31;
+    for (int i = tid; i < 1024; i += 256) {
+        const int m = ((i >> 5) * (i & 31)) & 1023;
+        s_tw[i] = make_float2(cs[m], -cs[1024 + m]);
+    }
+    __syncthreads();
+    const long t = (long)blockIdx.x * 8 + hw;
+    if (t >= count) return;
+    f32x2 *g = reinterpret_cast<f32x2 *>(data) + t * 1024;
+    cf v[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        const f32x2 x = __builtin_nontemporal_load(&g[l5 + 32 * j]);
+        // the inverse divides by N on the way in, as llz_ifft does (llz_fft.c:187-195); 1/1024 is exact
+        v[j] = INV ? cf{x.x * (1.0f / 1024.0f), x.y * (1.0f / 1024.0f)} : cf{x.x, x.y};
+    }
+    fft32<INV>(v);                                                 // over j: v[q] = Y[k1 = brev5(q)] of column l5
+    transpose_twiddle<INV>(v, bufs[hw], s_tw, l5);                 // * W^(k1 * l5), then lane k1 holds row k1
+    fft32<INV>(v);                                                 // over the column index: v[q] = X[l5 + 32 brev5(q)]
+#pragma unroll
+    for (int q = 0; q < 32; q++)
+        __builtin_nontemporal_store((f32x2){v[q].x, v[q].y}, &g[l5 + 32 * brev5(q)]);
+}
+
 template <typename A>
 int launch_fft(typename A::data_t *data, int count, int size, const typename A::tw_t *cs, int inverse,
                void *stream, const char *name)
@@ -346,6 +383,17 @@ int launch_fft(typename A::data_t *data, int count, int size, const typename A::
 
 extern "C" int llzs_fft_f32(float *data, int count, int size, const float *cs, int inverse, void *stream)
 {
+    if (size == 1024 && data && cs && count >= 1 && !getenv("LLZ_FFT_GENERIC")) {
+        const unsigned blocks = (unsigned)((count + 7) / 8);
+        if (inverse)
+            hipLaunchKernelGGL(k_fft1024_f32<true>, dim3(blocks), dim3(256), 0, as_stream(stream),
+                               data, count, cs);
+        else
+            hipLaunchKernelGGL(k_fft1024_f32<false>, dim3(blocks), dim3(256), 0, as_stream(stream),
+                               data, count, cs);
+        LLZ_LAUNCH_CHECK("k_fft1024_f32");
+        return LLZ_OK;
+    }
     return launch_fft<arith_f32>(data, count, size, cs, inverse, stream, "k_fft_radix2<f32>");
 }
 
