@@ -91,6 +91,62 @@ k_resample(const T *__restrict__ in, T *__restrict__ out, const T *__restrict__ 
     out[(size_t)c * out_pitch + i] = rs_finish(acc, gain, (T *)nullptr);
 }
 
+// int16 in/out, the reference's arithmetic (llz_resample.c:583-603) with the per-tap overhead taken out: the input span
+// is converted to double ONCE while it is staged in LDS (the int16 -> double conversion is exact, so converting before
+// or after the LDS round trip gives the same operand), and for L = 1 every lane uses the same tap row, which the
+// compiler then fetches through the scalar cache (the multiply takes the tap from an SGPR pair).  Per tap that leaves
+// ds_read_b64 + v_mul_f64 + v_add_f64 instead of ds_read_i16 + v_cvt_f64_i32 + a vector tap load + mul + add.
+// Products and sums are the reference's, in its order: rounded multiply, rounded add, ascending k.
+template <bool UNIFORM_TAPS>
+__global__ void __launch_bounds__(RS_THREADS)
+k_resample_i16_exact(const short *__restrict__ in, short *__restrict__ out, const short *__restrict__ hist,
+                     const double *__restrict__ g, long n_in, long n_out, long in_pitch, long out_pitch, int L, int M,
+                     int Q, double gain, long long i0, long long in0)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double *xs = reinterpret_cast<double *>(smem_raw);
+    const int c = blockIdx.y;
+    const long o0 = (long)blockIdx.x * RS_THREADS;
+    const long olast = min(o0 + RS_THREADS, n_out) - 1;
+    const long pos_first = (long)(((i0 + o0) * M) / L - in0);
+    const long pos_last = (long)(((i0 + olast) * M) / L - in0);
+    const long base = pos_first - (Q - 1);
+    const int span = (int)(pos_last - base + 1);
+    const short *row = in + (size_t)c * in_pitch;
+    const short *hrow = hist ? hist + (size_t)c * (Q - 1) : nullptr;
+    for (int p = threadIdx.x; p < span; p += RS_THREADS) {
+        const long idx = base + p;
+        short v = 0;
+        if (idx >= 0) {
+            if (idx < n_in) v = row[idx];
+        } else if (hrow && idx >= -(long)(Q - 1)) {
+            v = hrow[(Q - 1) + idx];
+        }
+        xs[p] = (double)v;
+    }
+    __syncthreads();
+    const long i = o0 + threadIdx.x;
+    if (i >= n_out) return;
+    const long long gi = i0 + i;
+    const double *xp = xs + (int)((gi * M) / L - in0 - base);          // x[(gi*M)/L]; taps walk backwards from here
+    const double *grow = UNIFORM_TAPS ? g : g + (size_t)(gi % L) * Q;
+    double acc = 0;
+    int k = 0;
+    for (; k + 8 <= Q; k += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const double prod = xp[-(k + u)] * grow[k + u];
+            acc = acc + prod;
+        }
+    }
+    for (; k < Q; k++) {
+        const double prod = xp[-k] * grow[k];
+        acc = acc + prod;
+    }
+    out[(size_t)c * out_pitch + i] = rs_finish(acc, gain, (short *)nullptr);
+}
+
 // history update for int16 (float uses k_fir_tail_f32): hist_new = last `keep` of concat(hist_old, in[0:n])
 __global__ void __launch_bounds__(256)
 k_tail_i16(const short *__restrict__ in, const short *__restrict__ hist_old, short *__restrict__ hist_new, long n,
@@ -306,8 +362,32 @@ extern "C" int llzs_resample_i16(const short *in, short *out, const short *hist,
                                  long n_in, long n_out, long in_pitch, long out_pitch, int L, int M, int Q,
                                  double gain, long long i0, long long in0, void *stream)
 {
-    return launch_resample<short>(in, out, hist, g, channels, n_in, n_out, in_pitch, out_pitch, L, M, Q, gain, i0,
-                                  in0, stream, "k_resample<short>");
+    if (!in || !out || !g || channels <= 0 || channels > 65535 || n_in <= 0 || n_out <= 0 || L < 1 || M < 1 ||
+        Q < 1 || in_pitch < n_in || out_pitch < n_out) {
+        llzs_set_error("k_resample_i16_exact: bad arguments");
+        return LLZ_ERR_ARG;
+    }
+    const int span_max = (int)((255L * M + L - 1) / L) + 1 + Q;
+    const size_t lds = (size_t)span_max * sizeof(double);
+    if (lds > 160 * 1024)                                           // very long spans: the int16-staged kernel
+        return launch_resample<short>(in, out, hist, g, channels, n_in, n_out, in_pitch, out_pitch, L, M, Q, gain, i0,
+                                      in0, stream, "k_resample<short>");
+    dim3 grid((unsigned)((n_out + RS_THREADS - 1) / RS_THREADS), (unsigned)channels);
+    if (L == 1) {
+        if (lds > 64 * 1024)
+            LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resample_i16_exact<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_resample_i16_exact<true>, grid, dim3(RS_THREADS), lds, as_stream(stream), in, out, hist, g,
+                           n_in, n_out, in_pitch, out_pitch, L, M, Q, gain, i0, in0);
+    } else {
+        if (lds > 64 * 1024)
+            LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resample_i16_exact<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_resample_i16_exact<false>, grid, dim3(RS_THREADS), lds, as_stream(stream), in, out, hist, g,
+                           n_in, n_out, in_pitch, out_pitch, L, M, Q, gain, i0, in0);
+    }
+    LLZ_LAUNCH_CHECK("k_resample_i16_exact");
+    return LLZ_OK;
 }
 
 extern "C" int llzs_tail_i16(const short *in, const short *hist_old, short *hist_new, int channels, long n,
