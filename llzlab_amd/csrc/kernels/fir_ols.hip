@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(OLS_THREADS)
 k_fir_ols_walk_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
                    const float2 *__restrict__ hfreq, const float2 *__restrict__ twid, int channels, int n,
                    long in_pitch, long out_pitch, int flt_len, int jobs_per_channel, int segs_per_channel,
-                   long total_segs)
+                   long total_segs, int seg_len)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *s_tw = reinterpret_cast<float2 *>(smem);
@@ -333,8 +333,8 @@ k_fir_ols_walk_f32(const float *__restrict__ in, float *__restrict__ out, const 
         const long seg = sp + half;
         const bool seg_live = seg < total_segs;
         const int c = seg_live ? (int)(seg / segs_per_channel) : 0;
-        const int j0 = seg_live ? (int)(seg - (long)c * segs_per_channel) * OLS_SEG : 0;
-        const int jcount = seg_live ? min(OLS_SEG, jobs_per_channel - j0) : 0;
+        const int j0 = seg_live ? (int)(seg - (long)c * segs_per_channel) * seg_len : 0;
+        const int jcount = seg_live ? min(seg_len, jobs_per_channel - j0) : 0;
         const float *row = in + (size_t)c * in_pitch;
         float *orow = out + (size_t)c * out_pitch;
         const float *hrow = hist ? hist + (size_t)c * keep : nullptr;
@@ -345,7 +345,7 @@ k_fir_ols_walk_f32(const float *__restrict__ in, float *__restrict__ out, const 
         if (PREFETCH) walk_load(raw, row, j0 * OLS_JOB, l5, n, jcount > 0);
 
 #pragma unroll 1
-        for (int jj = 0; jj < OLS_SEG; jj++) {
+        for (int jj = 0; jj < seg_len; jj++) {
             const int s = (j0 + jj) * OLS_JOB;
             const bool live = jj < jcount;
             if (!__any(live)) break;
@@ -411,18 +411,29 @@ extern "C" int llzs_fir_ols_f32(const float *in, float *out, const float *hist, 
     const long max_blocks = 256L * per_cu;       // one resident set of workgroups, grid stride over the work list
     const float2 *hf = reinterpret_cast<const float2 *>(hfreq), *tw = reinterpret_cast<const float2 *>(twid);
     if (variant >= 2) {
-        const int segs_per_channel = (jobs_per_channel + OLS_SEG - 1) / OLS_SEG;
+        // jobs per segment: a half-wave walks seg_len consecutive jobs of one channel (the overlap stays in registers), at
+        // most OLS_SEG.  Small batches (BASELINE config 2: 64 channels) would leave half-wave slots idle or quantise badly
+        // into rounds with the full length, so take the length that minimises rounds x (length + halo reload)
+        const long slots = max_blocks * OLS_WAVES * 2;
+        int seg_len = OLS_SEG;
+        double best = 1e300;
+        for (int sl = OLS_SEG; sl >= 1; sl--) {
+            const long segs = (long)((jobs_per_channel + sl - 1) / sl) * channels;
+            const double cost = (double)((segs + slots - 1) / slots) * (sl + 0.17);
+            if (cost < best * 0.999) { best = cost; seg_len = sl; }
+        }
+        const int segs_per_channel = (jobs_per_channel + seg_len - 1) / seg_len;
         const long total_segs = (long)segs_per_channel * channels;
         blocks = (total_segs + 2 * OLS_WAVES - 1) / (2 * OLS_WAVES);
         if (blocks > max_blocks) blocks = max_blocks;
         if (prefetch)
             hipLaunchKernelGGL(k_fir_ols_walk_f32<true>, dim3((unsigned)blocks), dim3(OLS_THREADS), lds_bytes,
                                as_stream(stream), in, out, hist, hf, tw, channels, n, in_pitch, out_pitch, flt_len,
-                               jobs_per_channel, segs_per_channel, total_segs);
+                               jobs_per_channel, segs_per_channel, total_segs, seg_len);
         else
             hipLaunchKernelGGL(k_fir_ols_walk_f32<false>, dim3((unsigned)blocks), dim3(OLS_THREADS), lds_bytes,
                                as_stream(stream), in, out, hist, hf, tw, channels, n, in_pitch, out_pitch, flt_len,
-                               jobs_per_channel, segs_per_channel, total_segs);
+                               jobs_per_channel, segs_per_channel, total_segs, seg_len);
         LLZ_LAUNCH_CHECK("k_fir_ols_walk_f32");
         return LLZ_OK;
     }
