@@ -6,7 +6,7 @@
  *         reference's operation order, the twiddle steps on the host in the reference's statement order:
  *         bit-identical results for all three algorithms.
  * Part 2: many frames per call, float32, the N/4-point-FFT algorithm.
- * The fixed-point variant (reference llz_mdct_fixed.c) is not built yet.
+ * The fixed-point variant (reference llz_mdct_fixed.c) is in llz_mdct_fixed.h.
  */
 #ifndef LLZ_MDCT_H
 #define LLZ_MDCT_H

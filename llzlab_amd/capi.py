@@ -212,6 +212,12 @@ def lib():
     sig("llz_mdct_batch_set_stream", i, ul, vp)
     sig("llz_mdct_batch", i, ul, vp, vp, i)
     sig("llz_imdct_batch", i, ul, vp, vp, i)
+    # llz_mdct_fixed.h
+    ip = C.POINTER(C.c_int)
+    sig("llz_mdct_fixed_init", ul, i, i)
+    sig("llz_mdct_fixed_uninit", None, ul)
+    sig("llz_mdct_fixed", None, ul, ip, ip)
+    sig("llz_imdct_fixed", None, ul, ip, ip)
     # llz_pcm.h
     sig("llz_pcm_deinterleave_i16_f32", i, vp, vp, i, lng, C.c_float, vp)
     sig("llz_pcm_interleave_f32_i16", i, vp, vp, i, lng, C.c_float, vp)

@@ -26,6 +26,19 @@ k_matvec_exact_f64(const double *__restrict__ A, const double *__restrict__ x, d
     y[r] = acc;
 }
 
+// y[r] = sum_c (int)(((int64)x[c] * A[r][c]) >> 15) with wrapping int32 adds: the defining sums of MDCT_FIXED_ORIGIN
+// (llz_mdct_fixed.c:116-152).  Integer adds are associative modulo 2^32, so any order is the reference's result.
+__global__ void __launch_bounds__(256)
+k_matvec_q15(const short *__restrict__ A, const int *__restrict__ x, int *__restrict__ y, int rows, int cols)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const short *row = A + (size_t)r * cols;
+    unsigned acc = 0;
+    for (int c = 0; c < cols; c++) acc += (unsigned)(int)(((long long)x[c] * (long long)row[c]) >> 15);
+    y[r] = (int)acc;
+}
+
 // One workgroup transforms tpw frames of length N (N4 = N/4 complex points each).
 //   forward: in = x [count][N], out = X [count][N/2];   inverse: in = X [count][N/2], out = x [count][N]
 // tc/ts: cos and sin of -2 pi (k + 1/8) / N, k < N/4 (llz_mdct.c:459-462); cs: FFT table of size N/4.
@@ -115,6 +128,18 @@ extern "C" int llzs_matvec_exact_f64(const double *A, const double *x, double *y
     hipLaunchKernelGGL(k_matvec_exact_f64, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream), A, x, y,
                        rows, cols);
     LLZ_LAUNCH_CHECK("k_matvec_exact_f64");
+    return LLZ_OK;
+}
+
+extern "C" int llzs_matvec_q15(const short *A, const int *x, int *y, int rows, int cols, void *stream)
+{
+    if (!A || !x || !y || rows < 1 || cols < 1) {
+        llzs_set_error("matvec_q15: bad arguments");
+        return LLZ_ERR_ARG;
+    }
+    hipLaunchKernelGGL(k_matvec_q15, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream), A, x, y, rows,
+                       cols);
+    LLZ_LAUNCH_CHECK("k_matvec_q15");
     return LLZ_OK;
 }
 

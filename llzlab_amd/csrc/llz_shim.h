@@ -124,6 +124,8 @@ int llzs_stft_synthesis_f32(const float *re, const float *im, float *x, const fl
 
 /* MDCT (llz_mdct.c): y[r] = sum_c x[c]*A[r][c] in ascending c, separately rounded multiply and add (device doubles) */
 int llzs_matvec_exact_f64(const double *A, const double *x, double *y, int rows, int cols, void *stream);
+/* y[r] = sum_c (int)(((int64)x[c]*A[r][c]) >> 15), wrapping adds (llz_mdct_fixed.c:116-152) */
+int llzs_matvec_q15(const short *A, const int *x, int *y, int rows, int cols, void *stream);
 /* N/4-point-FFT MDCT / IMDCT of `count` float32 frames: forward [count][N] -> [count][N/2], inverse the other way;
  * tc/ts: cos/sin of -2*pi*(k+1/8)/N, k < N/4; cs: cos then sin of 2*pi*i/(N/4) */
 int llzs_mdct4_f32(const float *in, float *out, int count, int N, const float *tc, const float *ts, const float *cs,

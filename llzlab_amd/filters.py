@@ -551,6 +551,35 @@ class Mdct:
     __del__ = close
 
 
+class MdctFixed:
+    """llz_mdct_fixed_init / llz_mdct_fixed / llz_imdct_fixed (llz_mdct_fixed.h:24-28): host int32, bit-exact."""
+
+    def __init__(self, type_, length):
+        self._L = capi.lib()
+        self.handle = check_handle(self._L.llz_mdct_fixed_init(type_, length), "llz_mdct_fixed_init")
+        self.length = length
+
+    def _run(self, fn, a, n_out):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        b = np.zeros(n_out, dtype=np.int32)
+        ip = C.POINTER(C.c_int)
+        fn(self.handle, a.ctypes.data_as(ip), b.ctypes.data_as(ip))
+        return b
+
+    def forward(self, x):
+        return self._run(self._L.llz_mdct_fixed, x, self.length // 2)
+
+    def inverse(self, X):
+        return self._run(self._L.llz_imdct_fixed, X, self.length)
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            self._L.llz_mdct_fixed_uninit(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
 class _MdctFrames:
     _init = _uninit = _run = None
 

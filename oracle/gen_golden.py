@@ -212,6 +212,15 @@ def main():
             X = r.mdct(t, x)
             d[f"mdct{t}_{n}"] = X
             d[f"imdct{t}_{n}"] = r.imdct(t, X)
+    for n in (16, 64, 256, 2048):
+        xi = g.integers(-20000, 20001, n).astype(np.int32)
+        d[f"xi_{n}"] = xi
+        for t in (0, 1, 2):
+            if t == 0 and n > 256:
+                continue
+            Xi = r.mdct_fixed(t, xi)
+            d[f"mdctx{t}_{n}"] = Xi
+            d[f"imdctx{t}_{n}"] = r.mdct_fixed(t, Xi, inverse=True)
     for frame_len, win in ((8, 0), (64, 1), (512, 0)):
         x = g.uniform(-1, 1, frame_len * 6).astype(np.float32).astype(np.float64)
         X, y = r.mdct_frames(frame_len, win, x)

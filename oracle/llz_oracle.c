@@ -1022,6 +1022,174 @@ void orc_mdct_free(void *p)
     free(f->tw_c); free(f->tw_s); free(f->rot); free(f);
 }
 
+/* fixed-point MDCT, reference libllzfilter/llz_mdct_fixed.c:116-392: the float algorithms with Q15 tables
+ * (q15() above = LLZ_FIX15) and (int64 a * b) >> 15 products (mul15() above = LLZ_FIXMUL_32X15); int32 adds wrap */
+typedef struct {
+    int type, length;
+    void *fft;
+    int *fft_buf, *rot;
+    short *cos_pos, *cos_inv;
+    short *pre_c_pos, *pre_s_pos, *c_pos, *s_pos, *pre_c_inv, *pre_s_inv, *c_inv, *s_inv;
+    short *tw_c, *tw_s, sqrt_cof;
+} orc_mdctx_t;
+
+static inline int wneg(int a) { return (int)(0u - (unsigned)a); }
+static inline int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+
+void *orc_mdctx_new(int type, int size)
+{
+    orc_mdctx_t *f = (orc_mdctx_t *)calloc(1, sizeof(*f));
+    int base = (int)(log(size) / log(2));
+    if ((1 << base) < size) base += 1;
+    const int length = 1 << base;
+    f->length = length; f->type = type;
+    if (type == 0) {                                    /* llz_mdct_fixed.c:307-325 */
+        f->cos_pos = (short *)calloc((size_t)(length >> 1) * length, sizeof(short));
+        f->cos_inv = (short *)calloc((size_t)length * (length >> 1), sizeof(short));
+        for (int k = 0; k < (length >> 1); k++)
+            for (int n = 0; n < length; n++) {
+                const double tmp = (M_PI / (2 * length)) * (2 * n + 1 + (length >> 1)) * (2 * k + 1);
+                f->cos_pos[(size_t)k * length + n] = f->cos_inv[(size_t)n * (length >> 1) + k] = q15(cos(tmp));
+            }
+    } else if (type == 1) {                             /* llz_mdct_fixed.c:326-367 */
+        const double n0 = ((double)length / 2 + 1) / 2;
+        f->fft = orc_fftx_new(length);
+        f->fft_buf = (int *)calloc(2 * (size_t)length, sizeof(int));
+        f->pre_c_pos = (short *)malloc(sizeof(short) * length); f->pre_s_pos = (short *)malloc(sizeof(short) * length);
+        f->c_pos = (short *)malloc(sizeof(short) * (length >> 1)); f->s_pos = (short *)malloc(sizeof(short) * (length >> 1));
+        f->pre_c_inv = (short *)malloc(sizeof(short) * length); f->pre_s_inv = (short *)malloc(sizeof(short) * length);
+        f->c_inv = (short *)malloc(sizeof(short) * length); f->s_inv = (short *)malloc(sizeof(short) * length);
+        for (int k = 0; k < length; k++) {
+            f->pre_c_pos[k] = q15(cos(-(M_PI * k) / length));
+            f->pre_s_pos[k] = q15(sin(-(M_PI * k) / length));
+        }
+        for (int k = 0; k < (length >> 1); k++) {
+            f->c_pos[k] = q15(cos(-2 * M_PI * n0 * (k + 0.5) / length));
+            f->s_pos[k] = q15(sin(-2 * M_PI * n0 * (k + 0.5) / length));
+        }
+        for (int k = 0; k < length; k++) {
+            f->pre_c_inv[k] = q15(cos((2 * M_PI * k * n0) / length));
+            f->pre_s_inv[k] = q15(sin((2 * M_PI * k * n0) / length));
+        }
+        for (int k = 0; k < length; k++) {
+            f->c_inv[k] = q15(cos(M_PI * (k + n0) / length));
+            f->s_inv[k] = q15(sin(M_PI * (k + n0) / length));
+        }
+    } else {                                            /* llz_mdct_fixed.c:368-387 */
+        f->fft = orc_fftx_new(length >> 2);
+        f->fft_buf = (int *)calloc((size_t)(length >> 1), sizeof(int));
+        f->sqrt_cof = q15(1. / sqrt(length));
+        f->rot = (int *)calloc((size_t)length, sizeof(int));
+        f->tw_c = (short *)malloc(sizeof(short) * (length >> 2));
+        f->tw_s = (short *)malloc(sizeof(short) * (length >> 2));
+        for (int k = 0; k < (length >> 2); k++) {
+            f->tw_c[k] = q15(cos(-2 * M_PI * (k + 0.125) / length));
+            f->tw_s[k] = q15(sin(-2 * M_PI * (k + 0.125) / length));
+        }
+    }
+    return f;
+}
+
+int orc_mdctx_length(void *p) { return ((orc_mdctx_t *)p)->length; }
+
+void orc_mdctx_fwd(void *p, const int *x, int *X)
+{
+    orc_mdctx_t *f = (orc_mdctx_t *)p;
+    const int N = f->length, N2 = N >> 1, N4 = N >> 2;
+    if (f->type == 0) {                                 /* llz_mdct_fixed.c:116-133 */
+        for (int k = 0; k < N2; k++) {
+            int Xk = 0;
+            for (int n = 0; n < N; n++) Xk = wadd(Xk, mul15(x[n], f->cos_pos[(size_t)k * N + n]));
+            X[k] = Xk;
+        }
+    } else if (f->type == 1) {                          /* llz_mdct_fixed.c:155-172 */
+        for (int k = 0; k < N; k++) {
+            f->fft_buf[k + k] = mul15(x[k], f->pre_c_pos[k]);
+            f->fft_buf[k + k + 1] = mul15(x[k], f->pre_s_pos[k]);
+        }
+        orc_fftx_fwd(f->fft, f->fft_buf);
+        for (int k = 0; k < N2; k++)
+            X[k] = wsub(mul15(f->fft_buf[k + k], f->c_pos[k]), mul15(f->fft_buf[k + k + 1], f->s_pos[k]));
+    } else {                                            /* llz_mdct_fixed.c:197-233 */
+        int *rot = f->rot;
+        memset(rot, 0, sizeof(int) * (size_t)f->length);
+        for (int k = 0; k < N4; k++) rot[k] = wneg(x[k + 3 * N4]);
+        for (int k = N4; k < N; k++) rot[k] = x[k - N4];
+        for (int k = 0; k < N4; k++) {
+            const int re = wsub(rot[2 * k], rot[N - 1 - 2 * k]);
+            const int im = wsub(rot[N2 - 1 - 2 * k], rot[N2 + 2 * k]);
+            f->fft_buf[k + k] = wsub(mul15(re, f->tw_c[k]), mul15(im, f->tw_s[k])) >> 1;
+            f->fft_buf[k + k + 1] = wadd(mul15(re, f->tw_s[k]), mul15(im, f->tw_c[k])) >> 1;
+        }
+        orc_fftx_fwd(f->fft, f->fft_buf);
+        for (int k = 0; k < N4; k++) {
+            const int re = f->fft_buf[k + k], im = f->fft_buf[k + k + 1];
+            X[2 * k] = wmul(2, wsub(mul15(re, f->tw_c[k]), mul15(im, f->tw_s[k])));
+            X[N2 - 1 - 2 * k] = wmul(-2, wadd(mul15(re, f->tw_s[k]), mul15(im, f->tw_c[k])));
+        }
+    }
+}
+
+void orc_mdctx_inv(void *p, const int *X, int *x)
+{
+    orc_mdctx_t *f = (orc_mdctx_t *)p;
+    const int N = f->length, N2 = N >> 1, N4 = N >> 2;
+    if (f->type == 0) {                                 /* llz_mdct_fixed.c:135-152 */
+        for (int n = 0; n < N; n++) {
+            int xn = 0;
+            for (int k = 0; k < N2; k++) xn = wadd(xn, mul15(X[k], f->cos_inv[(size_t)n * N2 + k]));
+            x[n] = wmul(xn, 4) / N;
+        }
+    } else if (f->type == 1) {                          /* llz_mdct_fixed.c:174-195 */
+        for (int k = 0; k < N2; k++) {
+            f->fft_buf[k + k] = mul15(X[k], f->pre_c_inv[k]);
+            f->fft_buf[k + k + 1] = mul15(X[k], f->pre_s_inv[k]);
+        }
+        for (int k = N2, i = N2 - 1; k < N; k++, i--) {
+            f->fft_buf[k + k] = mul15(wneg(X[i]), f->pre_c_inv[k]);
+            f->fft_buf[k + k + 1] = mul15(wneg(X[i]), f->pre_s_inv[k]);
+        }
+        orc_fftx_inv(f->fft, f->fft_buf);
+        for (int k = 0; k < N; k++)
+            x[k] = (int)((unsigned)wsub(mul15(f->fft_buf[k + k], f->c_inv[k]), mul15(f->fft_buf[k + k + 1], f->s_inv[k])) << 1);
+    } else {                                            /* llz_mdct_fixed.c:235-283 */
+        int *rot = f->rot;
+        const short cof = f->sqrt_cof;
+        memset(rot, 0, sizeof(int) * (size_t)f->length);
+        for (int k = 0; k < N4; k++) {
+            const int re = X[2 * k], im = X[N2 - 1 - 2 * k];
+            f->fft_buf[k + k] = wsub(mul15(re, f->tw_c[k]), mul15(im, f->tw_s[k])) >> 1;
+            f->fft_buf[k + k + 1] = wadd(mul15(re, f->tw_s[k]), mul15(im, f->tw_c[k])) >> 1;
+        }
+        orc_fftx_fwd(f->fft, f->fft_buf);
+        for (int k = 0; k < N4; k++) {
+            const int re = f->fft_buf[k + k], im = f->fft_buf[k + k + 1];
+            int tmp = wsub(mul15(re, f->tw_c[k]), mul15(im, f->tw_s[k]));
+            f->fft_buf[k + k] = wmul(8, mul15(tmp, cof));
+            tmp = wadd(mul15(re, f->tw_s[k]), mul15(im, f->tw_c[k]));
+            f->fft_buf[k + k + 1] = wmul(8, mul15(tmp, cof));
+        }
+        for (int k = 0; k < N4; k++) {
+            rot[2 * k] = f->fft_buf[k + k];
+            rot[N2 + 2 * k] = f->fft_buf[k + k + 1];
+        }
+        for (int k = 1; k < N; k += 2) rot[k] = wneg(rot[N - 1 - k]);
+        for (int k = 0; k < 3 * N4; k++) x[k] = mul15(rot[N4 + k], cof);
+        for (int k = 3 * N4; k < N; k++) x[k] = mul15(wneg(rot[k - 3 * N4]), cof);
+    }
+}
+
+void orc_mdctx_free(void *p)
+{
+    orc_mdctx_t *f = (orc_mdctx_t *)p;
+    if (!f) return;
+    if (f->fft) orc_fftx_free(f->fft);
+    free(f->fft_buf); free(f->rot); free(f->cos_pos); free(f->cos_inv);
+    free(f->pre_c_pos); free(f->pre_s_pos); free(f->c_pos); free(f->s_pos);
+    free(f->pre_c_inv); free(f->pre_s_inv); free(f->c_inv); free(f->s_inv);
+    free(f->tw_c); free(f->tw_s); free(f);
+}
+
 /* analysis / synthesis by windowed MDCT frames with 50 % overlap (TDAC), reference llz_asmodel.c:313-463; the
  * transform is always type 2 (MDCT_FFT4) of length 2*frame_len; win 0 = sine, 1 = KBD with alpha 6 */
 typedef struct {

@@ -106,6 +106,13 @@ void   orc_mdct_fwd(void *h, const double *x, double *X);          /* x: length,
 void   orc_mdct_inv(void *h, const double *X, double *x);
 void   orc_mdct_free(void *h);
 
+/* fixed-point MDCT (int32 data, Q15 tables), reference libllzfilter/llz_mdct_fixed.c:116-392; types as above */
+void  *orc_mdctx_new(int type, int size);
+int    orc_mdctx_length(void *h);
+void   orc_mdctx_fwd(void *h, const int *x, int *X);
+void   orc_mdctx_inv(void *h, const int *X, int *x);
+void   orc_mdctx_free(void *h);
+
 /* windowed MDCT frames with 50 % overlap (TDAC), reference llz_asmodel.c:313-463; win 0 = sine, 1 = KBD(alpha 6) */
 void  *orc_amdct_new(int frame_len, int win);
 void   orc_amdct_analysis(void *h, const double *x, double *X);    /* x: frame_len in, X: frame_len coefficients */

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(L):
 
 
 def test_headers_cite_reference_lines():
-    for fn in ("llz_fir.h", "llz_iir.h", "llz_resample.h", "llz_fft.h", "llz_fft_fixed.h", "llz_corr.h", "llz_asmodel.h", "llz_mdct.h"):
+    for fn in ("llz_fir.h", "llz_iir.h", "llz_resample.h", "llz_fft.h", "llz_fft_fixed.h", "llz_corr.h", "llz_asmodel.h", "llz_mdct.h", "llz_mdct_fixed.h"):
         text = open(os.path.join(ROOT, "include", fn)).read()
         assert re.search(r"llz_\w+\.[ch]:\d+", text), fn + " must cite the reference interface it replaces"
 

@@ -636,6 +636,15 @@ def test_mdct_reference_symbols_exact(dev):
             assert np.array_equal(X, d[f"mdct{t}_{n}"]), (n, t)
             assert np.array_equal(m.inverse(X), d[f"imdct{t}_{n}"]), (n, t)
             m.close()
+        xi = d[f"xi_{n}"]
+        for t in (0, 1, 2):                                             # fixed point: int32 data, Q15 tables
+            if t == 0 and n > 256:
+                continue
+            m = filters.MdctFixed(t, n)
+            Xi = m.forward(xi)
+            assert np.array_equal(Xi, d[f"mdctx{t}_{n}"]), (n, t)
+            assert np.array_equal(m.inverse(Xi), d[f"imdctx{t}_{n}"]), (n, t)
+            m.close()
     for frame_len, win in ((8, 0), (64, 1), (512, 0)):
         x = d[f"fx_{frame_len}_{win}"]
         a, s = filters.AnalysisMdct(frame_len, win), filters.SynthesisMdct(frame_len, win)

@@ -269,6 +269,13 @@ def test_mdct(oracle):
                 continue
             X = oracle.mdct(t, x)
             assert same(X, d[f"mdct{t}_{n}"]) and same(oracle.imdct(t, X), d[f"imdct{t}_{n}"]), (n, t)
+        xi = d[f"xi_{n}"]
+        for t in (0, 1, 2):
+            if t == 0 and n > 256:
+                continue
+            Xi = oracle.mdct_fixed(t, xi)
+            assert np.array_equal(Xi, d[f"mdctx{t}_{n}"]), (n, t)
+            assert np.array_equal(oracle.mdct_fixed(t, Xi, inverse=True), d[f"imdctx{t}_{n}"]), (n, t)
     for frame_len, win in ((8, 0), (64, 1), (512, 0)):
         x = d[f"fx_{frame_len}_{win}"]
         X, y = oracle.mdct_frames(frame_len, win, x)
