@@ -283,7 +283,10 @@ def sharded_configs(torch, filters, capi, shard, dev, comm_dev, stream, rank, wo
     out["iir8_1024ch_sharded"] = {
         "Msamples_s": total_ch * n / ms / 1e3, "GBs_per_gpu": 8 * ch * n / ms / 1e6,
         "hbm_frac_per_gpu": 8 * ch * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "channels_per_gpu": ch,
-        "scaling": "strong"}
+        "scaling": "strong",
+        # the binding roof of this kernel is the FP64 vector pipe, not HBM: 7 DFMA per sample and section
+        "fp64_TFLOPs_per_gpu": 2 * 7 * 8 * ch * n / ms / 1e9, "fp64_peak_TFLOPs": 78.6,
+        "fp64_frac_per_gpu": 2 * 7 * 8 * ch * n / ms / 1e9 / 78.6}
     q.close()
     del x, y
     torch.cuda.empty_cache()
