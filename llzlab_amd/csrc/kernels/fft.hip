@@ -211,6 +211,50 @@ k_stft_analysis_f32(const float *__restrict__ x, const float *__restrict__ hist,
     }
 }
 
+// fft_len = 1024 analysis frames on the half-wave machinery of k_fft1024_f32: the windowed samples go from HBM straight
+// into registers (imaginary parts zero), bins 0..512 straight back; 8 frames per workgroup.
+__global__ void __launch_bounds__(256)
+k_stft_analysis1024_f32(const float *__restrict__ x, const float *__restrict__ hist, float *__restrict__ re,
+                        float *__restrict__ im, const float *__restrict__ w, int frames, int F,
+                        const float *__restrict__ cs, long x_pitch, long total_tr)
+{
+    __shared__ float2 s_tw[1024];
+    __shared__ float bufs[8][OLS_XBUF];
+    const int tid = threadIdx.x, hw = tid >> 5, l5 = tid & 31;
+    for (int i = tid; i < 1024; i += 256) {
+        const int m = ((i >> 5) * (i & 31)) & 1023;
+        s_tw[i] = make_float2(cs[m], -cs[1024 + m]);
+    }
+    __syncthreads();
+    const long g = (long)blockIdx.x * 8 + hw;
+    if (g >= total_tr) return;
+    const int c = (int)(g / frames), f = (int)(g - (long)c * frames);
+    const int keep = 1024 - F;
+    const long t0 = (long)(f + 1) * F - 1024;
+    const float *row = x + (size_t)c * x_pitch;
+    const float *hrow = hist + (size_t)c * keep;
+    cf v[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        const int i = l5 + 32 * j;
+        const long t = t0 + i;
+        const float smp = t >= 0 ? row[t] : hrow[keep + t];
+        v[j] = cf{smp * w[i], 0.f};
+    }
+    fft32<false>(v);
+    transpose_twiddle<false>(v, bufs[hw], s_tw, l5);
+    fft32<false>(v);
+    const size_t o = (size_t)g * 513;
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+        const int bin = l5 + 32 * brev5(q);                         // v[q] = X[l5 + 32 brev5(q)]
+        if (bin <= 512) {
+            re[o + bin] = v[q].x;
+            im[o + bin] = v[q].y;
+        }
+    }
+}
+
 // synthesis: a workgroup owns output blocks [b0, b1) of one channel.  Block t (frame_len samples) is the sum of the
 // windowed inverse transforms of frames t-R+1 .. t (llz_asmodel.c:279-304), so the workgroup walks frames
 // max(0, b0-R+1) .. b1-1 in groups of tpw, keeps the running overlap-add tail (size - F samples) in LDS and drops the
@@ -335,6 +379,84 @@ k_fft1024_f32(float *__restrict__ data, int count, const float *__restrict__ cs 
 #pragma unroll
     for (int q = 0; q < 32; q++)
         __builtin_nontemporal_store((f32x2){v[q].x, v[q].y}, &g[l5 + 32 * brev5(q)]);
+}
+
+// fft_len = 1024 synthesis: as k_stft_synthesis_f32, with the inverse transforms on the half-wave machinery (8 frames per
+// group, one per half-wave): bins from HBM straight into registers with the Hermitian upper half taken from the mirrored
+// bin, windowed real output written to an LDS segment image, then the same overlap-add walk.
+__global__ void __launch_bounds__(256)
+k_stft_synthesis1024_f32(const float *__restrict__ re, const float *__restrict__ im, float *__restrict__ x,
+                         const float *__restrict__ ola_old, float *__restrict__ ola_new, const float *__restrict__ w,
+                         int frames, int F, const float *__restrict__ cs, long x_pitch, int run_len, int runs, float magic)
+{
+    constexpr int N = 1024, TPW = 8;
+    __shared__ float2 s_tw[1024];
+    __shared__ float bufs[TPW][OLS_XBUF];
+    __shared__ float seg[TPW][N];
+    __shared__ float carry[N];                                         // N - F used
+    const int tid = threadIdx.x, hw = tid >> 5, l5 = tid & 31;
+    for (int i = tid; i < 1024; i += 256) {
+        const int m = ((i >> 5) * (i & 31)) & 1023;
+        s_tw[i] = make_float2(cs[m], -cs[1024 + m]);
+    }
+    const int c = blockIdx.x / runs, run = blockIdx.x - c * runs;
+    const int b0 = run * run_len, b1 = min(frames, b0 + run_len);
+    const int R = N / F, keep = N - F;
+    const int fs = max(0, b0 - (R - 1));
+    for (int q = tid; q < keep; q += 256) carry[q] = fs == 0 ? ola_old[(size_t)c * keep + q] : 0.f;
+    for (int g0 = fs; g0 < b1; g0 += TPW) {
+        const int ng = min(TPW, b1 - g0);
+        __syncthreads();                                               // carry and seg of the previous group are consumed
+        if (hw < ng) {
+            const size_t o = ((size_t)c * frames + g0 + hw) * 513;
+            cf v[32];
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                const int k = l5 + 32 * j;
+                const int kk = k <= 512 ? k : N - k;                   // upper half: conjugate of the mirrored bin
+                const float a = re[o + kk] * (1.0f / 1024.0f), b = im[o + kk] * (1.0f / 1024.0f);
+                v[j] = cf{a, k <= 512 ? b : -b};
+            }
+            fft32<true>(v);
+            transpose_twiddle<true>(v, bufs[hw], s_tw, l5);
+            fft32<true>(v);
+#pragma unroll
+            for (int q = 0; q < 32; q++) {
+                const int n = l5 + 32 * brev5(q);                      // v[q].x = real part of sample n
+                seg[hw][n] = v[q].x * w[n];
+            }
+        }
+        __syncthreads();
+        const int span = (ng - 1) * F + N;                             // <= 7*512 + 1024
+        float acc[18];
+#pragma unroll
+        for (int m = 0; m < 18; m++) {
+            const int p = tid + m * 256;
+            float a = 0.f;
+            if (p < span) {
+                a = p < keep ? carry[p] : 0.f;
+                const int k_hi = min(ng - 1, p / F);
+                const int k_lo = p < N ? 0 : (p - N) / F + 1;
+                for (int k = k_lo; k <= k_hi; k++) a += seg[k][p - k * F];
+            }
+            acc[m] = a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 18; m++) {
+            const int p = tid + m * 256;
+            if (p < span) {
+                if (p < ng * F) {
+                    if (g0 + p / F >= b0) x[(size_t)c * x_pitch + (size_t)g0 * F + p] = magic * acc[m];
+                } else {
+                    carry[p - ng * F] = acc[m];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (b1 == frames)
+        for (int q = tid; q < keep; q += 256) ola_new[(size_t)c * keep + q] = carry[q];
 }
 
 template <typename A>
@@ -477,6 +599,12 @@ extern "C" int llzs_stft_analysis_f32(const float *x, const float *hist, float *
     const int rc = stft_check(channels, frames, F, size, &log2n, "stft_analysis_f32");
     if (rc != LLZ_OK) return rc;
     const long total_tr = (long)channels * frames;
+    if (size == 1024 && !getenv("LLZ_FFT_GENERIC")) {
+        hipLaunchKernelGGL(k_stft_analysis1024_f32, dim3((unsigned)((total_tr + 7) / 8)), dim3(256), 0, as_stream(stream),
+                           x, hist, re, im, w, frames, F, cs, x_pitch, total_tr);
+        LLZ_LAUNCH_CHECK("k_stft_analysis1024_f32");
+        return LLZ_OK;
+    }
     int tpw = 2048 / size;
     if (tpw > total_tr) tpw = (int)total_tr;
     const int tstride = size + (size >> 5) + 1;
@@ -507,6 +635,16 @@ extern "C" int llzs_stft_synthesis_f32(const float *re, const float *im, float *
     int run_len = (int)(want < 8 * R ? 8 * R : want);
     if (run_len < tpw) run_len = tpw;
     if (run_len > frames) run_len = frames;
+    if (size == 1024 && !getenv("LLZ_FFT_GENERIC")) {
+        if (run_len < 8 * R) run_len = 8 * R;
+        if (run_len > frames) run_len = frames;
+        const int runs1k = (frames + run_len - 1) / run_len;
+        hipLaunchKernelGGL(k_stft_synthesis1024_f32, dim3((unsigned)((long)channels * runs1k)), dim3(256), 0,
+                           as_stream(stream), re, im, x, ola_old, ola_new, w, frames, F, cs, x_pitch, run_len, runs1k,
+                           magic);
+        LLZ_LAUNCH_CHECK("k_stft_synthesis1024_f32");
+        return LLZ_OK;
+    }
     const int runs = (frames + run_len - 1) / run_len;
     const int tstride = size + (size >> 5) + 1;
     const size_t lds = (size_t)tpw * tstride * 2 * sizeof(float) + (size_t)tw_entries(size) * 2 * sizeof(float) +
