@@ -459,6 +459,132 @@ k_stft_synthesis1024_f32(const float *__restrict__ re, const float *__restrict__
         for (int q = tid; q < keep; q += 256) ola_new[(size_t)c * keep + q] = carry[q];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Square sizes N = E*E beside 1024 (E = 16: N = 256, E = 64: N = 4096), float32: the same two-register-pass scheme as
+// k_fft1024_f32 with a group of E lanes per transform (a quarter wave / a whole wave), E elements per lane.
+// The E-point transform is the decimation-in-time form of fft32.hpp written for any E <= 64 (constants in 64ths of a
+// turn); the inter-pass twiddles W_N^(k1*l) come from a [E][E] table laid out so that a group reads a contiguous row.
+__device__ constexpr float kCos64[17] = {1.00000000000000000000f, 0.99518472667219692873f, 0.98078528040323043058f, 0.95694033573220882438f, 0.92387953251128673848f, 0.88192126434835504956f, 0.83146961230254523567f, 0.77301045336273699338f, 0.70710678118654757274f, 0.63439328416364548779f, 0.55557023301960228867f, 0.47139673682599780857f, 0.38268343236508983729f, 0.29028467725446233105f, 0.19509032201612833135f, 0.09801714032956077016f, 0.00000000000000006123f};
+
+template <int E>
+__device__ constexpr int brevE(int r)
+{
+    int o = 0;
+    for (int b = 1, t = E >> 1; b < E; b <<= 1, t >>= 1)
+        if (r & b) o |= t;
+    return o;
+}
+
+// (a, b) -> (a + w b, a - w b), w = W_E^q (conjugated for the inverse), 0 <= q < E/2, Linzer-Feig form as in fft32.hpp
+template <int E, bool INV>
+__device__ __forceinline__ void bfly_ditE(cf &a, cf &b, int q)
+{
+    const int q64 = q * (64 / E);                               // sixty-fourths of a turn, 0..31
+    const cf A = a, B = b;
+    if (q64 == 0) {
+        a = cadd(A, B); b = csub(A, B);
+        return;
+    }
+    if (q64 == 16) {
+        const cf wb = INV ? cf{-B.y, B.x} : cf{B.y, -B.x};
+        a = cadd(A, wb); b = csub(A, wb);
+        return;
+    }
+    const float c = q64 <= 16 ? kCos64[q64] : -kCos64[32 - q64];
+    const float s0 = q64 <= 16 ? kCos64[16 - q64] : kCos64[q64 - 16];
+    const float sn = INV ? s0 : -s0;
+    float p, g, f;
+    if (c >= s0 || -c >= s0) {
+        const float t = sn / c;
+        p = __builtin_fmaf(-t, B.y, B.x);
+        g = __builtin_fmaf(t, B.x, B.y);
+        f = c;
+    } else {
+        const float r = c / sn;
+        p = __builtin_fmaf(r, B.x, -B.y);
+        g = __builtin_fmaf(r, B.y, B.x);
+        f = sn;
+    }
+    a = cf{__builtin_fmaf(f, p, A.x), __builtin_fmaf(f, g, A.y)};
+    b = cf{__builtin_fmaf(-f, p, A.x), __builtin_fmaf(-f, g, A.y)};
+}
+
+// natural order in, v[r] = X[brevE(r)] out.  The decimation-in-time network works on w[i] = v[brevE(i)] and leaves
+// w[j] = X[j]; with w aliased onto v through the index map both permutations cost nothing.
+template <int E, bool INV>
+__device__ __forceinline__ void fftE(cf (&v)[E])
+{
+#pragma unroll
+    for (int half = 1; half <= E / 2; half <<= 1) {
+        const int tstep = (E / 2) / half;
+#pragma unroll
+        for (int blk = 0; blk < E; blk += 2 * half) {
+#pragma unroll
+            for (int q = 0; q < half; q++)
+                bfly_ditE<E, INV>(v[brevE<E>(blk + q)], v[brevE<E>(blk + q + half)], q * tstep);
+        }
+    }
+}
+
+// tw2d: [E][E] float2, entry [k1][l] = exp(-2 pi j k1 l / N); one transform per group of E lanes, 256 / E per workgroup
+template <int E, bool INV>
+__global__ void __launch_bounds__(256)
+k_fft_square_f32(float *__restrict__ data, int count, const float2 *__restrict__ tw2d)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int N = E * E, GROUPS = 256 / E, PITCH = E + 1;
+    __shared__ float bufs[GROUPS][E * PITCH];
+    const int tid = threadIdx.x, grp = tid / E, lg = tid % E;
+    const long t = (long)blockIdx.x * GROUPS + grp;
+    if (t >= count) return;                                     // whole groups leave together: no barrier below
+    f32x2 *g = reinterpret_cast<f32x2 *>(data) + t * N;
+    float *buf = bufs[grp];
+    cf v[E];
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const f32x2 x = __builtin_nontemporal_load(&g[lg + E * j]);
+        v[j] = INV ? cf{x.x * (1.0f / N), x.y * (1.0f / N)} : cf{x.x, x.y};
+    }
+    fftE<E, INV>(v);                                            // v[q] = Y[k1 = brevE(q)] of column lg
+    // two single-plane E x E transposes inside the group (the lanes of a group run in lockstep inside one wave)
+#pragma unroll
+    for (int q = 0; q < E; q++) buf[brevE<E>(q) * PITCH + lg] = v[q].x;
+    OLS_WAVE_SYNC();
+#pragma unroll
+    for (int cidx = 0; cidx < E; cidx++) v[cidx].x = buf[lg * PITCH + cidx];
+    OLS_WAVE_SYNC();
+#pragma unroll
+    for (int q = 0; q < E; q++) buf[brevE<E>(q) * PITCH + lg] = v[q].y;
+    OLS_WAVE_SYNC();
+#pragma unroll
+    for (int cidx = 0; cidx < E; cidx++) v[cidx].y = buf[lg * PITCH + cidx];
+    OLS_WAVE_SYNC();
+    // inter-pass twiddle after the transpose: lane k1 = lg needs W^(k1 * l) for l = 0..E-1 = tw2d[l][k1] (the table is
+    // symmetric), a contiguous row per l across the group.  In chunks of eight so that the loads do not all go live at once
+#pragma unroll
+    for (int l0 = 0; l0 < E; l0 += 8) {
+#pragma unroll
+        for (int l = l0; l < l0 + 8; l++) {
+            const float2 w = tw2d[l * E + lg];
+            v[l] = cmul<INV>(v[l], cf{w.x, w.y});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    fftE<E, INV>(v);                                            // v[q] = X[lg + E brevE(q)]
+#pragma unroll
+    for (int q = 0; q < E; q++)
+        __builtin_nontemporal_store((f32x2){v[q].x, v[q].y}, &g[lg + E * brevE<E>(q)]);
+}
+
+// fills tw2d from the handle's table cs (cos then sin of 2 pi i / N): exactly the host-built values
+__global__ void k_fft_square_table(float2 *__restrict__ tw2d, const float *__restrict__ cs, int E)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, N = E * E;
+    if (i >= N) return;
+    const int m = ((i / E) * (i % E)) & (N - 1);
+    tw2d[i] = make_float2(cs[m], -cs[N + m]);
+}
+
 template <typename A>
 int launch_fft(typename A::data_t *data, int count, int size, const typename A::tw_t *cs, int inverse,
                void *stream, const char *name)
@@ -505,6 +631,33 @@ int launch_fft(typename A::data_t *data, int count, int size, const typename A::
 
 extern "C" int llzs_fft_f32(float *data, int count, int size, const float *cs, int inverse, void *stream)
 {
+    if ((size == 256 || size == 4096) && data && cs && count >= 1 && !getenv("LLZ_FFT_GENERIC")) {
+        // the [E][E] twiddle table is derived once per device and size from the caller's table (kept for the process)
+        static float2 *tables[16][2];
+        int dev = 0;
+        LLZ_HIP_CHECK(hipGetDevice(&dev));
+        const int E = size == 256 ? 16 : 64, slot = size == 256 ? 0 : 1;
+        if (dev < 0 || dev >= 16) dev = 0;
+        if (!tables[dev][slot]) {
+            float2 *t = nullptr;
+            LLZ_HIP_CHECK(hipMalloc(&t, sizeof(float2) * (size_t)size));
+            hipLaunchKernelGGL(k_fft_square_table, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, as_stream(stream), t,
+                               cs, E);
+            LLZ_LAUNCH_CHECK("k_fft_square_table");
+            tables[dev][slot] = t;
+        }
+        const float2 *tw2d = tables[dev][slot];
+        const unsigned blocks = (unsigned)((count + (256 / E) - 1) / (256 / E));
+        if (E == 16) {
+            if (inverse) hipLaunchKernelGGL((k_fft_square_f32<16, true>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d);
+            else hipLaunchKernelGGL((k_fft_square_f32<16, false>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d);
+        } else {
+            if (inverse) hipLaunchKernelGGL((k_fft_square_f32<64, true>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d);
+            else hipLaunchKernelGGL((k_fft_square_f32<64, false>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d);
+        }
+        LLZ_LAUNCH_CHECK("k_fft_square_f32");
+        return LLZ_OK;
+    }
     if (size == 1024 && data && cs && count >= 1 && !getenv("LLZ_FFT_GENERIC")) {
         const unsigned blocks = (unsigned)((count + 7) / 8);
         if (inverse)
