@@ -644,6 +644,7 @@ extern "C" int llzs_fft_f32(float *data, int count, int size, const float *cs, i
             hipLaunchKernelGGL(k_fft_square_table, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, as_stream(stream), t,
                                cs, E);
             LLZ_LAUNCH_CHECK("k_fft_square_table");
+            LLZ_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));   // published only once complete: other streams may use it
             tables[dev][slot] = t;
         }
         const float2 *tw2d = tables[dev][slot];
