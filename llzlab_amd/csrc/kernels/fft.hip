@@ -535,8 +535,12 @@ k_fft_square_f32(float *__restrict__ data, int count, const float2 *__restrict__
     constexpr int N = E * E, GROUPS = 256 / E, PITCH = E + 1;
     __shared__ float bufs[GROUPS][E * PITCH];
     const int tid = threadIdx.x, grp = tid / E, lg = tid % E;
-    const long t = (long)blockIdx.x * GROUPS + grp;
+    long t = (long)blockIdx.x * GROUPS + grp;
     if (t >= count) return;                                     // whole groups leave together: no barrier below
+    // a whole wave per transform: tell the compiler the base is wave-uniform, so that the 2 x 64 accesses are scalar base +
+    // one lane offset + immediates instead of 128 separate 64-bit address pairs (400+ -> ~300 VGPRs; still one wave per
+    // SIMD: the 64-element network itself holds ~220, fencing the butterflies in groups did not lower it)
+    if (E == 64) t = (long)blockIdx.x * GROUPS + __builtin_amdgcn_readfirstlane(grp);
     f32x2 *g = reinterpret_cast<f32x2 *>(data) + t * N;
     float *buf = bufs[grp];
     cf v[E];
