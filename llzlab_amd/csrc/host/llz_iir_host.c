@@ -2,6 +2,7 @@
  * llz_iir_host.c -- handle layer of the IIR path: the reference's single-channel direct-form-I symbols
  * (reference libllzfilter/llz_iir.c:37-156) and the multi-channel biquad-cascade extension.
  */
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include "../../../include/llz_iir.h"
@@ -107,6 +108,7 @@ typedef struct {
     double *d_coef;      /* stages x {b0,b1,b2,a1,a2} */
     double *d_pd, *d_pl; /* state-transition powers for the pipelined kernel: [S][6][4] and [S][64][12] */
     double *d_state;     /* [channels][stages][x1,x2,y1,y2] */
+    int warm_chunks;     /* 1024-sample chunks after which any state error has decayed below 1e-13 (0: unknown / too long) */
     void *stream;
     llz_stage_t st_in, st_out;
 } iirm_t;
@@ -163,6 +165,45 @@ static int iirm_build_powers(iirm_t *f, const double *c5)
     return rc;
 }
 
+/* How long does the cascade remember?  The pipelined kernel may split a channel along time when there are too few
+ * channels to fill the chip; a later segment then starts `warm` chunks early from the zero state.  That is sound when the
+ * homogeneous response (the response to any initial state) has died out by then.  Measured here on the cascade itself:
+ * unit initial outputs planted in each section in turn, zero input, the largest magnitude at any section output per
+ * 1024-sample chunk; the first chunk count after which it stays below 1e-13 of its peak, or 0 if that takes more than 64
+ * chunks (or the filter does not decay at all). */
+static int iirm_memory_chunks(const double *c5, int S)
+{
+    enum { MAXC = 64, CH = 1024 };
+    double env[MAXC];
+    for (int k = 0; k < MAXC; k++) env[k] = 0.0;
+    for (int s0 = 0; s0 < S; s0++) {
+        double x1[16] = {0}, x2[16] = {0}, y1[16] = {0}, y2[16] = {0};
+        y1[s0] = 1.0; y2[s0] = 1.0;
+        for (int k = 0; k < MAXC; k++) {
+            double m = 0.0;
+            for (int i = 0; i < CH; i++) {
+                double v = 0.0;
+                for (int s = 0; s < S; s++) {
+                    double acc = c5[5 * s] * v + c5[5 * s + 1] * x1[s] + c5[5 * s + 2] * x2[s]
+                                 - c5[5 * s + 3] * y1[s] - c5[5 * s + 4] * y2[s];
+                    x2[s] = x1[s]; x1[s] = v; y2[s] = y1[s]; y1[s] = acc;
+                    v = acc;
+                    const double a = fabs(acc);
+                    if (a > m) m = a;
+                }
+            }
+            if (!(m < 1e300)) return 0;                              /* unstable or NaN */
+            if (m > env[k]) env[k] = m;
+        }
+    }
+    double peak = 1.0;
+    for (int k = 0; k < MAXC; k++) if (env[k] > peak) peak = env[k];
+    int last_loud = -1;
+    for (int k = 0; k < MAXC; k++) if (env[k] >= 1e-13 * peak) last_loud = k;
+    if (last_loud >= MAXC - 2) return 0;                             /* still audible at the end of the probe */
+    return last_loud + 2;                                            /* one chunk of margin */
+}
+
 unsigned long llz_iir_cascade_mc_init(int channels, int stages, const double *coef)
 {
     if (channels < 1 || stages < 1 || stages > 16 || !coef) {
@@ -188,6 +229,7 @@ unsigned long llz_iir_cascade_mc_init(int channels, int stages, const double *co
     if (rc == LLZ_OK) rc = llzs_h2d(f->d_coef, c5, sizeof(double) * 5 * (size_t)stages, NULL);
     if (rc == LLZ_OK) rc = llzs_memset(f->d_state, 0, st_bytes, NULL);
     if (rc == LLZ_OK) rc = iirm_build_powers(f, c5);
+    if (rc == LLZ_OK) f->warm_chunks = iirm_memory_chunks(c5, stages);
     if (rc == LLZ_OK) rc = llzs_sync(NULL);
     free(c5);
     if (rc != LLZ_OK) {
@@ -239,7 +281,7 @@ int llz_iir_cascade_mc(unsigned long handle, const float *x, float *y, int frame
     const int n_fast = aligned ? frame_len - frame_len % LLZS_IIR_PIPE_CHUNK : 0;
     if (rc == LLZ_OK && n_fast > 0)
         rc = llzs_iir_cascade_pipe_f32(d_in, d_out, f->d_coef, f->d_pd, f->d_pl, f->d_state, f->channels, n_fast,
-                                       frame_len, frame_len, f->stages, f->stream);
+                                       frame_len, frame_len, f->stages, f->warm_chunks, f->stream);
     if (rc == LLZ_OK && n_fast < frame_len)
         rc = llzs_iir_cascade_f32(d_in + n_fast, d_out + n_fast, f->d_coef, f->d_state, f->channels,
                                   frame_len - n_fast, frame_len, frame_len, f->stages, f->stream);

@@ -10,6 +10,7 @@
 //                        LDS in 64x64 tiles so HBM sees 256-byte rows although lanes own channels. State and
 //                        arithmetic are double (the recurrence amplifies rounding by ~1/(1-r)^2 for pole radius r).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -181,12 +182,20 @@ __device__ __forceinline__ double lane63_f64(double v)
 __global__ void __launch_bounds__(1024)
 k_iir_cascade_pipe_f32(const float *__restrict__ in, float *__restrict__ out, const double *__restrict__ coef,
                        const double *__restrict__ pd /* [S][6][4] */, const double *__restrict__ pl /* [S][64][12] */,
-                       double *__restrict__ state, int nchunks, long in_pitch, long out_pitch, int stages)
+                       double *__restrict__ state, int nchunks_total, long in_pitch, long out_pitch, int stages,
+                       int segs, int seg_chunks, int warm)
 {
     extern __shared__ __attribute__((aligned(16))) double slots[];        // [stages-1][PIPE_CHUNK]: one per section boundary
     const int lane = threadIdx.x & 63;
     const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // this wave's section (wave-uniform)
-    const int c = blockIdx.x;
+    // (3) segments along time when there are too few channels to fill the chip: workgroup (c, seg) owns chunks
+    //     [seg*seg_chunks, (seg+1)*seg_chunks) of channel c.  Segment 0 starts from the channel's true state; a later one
+    //     starts `warm` chunks early from the zero state and discards those outputs: the host has checked on the
+    //     cascade's own homogeneous responses that a state error decays below 1e-13 within `warm` chunks.
+    const int c = blockIdx.x / segs, seg = blockIdx.x - c * segs;
+    const int skip = seg > 0 ? warm : 0;                                   // leading chunks computed but not written
+    const int chunk0 = seg * seg_chunks - skip;
+    const int nchunks = min(nchunks_total, (seg + 1) * seg_chunks) - chunk0;
     const double b0 = coef[5 * s + 0], b1 = coef[5 * s + 1], b2 = coef[5 * s + 2];
     const double a1 = coef[5 * s + 3], a2 = coef[5 * s + 4];
     double P[4][4];                                                       // P^1, P^2, P^4, P^8 (wave-uniform)
@@ -200,10 +209,11 @@ k_iir_cascade_pipe_f32(const float *__restrict__ in, float *__restrict__ out, co
     const double M1a = plane_tab[4], M1b = plane_tab[5], M1c = plane_tab[6], M1d = plane_tab[7];
     const double M2a = plane_tab[8], M2b = plane_tab[9], M2c = plane_tab[10], M2d = plane_tab[11];
     double *st = state + ((size_t)c * stages + s) * 4;
-    double su1 = st[0], su2 = st[1], sy1 = st[2], sy2 = st[3];           // x(n-1), x(n-2), y(n-1), y(n-2)
+    double su1 = 0.0, su2 = 0.0, sy1 = 0.0, sy2 = 0.0;                   // x(n-1), x(n-2), y(n-1), y(n-2)
+    if (seg == 0) { su1 = st[0]; su2 = st[1]; sy1 = st[2]; sy2 = st[3]; }
 
-    const float *row = in + (size_t)c * in_pitch + lane * PIPE_R;
-    float *orow = out + (size_t)c * out_pitch + lane * PIPE_R;
+    const float *row = in + (size_t)c * in_pitch + (size_t)chunk0 * PIPE_CHUNK + lane * PIPE_R;
+    float *orow = out + (size_t)c * out_pitch + (size_t)chunk0 * PIPE_CHUNK + lane * PIPE_R;
     double *my_in = slots + (size_t)(s > 0 ? s - 1 : 0) * PIPE_CHUNK + lane;    // boundary s-1 | s
     double *my_out = slots + (size_t)s * PIPE_CHUNK + lane;                      // boundary s | s+1 (unused by the last)
     const bool first = (s == 0), last = (s == stages - 1);
@@ -299,10 +309,12 @@ k_iir_cascade_pipe_f32(const float *__restrict__ in, float *__restrict__ out, co
             sy1 = lane63_f64(y1); sy2 = lane63_f64(y2);
             if (last) {
                 float *dst = orow + (size_t)chunk * PIPE_CHUNK;
+                if (chunk >= skip) {                              // warm-up chunks of a later segment are not written
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                    *reinterpret_cast<float4 *>(dst + 4 * q) = make_float4((float)u[4 * q], (float)u[4 * q + 1],
-                                                                            (float)u[4 * q + 2], (float)u[4 * q + 3]);
+                    for (int q = 0; q < 4; q++)
+                        *reinterpret_cast<float4 *>(dst + 4 * q) = make_float4((float)u[4 * q], (float)u[4 * q + 1],
+                                                                                (float)u[4 * q + 2], (float)u[4 * q + 3]);
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < PIPE_R; k++) my_out[k * 64] = u[k];
@@ -310,7 +322,7 @@ k_iir_cascade_pipe_f32(const float *__restrict__ in, float *__restrict__ out, co
         }
         __syncthreads();                           // outputs visible before the next step's reads
     }
-    if (lane == 0) { st[0] = su1; st[1] = su2; st[2] = sy1; st[3] = sy2; }
+    if (lane == 0 && seg == segs - 1) { st[0] = su1; st[1] = su2; st[2] = sy1; st[3] = sy2; }
 }
 
 } // namespace
@@ -356,7 +368,7 @@ extern "C" int llzs_iir_cascade_f32(const float *in, float *out, const double *c
 // the rows 16-byte aligned (pitches % 4 == 0); the caller runs the remainder through llzs_iir_cascade_f32.
 extern "C" int llzs_iir_cascade_pipe_f32(const float *in, float *out, const double *coef, const double *pd,
                                          const double *pl, double *state, int channels, int n, long in_pitch,
-                                         long out_pitch, int stages, void *stream)
+                                         long out_pitch, int stages, int warm_chunks, void *stream)
 {
     if (!in || !out || !coef || !pd || !pl || !state || channels <= 0 || n <= 0 || (n % PIPE_CHUNK) ||
         stages < 1 || stages > 16 || in_pitch < n || out_pitch < n || (in_pitch & 3) || (out_pitch & 3) ||
@@ -369,8 +381,21 @@ extern "C" int llzs_iir_cascade_pipe_f32(const float *in, float *out, const doub
     if (lds > 64 * 1024)
         LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_iir_cascade_pipe_f32),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_iir_cascade_pipe_f32, dim3((unsigned)channels), dim3(64 * stages), lds, as_stream(stream),
-                       in, out, coef, pd, pl, state, n / PIPE_CHUNK, in_pitch, out_pitch, stages);
+    // time segments: only when the channels alone leave most of the chip idle (fewer than two workgroups per CU) and the
+    // warm-up stays a small part of a segment
+    const int nchunks = n / PIPE_CHUNK;
+    int segs = 1;
+    if (warm_chunks > 0 && channels < 512) {
+        segs = (512 + channels - 1) / channels;
+        if (segs > 16) segs = 16;
+        while (segs > 1 && nchunks / segs < 8 * warm_chunks) segs--;
+    }
+    if (const char *e = getenv("LLZ_IIR_SEGS")) { const int v = atoi(e); if (v >= 1 && v <= 64 && (v == 1 || warm_chunks > 0)) segs = v; }
+    const int seg_chunks = (nchunks + segs - 1) / segs;
+    segs = (nchunks + seg_chunks - 1) / seg_chunks;
+    hipLaunchKernelGGL(k_iir_cascade_pipe_f32, dim3((unsigned)((long)channels * segs)), dim3(64 * stages), lds,
+                       as_stream(stream), in, out, coef, pd, pl, state, nchunks, in_pitch, out_pitch, stages, segs,
+                       seg_chunks, warm_chunks);
     LLZ_LAUNCH_CHECK("k_iir_cascade_pipe_f32");
     return LLZ_OK;
 }

@@ -439,6 +439,29 @@ def test_fft_fixed_wraps_like_the_reference_arithmetic(dev, oracle):
     f.close()
 
 
+def test_iir_cascade_few_channels_split_along_time(dev, oracle):
+    """few channels and a long frame: the pipelined kernel splits each channel into time segments that start a measured
+    warm-up early from the zero state (the cascade's memory, probed at init); the result must still match the sequential
+    oracle, including the high-Q section, and the state handed to the next call must be the true one"""
+    d = load("iir.npz")
+    coef = np.stack([np.concatenate([d["bq"], d["aq"]]), np.concatenate([d["b2"], d["a2"]]),
+                     np.concatenate([d["bq"], d["aq"]])])
+    channels, n = 2, 1024 * 240
+    x = oracle.synth_f32(channels, n + 4096, seed=5)
+    ref = oracle.iir_cascade_batch_f32(x, coef)
+    f = filters.IirCascadeMC(channels, coef)
+    xd = torch.from_numpy(np.ascontiguousarray(x[:, :n])).to(dev)
+    yd = torch.empty_like(xd)
+    f.filter(xd, yd)
+    x2 = torch.from_numpy(np.ascontiguousarray(x[:, n:])).to(dev)
+    y2 = torch.empty_like(x2)
+    f.filter(x2, y2)                                                    # continues from the state the segments left
+    f.close()
+    got = np.concatenate([yd.cpu().numpy(), y2.cpu().numpy()], axis=1)
+    rms_check(got, ref, "iir split along time")
+    assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("channels,n", [(3, 1024 * 5), (2, 1024 * 3 + 777), (130, 2048)])
 def test_iir_cascade_pipelined_path_long(dev, oracle, channels, n):
     """whole 1024-sample chunks run through the stage-pipelined kernel, the remainder through the per-channel one;
