@@ -416,11 +416,15 @@ extern "C" int llzs_fir_ols_f32(const float *in, float *out, const float *hist, 
         // into rounds with the full length, so take the length that minimises rounds x (length + halo reload)
         const long slots = max_blocks * OLS_WAVES * 2;
         int seg_len = OLS_SEG;
-        double best = 1e300;
-        for (int sl = OLS_SEG; sl >= 1; sl--) {
-            const long segs = (long)((jobs_per_channel + sl - 1) / sl) * channels;
-            const double cost = (double)((segs + slots - 1) / slots) * (sl + 0.17);
-            if (cost < best * 0.999) { best = cost; seg_len = sl; }
+        if ((long)((jobs_per_channel + OLS_SEG - 1) / OLS_SEG) * channels < 4 * slots) {
+            // (large batches keep the full length: on 4096 channels a shorter segment measured 2.6 % slower, the start of
+            // a segment costs about one job: halo reload and an empty prefetch pipeline)
+            double best = 1e300;
+            for (int sl = OLS_SEG; sl >= 1; sl--) {
+                const long segs = (long)((jobs_per_channel + sl - 1) / sl) * channels;
+                const double cost = (double)((segs + slots - 1) / slots) * (sl + 1.0);
+                if (cost < best * 0.999) { best = cost; seg_len = sl; }
+            }
         }
         const int segs_per_channel = (jobs_per_channel + seg_len - 1) / seg_len;
         const long total_segs = (long)segs_per_channel * channels;
