@@ -194,7 +194,8 @@ def main():
         achieved = BYTES_PER_SAMPLE * channels * n / (kern_ms * 1e-3) / 1e9      # GB/s, algorithmic bytes
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        # the committed PMC figure is per launch of the DEFAULT workload: report it only for that workload
+        if os.path.exists(tpath) and channels == CHANNELS and n == N_SAMPLES and fir_algo == 2:
             try:
                 traffic = json.load(open(tpath)).get("headline_kernel_bytes_per_launch")
             except Exception:
