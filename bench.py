@@ -58,6 +58,13 @@ def cpu_baseline(taps64, oracle_mod):
                       f"{threads} threads ({dt:.1f} s)"}
 
 
+def ols_kernel_name(channels, n):
+    """which overlap-save kernel the launcher takes (llzs_fir_ols_f32 in csrc/kernels/fir_ols.hip): the chain form when a
+    half-wave walks several 16-job segments, the walk form on batches that fit one round"""
+    jobs = (n + 1535) // 1536
+    return "k_fir_ols_chain_f32" if ((jobs + 15) // 16) * channels >= 4 * 4096 else "k_fir_ols_walk_f32"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,7 +219,7 @@ def main():
                        "algorithm": algo_name, "per_gpu_Msamples_s": value / world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": {1: "k_fir_td_f32", 2: "k_fir_ols_walk_f32", 3: "k_fir_mfma_bf16x3"}[fir_algo],
+                         "kernel": {1: "k_fir_td_f32", 2: ols_kernel_name(channels, n), 3: "k_fir_mfma_bf16x3"}[fir_algo],
                          "kernel_ms_avg": kern_ms, "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * channels * n,
                          "memcpy_d2d_GBs": memcpy_gbs,
                          "frac_of_memcpy_d2d": (achieved / memcpy_gbs) if memcpy_gbs else None},

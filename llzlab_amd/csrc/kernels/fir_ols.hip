@@ -386,6 +386,102 @@ k_fir_ols_walk_f32(const float *__restrict__ in, float *__restrict__ out, const 
     }
 }
 
+
+// Chain form: the walk form with the prefetch carried ACROSS segments.  In the walk form the prefetch issued during a
+// segment's last job runs past the segment's end and is discarded (1/16 of the input fetched twice), and every segment
+// starts with an exposed load of its halo and first job.  Here the last job of a segment prefetches the first job and
+// the halo of the half-wave's NEXT segment instead, so every load is used and no segment start waits on memory.
+__global__ void __launch_bounds__(OLS_THREADS)
+k_fir_ols_chain_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
+                    const float2 *__restrict__ hfreq, const float2 *__restrict__ twid, int channels, int n,
+                    long in_pitch, long out_pitch, int flt_len, int jobs_per_channel, int segs_per_channel,
+                    long total_segs, int seg_len)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *s_tw = reinterpret_cast<float2 *>(smem);
+    float2 *s_h = s_tw + 1024;
+    float *s_x = reinterpret_cast<float *>(s_h + 1024);
+    for (int i = threadIdx.x; i < 1024; i += OLS_THREADS) {
+        s_tw[i] = twid[i];
+        s_h[i] = hfreq[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int half = lane >> 5;
+    const int l5 = lane & 31;
+    float *buf = s_x + (wave * 2 + half) * OLS_XBUF;
+    const int keep = flt_len - 1;
+    const long halves_total = (long)gridDim.x * OLS_WAVES * 2;
+    const long first = ((long)blockIdx.x * OLS_WAVES + wave) * 2;
+
+    struct seginfo {
+        bool live;
+        int c, j0, jcount;
+    };
+    auto locate = [&](long seg) {
+        seginfo g;
+        g.live = seg < total_segs;
+        g.c = g.live ? (int)(seg / segs_per_channel) : 0;
+        g.j0 = g.live ? (int)(seg - (long)g.c * segs_per_channel) * seg_len : 0;
+        g.jcount = g.live ? min(seg_len, jobs_per_channel - g.j0) : 0;
+        return g;
+    };
+
+    seginfo cur = locate(first + half);
+    float halo[8];
+    ols_raw raw;
+    {
+        const float *row = in + (size_t)cur.c * in_pitch;
+        walk_load_halo(halo, row, hist ? hist + (size_t)cur.c * keep : nullptr, cur.j0 * OLS_JOB, l5, keep, cur.live);
+        walk_load(raw, row, cur.j0 * OLS_JOB, l5, n, cur.jcount > 0);
+    }
+    for (long sp = first; sp < total_segs; sp += halves_total) {
+        const seginfo nxt = locate(sp + halves_total + half);
+        const float *row = in + (size_t)cur.c * in_pitch;
+        float *orow = out + (size_t)cur.c * out_pitch;
+        const float *hrow = hist ? hist + (size_t)cur.c * keep : nullptr;
+        const float *nrow = in + (size_t)nxt.c * in_pitch;
+        const float *nhrow = hist ? hist + (size_t)nxt.c * keep : nullptr;
+        float halo_n[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) halo_n[i] = 0.f;
+
+#pragma unroll 1
+        for (int jj = 0; jj < seg_len; jj++) {
+            const int s = (cur.j0 + jj) * OLS_JOB;
+            const bool live = jj < cur.jcount;
+            if (!__any(live)) break;
+            cf v[32], u[32];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                v[i].x = halo[i];
+                v[i].y = raw.a[16 + i];
+                halo[i] = raw.b[16 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 24; i++) {
+                v[8 + i].x = raw.a[i];
+                v[8 + i].y = raw.b[i];
+            }
+            // next job of this segment, or (from the segment's last job on) the first job and halo of the next segment
+            const bool in_seg = (jj + 1) < cur.jcount;
+            walk_load(raw, in_seg ? row : nrow, in_seg ? s + OLS_JOB : nxt.j0 * OLS_JOB, l5, n,
+                      in_seg ? true : nxt.jcount > 0);
+            if (__any(!in_seg))
+                walk_load_halo(halo_n, nrow, nhrow, nxt.j0 * OLS_JOB, l5, keep, !in_seg && nxt.live);
+            ols_filter(v, u, buf, s_tw, s_h, l5);
+            ols_job jb;
+            jb.row = row; jb.orow = orow; jb.hrow = hrow; jb.s = s; jb.live = live;
+            ols_store(u, jb, l5, n);
+        }
+        cur = nxt;
+#pragma unroll
+        for (int i = 0; i < 8; i++) halo[i] = halo_n[i];
+    }
+}
+
 } // namespace
 
 extern "C" int llzs_fir_ols_f32(const float *in, float *out, const float *hist, const float *hfreq,
@@ -405,7 +501,8 @@ extern "C" int llzs_fir_ols_f32(const float *in, float *out, const float *hist, 
     const long pairs = (total_jobs + 1) / 2;
     const size_t lds_bytes = 2 * 1024 * sizeof(float2) + (size_t)OLS_WAVES * 2 * OLS_XBUF * sizeof(float);
     long blocks = (pairs + OLS_WAVES - 1) / OLS_WAVES;
-    // tuning knobs (measurement only): LLZ_OLS_VARIANT bit 0 = register prefetch, bit 1 = walk form;
+    // tuning knobs (measurement only): LLZ_OLS_VARIANT bit 0 = register prefetch, bit 1 = walk form, bit 2 / bit 3 = force /
+    // forbid the chain form;
     // LLZ_OLS_WG_PER_CU = resident workgroups per CU the grid is sized for
     static int variant = -1, wg_per_cu = -1;
     if (variant < 0) {
@@ -419,6 +516,10 @@ extern "C" int llzs_fir_ols_f32(const float *in, float *out, const float *hist, 
     const long max_blocks = 256L * per_cu;       // one resident set of workgroups, grid stride over the work list
     const float2 *hf = reinterpret_cast<const float2 *>(hfreq), *tw = reinterpret_cast<const float2 *>(twid);
     if (variant >= 2) {
+        // chain form (prefetch carried across segments) when a half-wave walks several segments; on a batch that fits one
+        // round the walk form is faster (64 ch x 63 taps: 0.14 vs 0.16 ms).  LLZ_OLS_VARIANT bit 2 forces it, bit 3 forbids
+        const bool large = (long)((jobs_per_channel + OLS_SEG - 1) / OLS_SEG) * channels >= 4 * max_blocks * OLS_WAVES * 2;
+        const bool chain = prefetch && ((variant & 4) != 0 || (large && (variant & 8) == 0));
         // jobs per segment: a half-wave walks seg_len consecutive jobs of one channel (the overlap stays in registers), at
         // most OLS_SEG.  Small batches (BASELINE config 2: 64 channels) would leave half-wave slots idle or quantise badly
         // into rounds with the full length, so take the length that minimises rounds x (length + halo reload)
@@ -438,7 +539,11 @@ extern "C" int llzs_fir_ols_f32(const float *in, float *out, const float *hist, 
         const long total_segs = (long)segs_per_channel * channels;
         blocks = (total_segs + 2 * OLS_WAVES - 1) / (2 * OLS_WAVES);
         if (blocks > max_blocks) blocks = max_blocks;
-        if (prefetch)
+        if (chain)
+            hipLaunchKernelGGL(k_fir_ols_chain_f32, dim3((unsigned)blocks), dim3(OLS_THREADS), lds_bytes,
+                               as_stream(stream), in, out, hist, hf, tw, channels, n, in_pitch, out_pitch, flt_len,
+                               jobs_per_channel, segs_per_channel, total_segs, seg_len);
+        else if (prefetch)
             hipLaunchKernelGGL(k_fir_ols_walk_f32<true>, dim3((unsigned)blocks), dim3(OLS_THREADS), lds_bytes,
                                as_stream(stream), in, out, hist, hf, tw, channels, n, in_pitch, out_pitch, flt_len,
                                jobs_per_channel, segs_per_channel, total_segs, seg_len);

@@ -4,6 +4,7 @@ Bit-exact for double (exact-order kernels), int16 and int32; float32 batch paths
 relative to rms(reference) -- the tolerance BASELINE.json's north_star states.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -15,6 +16,7 @@ from llzlab_amd import capi, filters  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-5   # RMS, north_star
 
 
@@ -716,3 +718,44 @@ def test_mdct_batch_vs_oracle(dev, oracle, n, count):
     m.forward(x, Xh)
     assert np.array_equal(Xh, got)
     m.close()
+
+
+# ------------------------------------------------------------------------------------------------ overlap-save, chain form
+_CHAIN_SCRIPT = r'''
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.environ["LLZ_REPO"])
+from llzlab_amd import filters
+from oracle import pyoracle as po
+po.build()
+oracle = po.Oracle()
+dev = torch.device("cuda:0")
+for channels, n, taps_n in ((3, 1536 * 40 + 100, 257), (5, 1536 * 33, 63), (2, 1000, 129), (9, 1536 * 17 + 1, 200)):
+    taps = oracle.fir_design(po.LPF, taps_n, 0.2, 0.0, po.KAISER)
+    x = oracle.synth_f32(channels, 2 * n, seed=taps_n)
+    ref = oracle.fir_batch_f32(x, taps.astype(np.float32).astype(np.float64))
+    f = filters.FirFilterMC(channels, n, taps, algo=filters.FIR_ALGO_OVERLAP_SAVE)
+    outs = []
+    for o in (0, n):                                    # two frames: the history carried between calls
+        xd = torch.from_numpy(np.ascontiguousarray(x[:, o:o + n])).to(dev)
+        yd = torch.empty_like(xd)
+        f.filter(xd, yd)
+        outs.append(yd.cpu().numpy())
+    got = np.concatenate(outs, axis=1).astype(np.float64)
+    err = float(np.sqrt(np.mean((got - ref) ** 2)))
+    rel = err / float(np.sqrt(np.mean(ref ** 2)))
+    assert err <= 1e-5 and rel <= 1e-5, (channels, n, taps_n, err, rel)
+    f.close()
+print("CHAIN_OK")
+'''
+
+
+def test_fir_ols_chain_form_forced(dev):
+    """the launcher takes the chain form (prefetch carried across segments) only on batches far larger than a test can
+    afford to check sample by sample; LLZ_OLS_VARIANT=7 forces it on small ones in a child process (the knob is read once
+    per process), including ragged lengths, segments shorter than 16 jobs and streaming across calls"""
+    import subprocess
+    env = dict(os.environ, LLZ_OLS_VARIANT="7", LLZ_REPO=ROOT)
+    r = subprocess.run([sys.executable, "-c", _CHAIN_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CHAIN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
