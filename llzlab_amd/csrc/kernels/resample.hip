@@ -12,6 +12,7 @@
 // is staged once in LDS with coalesced reads, so HBM sees each input sample about once (+Q/span halo from L2).
 // Tap rows come through the vector L1 (one row for L = 1: every lane reads the same address).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -89,6 +90,78 @@ k_resample(const T *__restrict__ in, T *__restrict__ out, const T *__restrict__ 
         }
     }
     out[(size_t)c * out_pitch + i] = rs_finish(acc, gain, (T *)nullptr);
+}
+
+// general L/M, float32, with the tap matrix in LDS ("per-phase sub-filters in LDS"): a workgroup owns RSL_R * 256
+// consecutive outputs of one channel, stages the whole L x Q matrix once (rows padded to qpad floats, qpad/4 odd, so that
+// the 16-byte row reads of 16 consecutive phases fall in distinct banks) next to the input span, and each lane walks
+// RSL_R outputs with one ds_read_b128 of taps per four MACs.  The first version fetched every tap through the vector
+// memory path per MAC (6-7 % of the HBM roofline).
+constexpr int RSL_R = 8;
+
+__global__ void __launch_bounds__(RS_THREADS)
+k_resample_f32_lds(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
+                   const float *__restrict__ g, long n_in, long n_out, long in_pitch, long out_pitch, int L, int M, int Q,
+                   float gain, long long i0, long long in0, int qpad)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *gl = reinterpret_cast<float *>(smem_raw);               // [L][qpad], zero beyond Q
+    float *xs = gl + (size_t)L * qpad + 8;                          // 8 zero floats in front: the padded taps read there
+    const int c = blockIdx.y;
+    const long o0 = (long)blockIdx.x * (RS_THREADS * RSL_R);
+    const long olast = min(o0 + RS_THREADS * RSL_R, n_out) - 1;
+    const long pos_first = (long)(((i0 + o0) * M) / L - in0);
+    const long pos_last = (long)(((i0 + olast) * M) / L - in0);
+    const long base = pos_first - (Q - 1);
+    const int span = (int)(pos_last - base + 1);
+    for (int e = threadIdx.x; e < L * qpad; e += RS_THREADS) {
+        const int l = e / qpad, k = e - l * qpad;
+        gl[e] = k < Q ? g[(size_t)l * Q + k] : 0.f;
+    }
+    if (threadIdx.x < 8) xs[-8 + (int)threadIdx.x] = 0.f;
+    const float *row = in + (size_t)c * in_pitch;
+    const float *hrow = hist ? hist + (size_t)c * (Q - 1) : nullptr;
+    for (int p = threadIdx.x; p < span; p += RS_THREADS) {
+        const long idx = base + p;
+        float v = 0.f;
+        if (idx >= 0) {
+            if (idx < n_in) v = row[idx];
+        } else if (hrow && idx >= -(long)(Q - 1)) {
+            v = hrow[(Q - 1) + idx];
+        }
+        xs[p] = v;
+    }
+    __syncthreads();
+    // index arithmetic once per lane, then by increments: output i+256 sits (256*M) input-steps/L further, i.e. the
+    // position advances by dq (+1 on a carry of the remainder) and the phase by 256 mod L -- no division per output
+    const long i_first = o0 + threadIdx.x;
+    if (i_first >= n_out) return;
+    const long long gi0 = i0 + i_first;
+    const long long num = gi0 * M;
+    int pos = (int)(num / L - in0 - base);                          // LDS index of x[(gi*M)/L]
+    int rem = (int)(num % L);
+    int ph = (int)(gi0 % L);
+    const int dq = (RS_THREADS * M) / L, dr = (RS_THREADS * M) % L, dph = RS_THREADS % L;
+#pragma unroll 1
+    for (int r = 0; r < RSL_R; r++) {
+        const long i = i_first + r * RS_THREADS;
+        if (i >= n_out) break;
+        const float *xp = xs + pos;                                 // taps walk backwards from here
+        const float *trow = gl + (size_t)ph * qpad;
+        float acc = 0.f;
+        for (int k = 0; k < qpad; k += 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(trow + k);
+            acc = __builtin_fmaf(xp[-k], t.x, acc);
+            acc = __builtin_fmaf(xp[-k - 1], t.y, acc);
+            acc = __builtin_fmaf(xp[-k - 2], t.z, acc);
+            acc = __builtin_fmaf(xp[-k - 3], t.w, acc);
+        }
+        out[(size_t)c * out_pitch + i] = acc * gain;
+        pos += dq; rem += dr;
+        if (rem >= L) { rem -= L; pos++; }
+        ph += dph;
+        if (ph >= L) ph -= L;
+    }
 }
 
 // int16 in/out, the reference's arithmetic (llz_resample.c:583-603) with the per-tap overhead taken out: the input span
@@ -354,6 +427,20 @@ extern "C" int llzs_resample_f32(const float *in, float *out, const float *hist,
                                  long n_in, long n_out, long in_pitch, long out_pitch, int L, int M, int Q,
                                  float gain, long long i0, long long in0, void *stream)
 {
+    if (in && out && g && channels > 0 && channels <= 65535 && n_in > 0 && n_out > 0 && L >= 1 && M >= 1 && Q >= 1 &&
+        in_pitch >= n_in && out_pitch >= n_out) {
+        int qpad = (Q + 3) & ~3;
+        if (((qpad >> 2) & 1) == 0) qpad += 4;                       // qpad/4 odd: conflict-free 16-byte row reads
+        const int span_max = (int)(((long)(RS_THREADS * RSL_R - 1) * M + L - 1) / L) + 1 + Q;
+        const size_t lds = ((size_t)L * qpad + 8 + span_max) * sizeof(float);
+        if (lds <= 64 * 1024 && !getenv("LLZ_RS_GENERIC_OLD")) {
+            dim3 grid((unsigned)((n_out + RS_THREADS * RSL_R - 1) / (RS_THREADS * RSL_R)), (unsigned)channels);
+            hipLaunchKernelGGL(k_resample_f32_lds, grid, dim3(RS_THREADS), lds, as_stream(stream), in, out, hist, g, n_in,
+                               n_out, in_pitch, out_pitch, L, M, Q, gain, i0, in0, qpad);
+            LLZ_LAUNCH_CHECK("k_resample_f32_lds");
+            return LLZ_OK;
+        }
+    }
     return launch_resample<float>(in, out, hist, g, channels, n_in, n_out, in_pitch, out_pitch, L, M, Q, gain, i0,
                                   in0, stream, "k_resample<float>");
 }

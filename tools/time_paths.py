@@ -70,9 +70,9 @@ if "resample_i16" in which:
     print(f"resample 1:3 i16 exact {ch}ch x {n}: {ms:.3f} ms  {ch * n / ms / 1e3:.0f} Msamples_in/s  {gb:.0f} GB/s ({gb / 80:.1f} %)")
     r.close()
     del x, y
-    for (L_, M_) in ((2, 3), (147, 160)):
+    for (L_, M_) in ((2, 3), (3, 2), (147, 160), (160, 147)):
         ch = 256
-        n = M_ * 8192
+        n = M_ * (8192 if M_ > 100 else 400000)
         x = torch.empty(ch, n, dtype=torch.float32, device=dev)
         y = torch.empty(ch, n * L_ // M_, dtype=torch.float32, device=dev)
         filters.synth_f32(x, 1, stream=stream)
