@@ -20,7 +20,7 @@ FIR_ALGO_AUTO, FIR_ALGO_TIME, FIR_ALGO_OVERLAP_SAVE, FIR_ALGO_TIME_MFMA = 0, 1, 
 OVERLAP_HIGH, OVERLAP_LOW = 0, 1      # llz_asmodel.h: 3/4 and 1/2 overlap
 MDCT_ORIGIN, MDCT_FFT, MDCT_FFT4 = 0, 1, 2
 MDCT_SINE, MDCT_KBD = 0, 1
-PCM_F32, PCM_I16 = 0, 1
+PCM_F32, PCM_I16, PCM_I16_FAST = 0, 1, 2
 
 _lib = None
 

@@ -266,7 +266,7 @@ typedef struct {
     llz_stage_t st_in, st_out;
 } rsm_t;
 
-static size_t rsm_sample_bytes(const rsm_t *r) { return r->fmt == LLZ_PCM_I16 ? sizeof(short) : sizeof(float); }
+static size_t rsm_sample_bytes(const rsm_t *r) { return r->fmt == LLZ_PCM_F32 ? sizeof(float) : sizeof(short); }
 
 static void rsm_destroy(rsm_t *r)
 {
@@ -309,8 +309,12 @@ static int rsm_upload_matrix(rsm_t *r)
 unsigned long llz_resample_mc_init(int channels, int L, int M, double gain, win_t win_type, int pcm_format)
 {
     if (channels < 1 || channels > 65535 || L < 1 || M < 1 ||
-        (pcm_format != LLZ_PCM_F32 && pcm_format != LLZ_PCM_I16)) {
+        (pcm_format != LLZ_PCM_F32 && pcm_format != LLZ_PCM_I16 && pcm_format != LLZ_PCM_I16_FAST)) {
         llzs_set_error("llz_resample_mc_init: channels %d L %d M %d format %d", channels, L, M, pcm_format);
+        return LLZ_BAD_HANDLE;
+    }
+    if (pcm_format == LLZ_PCM_I16_FAST && L != 1) {
+        llzs_set_error("llz_resample_mc_init: LLZ_PCM_I16_FAST needs L == 1 (got %d/%d); use LLZ_PCM_I16", L, M);
         return LLZ_BAD_HANDLE;
     }
     const double ratio = ((double)L) / M;
@@ -332,6 +336,10 @@ unsigned long llz_resample_mc_init(int channels, int L, int M, double gain, win_
         r->d_hist[1] = llzs_malloc(hist_bytes);
         if (!r->d_mat || !r->d_hist[0] || !r->d_hist[1]) rc = LLZ_ERR_NOMEM;
         if (rc == LLZ_OK) rc = rsm_upload_matrix(r);
+        if (rc == LLZ_OK && r->fmt == LLZ_PCM_I16_FAST && !llzs_fir_mfma_i16_fits(r->Q, r->M)) {
+            llzs_set_error("llz_resample_mc_init: %d taps at 1:%d do not fit the matrix-core kernel", r->Q, r->M);
+            rc = LLZ_ERR_RANGE;
+        }
         if (rc == LLZ_OK) rc = llzs_memset(r->d_hist[0], 0, hist_bytes, NULL);
         if (rc == LLZ_OK) rc = llzs_memset(r->d_hist[1], 0, hist_bytes, NULL);
         if (rc == LLZ_OK) rc = llzs_sync(NULL);
@@ -433,7 +441,10 @@ long llz_resample_mc(unsigned long handle, const void *in, long n_in, void *out)
     }
     const void *hist = r->Q > 1 ? r->d_hist[r->cur] : NULL;
     if (rc == LLZ_OK) {
-        if (r->fmt == LLZ_PCM_I16)
+        if (r->fmt == LLZ_PCM_I16_FAST)
+            rc = llzs_fir_mfma_i16((const short *)d_in, (short *)d_out, (const short *)hist, (const float *)r->d_mat,
+                                   r->channels, n_in, n_out, n_in, n_out, r->Q, r->M, (float)r->gain, r->stream);
+        else if (r->fmt == LLZ_PCM_I16)
             rc = llzs_resample_i16((const short *)d_in, (short *)d_out, (const short *)hist,
                                    (const double *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->L, r->M,
                                    r->Q, r->gain, r->out_count, r->in_count, r->stream);
@@ -450,7 +461,7 @@ long llz_resample_mc(unsigned long handle, const void *in, long n_in, void *out)
                                    r->Q, (float)r->gain, r->out_count, r->in_count, r->stream);
     }
     if (rc == LLZ_OK && r->Q > 1) {
-        if (r->fmt == LLZ_PCM_I16)
+        if (r->fmt != LLZ_PCM_F32)
             rc = llzs_tail_i16((const short *)d_in, (const short *)r->d_hist[r->cur],
                                (short *)r->d_hist[r->cur ^ 1], r->channels, n_in, n_in, r->Q - 1, r->stream);
         else

@@ -44,6 +44,11 @@ int llzs_fir_ols_f32(const float *in, float *out, const float *hist, const float
 int llzs_fir_mfma_f32(const float *in, float *out, const float *hist, const float *taps, int channels,
                       long n_in, long n_out, long in_pitch, long out_pitch, int T, int M, float gain, void *stream);
 int llzs_fir_mfma_f32_fits(int T, int M);           /* 1 when the LDS image of one tile fits */
+/* the same with int16 samples in and out (fp32 accumulate, clamp, truncate toward zero): within 1 LSB of the reference's
+ * double accumulation, not bit-exact; taps as floats, gain folded into them */
+int llzs_fir_mfma_i16(const short *in, short *out, const short *hist, const float *taps, int channels,
+                      long n_in, long n_out, long in_pitch, long out_pitch, int T, int M, float gain, void *stream);
+int llzs_fir_mfma_i16_fits(int T, int M);
 /* hist_new[c][:] = last (flt_len-1) samples of concat(hist_old[c], in[c][0:n]) */
 int llzs_fir_tail_f32(const float *in, const float *hist_old, float *hist_new,
                       int channels, int n, long in_pitch, int flt_len, void *stream);

@@ -11,7 +11,7 @@ import numpy as np
 
 from . import capi
 from .capi import (BAD_HANDLE, BLACKMAN, FIR_ALGO_AUTO, FIR_ALGO_OVERLAP_SAVE, FIR_ALGO_TIME, FIR_ALGO_TIME_MFMA, HAMMING, KAISER,  # noqa: F401
-                   PCM_F32, PCM_I16, LlzError, check, check_handle)
+                   PCM_F32, PCM_I16, PCM_I16_FAST, LlzError, check, check_handle)
 
 
 def _ptr(buf):
@@ -258,7 +258,8 @@ class Resample(_Resample1):
 
 
 class ResampleMC:
-    """channels x n_in -> channels x n_in*L/M; pcm_format PCM_F32 (float32) or PCM_I16 (bit-exact int16)."""
+    """channels x n_in -> channels x n_in*L/M; pcm_format PCM_F32 (float32), PCM_I16 (bit-exact int16) or PCM_I16_FAST
+    (int16 within 1 LSB of the reference, matrix cores, decimators only)."""
 
     def __init__(self, channels, L_, M, gain=1.0, win=BLACKMAN, pcm_format=PCM_F32, stream=None):
         self._L = capi.lib()

@@ -69,7 +69,12 @@ if "resample_i16" in which:
     gb = (2 + 2 / 3) * ch * n / ms / 1e6
     print(f"resample 1:3 i16 exact {ch}ch x {n}: {ms:.3f} ms  {ch * n / ms / 1e3:.0f} Msamples_in/s  {gb:.0f} GB/s ({gb / 80:.1f} %)")
     r.close()
-    del x, y
+    y.zero_()
+    r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, filters.PCM_I16_FAST, stream=stream)
+    ms = timeit(lambda: r.process(x, y), 3)
+    gb = (2 + 2 / 3) * ch * n / ms / 1e6
+    print(f"resample 1:3 i16 fast  {ch}ch x {n}: {ms:.3f} ms  {ch * n / ms / 1e3:.0f} Msamples_in/s  {gb:.0f} GB/s ({gb / 80:.1f} %)")
+    r.close()
     for (L_, M_) in ((2, 3), (3, 2), (147, 160), (160, 147)):
         ch = 256
         n = M_ * (8192 if M_ > 100 else 400000)
