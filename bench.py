@@ -292,9 +292,13 @@ def sharded_configs(torch, filters, capi, shard, dev, comm_dev, stream, rank, wo
         "Msamples_s": total_ch * n / ms / 1e3, "GBs_per_gpu": 8 * ch * n / ms / 1e6,
         "hbm_frac_per_gpu": 8 * ch * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "channels_per_gpu": ch,
         "scaling": "strong",
-        # the binding roof of this kernel is the FP64 vector pipe, not HBM: 7 DFMA per sample and section
-        "fp64_TFLOPs_per_gpu": 2 * 7 * 8 * ch * n / ms / 1e9, "fp64_peak_TFLOPs": 78.6,
-        "fp64_frac_per_gpu": 2 * 7 * 8 * ch * n / ms / 1e9 / 78.6}
+        # the binding roof of this kernel is the vector pipe, not HBM: 7 FMA per sample and section, in
+        # float32 when every section's rounding-noise gain allows it (this coefficient set: poles at radius 0.44), else
+        # in double
+        "arithmetic": "f32" if q.precision == 32 else "f64",
+        "valu_TFLOPs_per_gpu": 2 * 7 * 8 * ch * n / ms / 1e9,
+        "valu_peak_TFLOPs": 157.3 if q.precision == 32 else 78.6,
+        "valu_frac_per_gpu": 2 * 7 * 8 * ch * n / ms / 1e9 / (157.3 if q.precision == 32 else 78.6)}
     q.close()
     del x, y
     torch.cuda.empty_cache()

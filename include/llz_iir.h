@@ -26,6 +26,9 @@ void          llz_iir_cascade_mc_uninit(unsigned long handle);
 /* planar [channels][frame_len] float32, device or host pointers; any frame_len >= 1. Returns frame_len. */
 int           llz_iir_cascade_mc(unsigned long handle, const float *x, float *y, int frame_len);
 int           llz_iir_cascade_mc_set_stream(unsigned long handle, void *stream);
+/* working precision of the pipelined kernel for this coefficient set: 64, or 32 when every section's rounding-noise gain
+ * (sum of squares of the impulse response of 1/A(z), measured at init) is at most 16 -- poles of radius up to about 0.8 */
+int           llz_iir_cascade_mc_precision(unsigned long handle);
 
 #ifdef __cplusplus
 }

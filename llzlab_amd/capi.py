@@ -133,6 +133,7 @@ def lib():
     sig("llz_iir_cascade_mc_uninit", None, ul)
     sig("llz_iir_cascade_mc", i, ul, vp, vp, i)
     sig("llz_iir_cascade_mc_set_stream", i, ul, vp)
+    sig("llz_iir_cascade_mc_precision", i, ul)
     # llz_resample.h
     sig("llz_decimate_init", ul, i, d, i)
     sig("llz_decimate_uninit", None, ul)

@@ -109,6 +109,7 @@ typedef struct {
     double *d_pd, *d_pl; /* state-transition powers for the pipelined kernel: [S][6][4] and [S][64][12] */
     double *d_state;     /* [channels][stages][x1,x2,y1,y2] */
     int warm_chunks;     /* 1024-sample chunks after which any state error has decayed below 1e-13 (0: unknown / too long) */
+    int float32_ok;      /* every section's rounding-noise gain is small enough for float32 arithmetic */
     void *stream;
     llz_stage_t st_in, st_out;
 } iirm_t;
@@ -204,6 +205,30 @@ static int iirm_memory_chunks(const double *c5, int S)
     return last_loud + 2;                                            /* one chunk of margin */
 }
 
+/* May the pipelined kernel work in float32?  A rounding error e made at a section's output is filtered by the section's
+ * own 1/A(z) before it reaches the next section, so float32 arithmetic adds noise of relative size eps32 * sqrt(sum g^2)
+ * per section, g = impulse response of 1/A(z).  With eps32 = 6e-8 and at most 16 sections, sum g^2 <= 16 keeps the total
+ * near 1e-6, a tenth of the 1e-5 tolerance (0.44-radius poles: 1.2; 0.9-radius: 30; 0.99-radius: 290 -> double).
+ * Measured on each section's actual recurrence, not estimated from pole radii; anything that does not converge within
+ * 4096 samples is left in double. */
+static int iirm_float32_ok(const double *c5, int S)
+{
+    for (int s = 0; s < S; s++) {
+        const double a1 = c5[5 * s + 3], a2 = c5[5 * s + 4];
+        double y1 = 0.0, y2 = 0.0, energy = 0.0, tail = 0.0;
+        for (int n = 0; n < 4096; n++) {
+            const double y = (n == 0 ? 1.0 : 0.0) - a1 * y1 - a2 * y2;
+            y2 = y1; y1 = y;
+            energy += y * y;
+            if (n >= 4096 - 64) tail += y * y;
+        }
+        if (!(energy <= 16.0) || !(tail <= 1e-20 * energy)) return 0;
+        /* the feed-forward gain must not hide a cancellation either: |b| terms of ordinary size */
+        if (!(fabs(c5[5 * s]) + fabs(c5[5 * s + 1]) + fabs(c5[5 * s + 2]) <= 64.0)) return 0;
+    }
+    return 1;
+}
+
 unsigned long llz_iir_cascade_mc_init(int channels, int stages, const double *coef)
 {
     if (channels < 1 || stages < 1 || stages > 16 || !coef) {
@@ -230,6 +255,7 @@ unsigned long llz_iir_cascade_mc_init(int channels, int stages, const double *co
     if (rc == LLZ_OK) rc = llzs_memset(f->d_state, 0, st_bytes, NULL);
     if (rc == LLZ_OK) rc = iirm_build_powers(f, c5);
     if (rc == LLZ_OK) f->warm_chunks = iirm_memory_chunks(c5, stages);
+    if (rc == LLZ_OK) f->float32_ok = iirm_float32_ok(c5, stages);
     if (rc == LLZ_OK) rc = llzs_sync(NULL);
     free(c5);
     if (rc != LLZ_OK) {
@@ -237,6 +263,12 @@ unsigned long llz_iir_cascade_mc_init(int channels, int stages, const double *co
         return LLZ_BAD_HANDLE;
     }
     return (unsigned long)f;
+}
+
+int llz_iir_cascade_mc_precision(unsigned long handle)
+{
+    if (!LLZ_HANDLE_OK(handle, iirm_t, LLZ_TAG_IIRM)) return LLZ_ERR_ARG;
+    return ((iirm_t *)handle)->float32_ok ? 32 : 64;
 }
 
 void llz_iir_cascade_mc_uninit(unsigned long handle)
@@ -281,7 +313,7 @@ int llz_iir_cascade_mc(unsigned long handle, const float *x, float *y, int frame
     const int n_fast = aligned ? frame_len - frame_len % LLZS_IIR_PIPE_CHUNK : 0;
     if (rc == LLZ_OK && n_fast > 0)
         rc = llzs_iir_cascade_pipe_f32(d_in, d_out, f->d_coef, f->d_pd, f->d_pl, f->d_state, f->channels, n_fast,
-                                       frame_len, frame_len, f->stages, f->warm_chunks, f->stream);
+                                       frame_len, frame_len, f->stages, f->warm_chunks, f->float32_ok, f->stream);
     if (rc == LLZ_OK && n_fast < frame_len)
         rc = llzs_iir_cascade_f32(d_in + n_fast, d_out + n_fast, f->d_coef, f->d_state, f->channels,
                                   frame_len - n_fast, frame_len, frame_len, f->stages, f->stream);

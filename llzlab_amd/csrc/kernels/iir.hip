@@ -179,13 +179,30 @@ __device__ __forceinline__ double lane63_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
+// scalar helpers of the pipelined kernel for both working precisions
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_(double v) { return dpp_f64<CTRL, ROW_MASK>(v); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ double lane63_(double v) { return lane63_f64(v); }
+__device__ __forceinline__ float lane63_(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+
+// R = double: the general form.  R = float: taken only when the host has checked every section of the cascade for a low
+// rounding-noise gain (see llz_iir_cascade_mc_init): same algorithm, float32 arithmetic and 4 KB hand-over slots.
+template <typename R>
 __global__ void __launch_bounds__(1024)
-k_iir_cascade_pipe_f32(const float *__restrict__ in, float *__restrict__ out, const double *__restrict__ coef,
+k_iir_cascade_pipe(const float *__restrict__ in, float *__restrict__ out, const double *__restrict__ coef,
                        const double *__restrict__ pd /* [S][6][4] */, const double *__restrict__ pl /* [S][64][12] */,
                        double *__restrict__ state, int nchunks_total, long in_pitch, long out_pitch, int stages,
                        int segs, int seg_chunks, int warm)
 {
-    extern __shared__ __attribute__((aligned(16))) double slots[];        // [stages-1][PIPE_CHUNK]: one per section boundary
+    extern __shared__ __attribute__((aligned(16))) char slots_raw[];
+    R *slots = reinterpret_cast<R *>(slots_raw);        // [stages-1][PIPE_CHUNK]: one per section boundary
     const int lane = threadIdx.x & 63;
     const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // this wave's section (wave-uniform)
     // (3) segments along time when there are too few channels to fill the chip: workgroup (c, seg) owns chunks
@@ -196,26 +213,26 @@ k_iir_cascade_pipe_f32(const float *__restrict__ in, float *__restrict__ out, co
     const int skip = seg > 0 ? warm : 0;                                   // leading chunks computed but not written
     const int chunk0 = seg * seg_chunks - skip;
     const int nchunks = min(nchunks_total, (seg + 1) * seg_chunks) - chunk0;
-    const double b0 = coef[5 * s + 0], b1 = coef[5 * s + 1], b2 = coef[5 * s + 2];
-    const double a1 = coef[5 * s + 3], a2 = coef[5 * s + 4];
-    double P[4][4];                                                       // P^1, P^2, P^4, P^8 (wave-uniform)
+    const R b0 = (R)coef[5 * s + 0], b1 = (R)coef[5 * s + 1], b2 = (R)coef[5 * s + 2];
+    const R a1 = (R)coef[5 * s + 3], a2 = (R)coef[5 * s + 4];
+    R P[4][4];                                                       // P^1, P^2, P^4, P^8 (wave-uniform)
 #pragma unroll
     for (int d = 0; d < 4; d++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) P[d][j] = pd[(s * 6 + d) * 4 + j];
+        for (int j = 0; j < 4; j++) P[d][j] = (R)pd[(s * 6 + d) * 4 + j];
     // per-lane powers: L = P^lane (chunk state), M1 = P^(lane%16 + 1) (row hand-over), M2 = P^(lane%32 + 1) (half)
     const double *plane_tab = pl + (size_t)(s * 64 + lane) * 12;
-    const double L00 = plane_tab[0], L01 = plane_tab[1], L10 = plane_tab[2], L11 = plane_tab[3];
-    const double M1a = plane_tab[4], M1b = plane_tab[5], M1c = plane_tab[6], M1d = plane_tab[7];
-    const double M2a = plane_tab[8], M2b = plane_tab[9], M2c = plane_tab[10], M2d = plane_tab[11];
+    const R L00 = (R)plane_tab[0], L01 = (R)plane_tab[1], L10 = (R)plane_tab[2], L11 = (R)plane_tab[3];
+    const R M1a = (R)plane_tab[4], M1b = (R)plane_tab[5], M1c = (R)plane_tab[6], M1d = (R)plane_tab[7];
+    const R M2a = (R)plane_tab[8], M2b = (R)plane_tab[9], M2c = (R)plane_tab[10], M2d = (R)plane_tab[11];
     double *st = state + ((size_t)c * stages + s) * 4;
-    double su1 = 0.0, su2 = 0.0, sy1 = 0.0, sy2 = 0.0;                   // x(n-1), x(n-2), y(n-1), y(n-2)
-    if (seg == 0) { su1 = st[0]; su2 = st[1]; sy1 = st[2]; sy2 = st[3]; }
+    R su1 = 0, su2 = 0, sy1 = 0, sy2 = 0;                   // x(n-1), x(n-2), y(n-1), y(n-2)
+    if (seg == 0) { su1 = (R)st[0]; su2 = (R)st[1]; sy1 = (R)st[2]; sy2 = (R)st[3]; }
 
     const float *row = in + (size_t)c * in_pitch + (size_t)chunk0 * PIPE_CHUNK + lane * PIPE_R;
     float *orow = out + (size_t)c * out_pitch + (size_t)chunk0 * PIPE_CHUNK + lane * PIPE_R;
-    double *my_in = slots + (size_t)(s > 0 ? s - 1 : 0) * PIPE_CHUNK + lane;    // boundary s-1 | s
-    double *my_out = slots + (size_t)s * PIPE_CHUNK + lane;                      // boundary s | s+1 (unused by the last)
+    R *my_in = slots + (size_t)(s > 0 ? s - 1 : 0) * PIPE_CHUNK + lane;    // boundary s-1 | s
+    R *my_out = slots + (size_t)s * PIPE_CHUNK + lane;                      // boundary s | s+1 (unused by the last)
     const bool first = (s == 0), last = (s == stages - 1);
 
     float4 pre[4];
@@ -227,13 +244,13 @@ k_iir_cascade_pipe_f32(const float *__restrict__ in, float *__restrict__ out, co
     for (int t = 0; t < steps; t++) {
         const int chunk = t - s;
         const bool active = chunk >= 0 && chunk < nchunks;
-        double u[PIPE_R];
+        R u[PIPE_R];
         if (active) {
             if (first) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    u[4 * q + 0] = (double)pre[q].x; u[4 * q + 1] = (double)pre[q].y;
-                    u[4 * q + 2] = (double)pre[q].z; u[4 * q + 3] = (double)pre[q].w;
+                    u[4 * q + 0] = (R)pre[q].x; u[4 * q + 1] = (R)pre[q].y;
+                    u[4 * q + 2] = (R)pre[q].z; u[4 * q + 3] = (R)pre[q].w;
                 }
                 if (chunk + 1 < nchunks) {
 #pragma unroll
@@ -248,65 +265,65 @@ k_iir_cascade_pipe_f32(const float *__restrict__ in, float *__restrict__ out, co
         __syncthreads();                           // every section has taken its input: slots may be rewritten
         if (active) {
             // the two samples in front of this lane: from lane-1, or from the previous chunk for lane 0
-            double um1 = dpp_f64<DPP_WAVE_SHR1, 0xF>(u[PIPE_R - 1]), um2 = dpp_f64<DPP_WAVE_SHR1, 0xF>(u[PIPE_R - 2]);
+            R um1 = dpp_<DPP_WAVE_SHR1, 0xF>(u[PIPE_R - 1]), um2 = dpp_<DPP_WAVE_SHR1, 0xF>(u[PIPE_R - 2]);
             if (lane == 0) { um1 = su1; um2 = su2; }
-            const double nu1 = lane63_f64(u[PIPE_R - 1]), nu2 = lane63_f64(u[PIPE_R - 2]);
+            const R nu1 = lane63_(u[PIPE_R - 1]), nu2 = lane63_(u[PIPE_R - 2]);
             // feed-forward part in place: u[k] <- b0 u[k] + b1 u[k-1] + b2 u[k-2]   (same association as the oracle)
             {
-                double p1 = um1, p2 = um2;
+                R p1 = um1, p2 = um2;
 #pragma unroll
                 for (int k = 0; k < PIPE_R; k++) {
-                    const double x = u[k];
-                    double acc = b0 * x;
-                    acc = __builtin_fma(b1, p1, acc);
-                    acc = __builtin_fma(b2, p2, acc);
+                    const R x = u[k];
+                    R acc = b0 * x;
+                    acc = fma_(b1, p1, acc);
+                    acc = fma_(b2, p2, acc);
                     u[k] = acc;
                     p2 = p1; p1 = x;
                 }
             }
             // zero-state response of this lane's 16 samples -> z = (y[15], y[14])
-            double z1 = 0.0, z2 = 0.0;
+            R z1 = 0.0, z2 = 0.0;
 #pragma unroll
             for (int k = 0; k < PIPE_R; k++) {
                 // the term with the OLDER output first: one DFMA latency per sample on the critical path, not two
-                const double y = __builtin_fma(-a1, z1, __builtin_fma(-a2, z2, u[k]));
+                const R y = fma_(-a1, z1, fma_(-a2, z2, u[k]));
                 z2 = z1; z1 = y;
             }
             // inclusive scan of the affine maps over the lanes, all with DPP moves:
             //   inside each row of 16 lanes: z_l <- z_l + P^d z_(l-d), d = 1,2,4,8 (out-of-row sources read as 0)
 #define LLZ_ROW_STEP(D, SH)                                                                                   \
             {                                                                                                 \
-                const double q1 = dpp_f64<DPP_ROW_SHR + SH, 0xF>(z1), q2 = dpp_f64<DPP_ROW_SHR + SH, 0xF>(z2);   \
-                z1 = __builtin_fma(P[D][0], q1, __builtin_fma(P[D][1], q2, z1));                              \
-                z2 = __builtin_fma(P[D][2], q1, __builtin_fma(P[D][3], q2, z2));                              \
+                const R q1 = dpp_<DPP_ROW_SHR + SH, 0xF>(z1), q2 = dpp_<DPP_ROW_SHR + SH, 0xF>(z2);   \
+                z1 = fma_(P[D][0], q1, fma_(P[D][1], q2, z1));                              \
+                z2 = fma_(P[D][2], q1, fma_(P[D][3], q2, z2));                              \
             }
             LLZ_ROW_STEP(0, 1) LLZ_ROW_STEP(1, 2) LLZ_ROW_STEP(2, 4) LLZ_ROW_STEP(3, 8)
 #undef LLZ_ROW_STEP
             //   rows 1 and 3 take the total of the row before them, advanced by (lane%16 + 1) lanes
             {
-                const double q1 = dpp_f64<DPP_BCAST15, 0xA>(z1), q2 = dpp_f64<DPP_BCAST15, 0xA>(z2);
-                z1 = __builtin_fma(M1a, q1, __builtin_fma(M1b, q2, z1));
-                z2 = __builtin_fma(M1c, q1, __builtin_fma(M1d, q2, z2));
+                const R q1 = dpp_<DPP_BCAST15, 0xA>(z1), q2 = dpp_<DPP_BCAST15, 0xA>(z2);
+                z1 = fma_(M1a, q1, fma_(M1b, q2, z1));
+                z2 = fma_(M1c, q1, fma_(M1d, q2, z2));
             }
             //   the upper half takes the total of the lower half, advanced by (lane%32 + 1) lanes
             {
-                const double q1 = dpp_f64<DPP_BCAST31, 0xC>(z1), q2 = dpp_f64<DPP_BCAST31, 0xC>(z2);
-                z1 = __builtin_fma(M2a, q1, __builtin_fma(M2b, q2, z1));
-                z2 = __builtin_fma(M2c, q1, __builtin_fma(M2d, q2, z2));
+                const R q1 = dpp_<DPP_BCAST31, 0xC>(z1), q2 = dpp_<DPP_BCAST31, 0xC>(z2);
+                z1 = fma_(M2a, q1, fma_(M2b, q2, z1));
+                z2 = fma_(M2c, q1, fma_(M2d, q2, z2));
             }
             // exact state in front of this lane: exclusive prefix + P^lane applied to the chunk's incoming state
-            const double e1 = dpp_f64<DPP_WAVE_SHR1, 0xF>(z1), e2 = dpp_f64<DPP_WAVE_SHR1, 0xF>(z2);
-            double y1 = __builtin_fma(L00, sy1, __builtin_fma(L01, sy2, e1));
-            double y2 = __builtin_fma(L10, sy1, __builtin_fma(L11, sy2, e2));
+            const R e1 = dpp_<DPP_WAVE_SHR1, 0xF>(z1), e2 = dpp_<DPP_WAVE_SHR1, 0xF>(z2);
+            R y1 = fma_(L00, sy1, fma_(L01, sy2, e1));
+            R y2 = fma_(L10, sy1, fma_(L11, sy2, e2));
             // the true recurrence from that state
 #pragma unroll
             for (int k = 0; k < PIPE_R; k++) {
-                const double y = __builtin_fma(-a1, y1, __builtin_fma(-a2, y2, u[k]));
+                const R y = fma_(-a1, y1, fma_(-a2, y2, u[k]));
                 u[k] = y;
                 y2 = y1; y1 = y;
             }
             su1 = nu1; su2 = nu2;
-            sy1 = lane63_f64(y1); sy2 = lane63_f64(y2);
+            sy1 = lane63_(y1); sy2 = lane63_(y2);
             if (last) {
                 float *dst = orow + (size_t)chunk * PIPE_CHUNK;
                 if (chunk >= skip) {                              // warm-up chunks of a later segment are not written
@@ -322,7 +339,7 @@ k_iir_cascade_pipe_f32(const float *__restrict__ in, float *__restrict__ out, co
         }
         __syncthreads();                           // outputs visible before the next step's reads
     }
-    if (lane == 0 && seg == segs - 1) { st[0] = su1; st[1] = su2; st[2] = sy1; st[3] = sy2; }
+    if (lane == 0 && seg == segs - 1) { st[0] = (double)su1; st[1] = (double)su2; st[2] = (double)sy1; st[3] = (double)sy2; }
 }
 
 } // namespace
@@ -368,7 +385,7 @@ extern "C" int llzs_iir_cascade_f32(const float *in, float *out, const double *c
 // the rows 16-byte aligned (pitches % 4 == 0); the caller runs the remainder through llzs_iir_cascade_f32.
 extern "C" int llzs_iir_cascade_pipe_f32(const float *in, float *out, const double *coef, const double *pd,
                                          const double *pl, double *state, int channels, int n, long in_pitch,
-                                         long out_pitch, int stages, int warm_chunks, void *stream)
+                                         long out_pitch, int stages, int warm_chunks, int float32_ok, void *stream)
 {
     if (!in || !out || !coef || !pd || !pl || !state || channels <= 0 || n <= 0 || (n % PIPE_CHUNK) ||
         stages < 1 || stages > 16 || in_pitch < n || out_pitch < n || (in_pitch & 3) || (out_pitch & 3) ||
@@ -377,9 +394,10 @@ extern "C" int llzs_iir_cascade_pipe_f32(const float *in, float *out, const doub
                        PIPE_CHUNK);
         return LLZ_ERR_ARG;
     }
-    const size_t lds = (size_t)(stages > 1 ? stages - 1 : 1) * PIPE_CHUNK * sizeof(double);
+    const bool f32 = float32_ok && !getenv("LLZ_IIR_F64");
+    const size_t lds = (size_t)(stages > 1 ? stages - 1 : 1) * PIPE_CHUNK * (f32 ? sizeof(float) : sizeof(double));
     if (lds > 64 * 1024)
-        LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_iir_cascade_pipe_f32),
+        LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_iir_cascade_pipe<double>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // time segments: only when the channels alone leave most of the chip idle (fewer than two workgroups per CU) and the
     // warm-up stays a small part of a segment
@@ -393,9 +411,14 @@ extern "C" int llzs_iir_cascade_pipe_f32(const float *in, float *out, const doub
     if (const char *e = getenv("LLZ_IIR_SEGS")) { const int v = atoi(e); if (v >= 1 && v <= 64 && (v == 1 || warm_chunks > 0)) segs = v; }
     const int seg_chunks = (nchunks + segs - 1) / segs;
     segs = (nchunks + seg_chunks - 1) / seg_chunks;
-    hipLaunchKernelGGL(k_iir_cascade_pipe_f32, dim3((unsigned)((long)channels * segs)), dim3(64 * stages), lds,
-                       as_stream(stream), in, out, coef, pd, pl, state, nchunks, in_pitch, out_pitch, stages, segs,
-                       seg_chunks, warm_chunks);
+    if (f32)
+        hipLaunchKernelGGL(k_iir_cascade_pipe<float>, dim3((unsigned)((long)channels * segs)), dim3(64 * stages), lds,
+                           as_stream(stream), in, out, coef, pd, pl, state, nchunks, in_pitch, out_pitch, stages, segs,
+                           seg_chunks, warm_chunks);
+    else
+        hipLaunchKernelGGL(k_iir_cascade_pipe<double>, dim3((unsigned)((long)channels * segs)), dim3(64 * stages), lds,
+                           as_stream(stream), in, out, coef, pd, pl, state, nchunks, in_pitch, out_pitch, stages, segs,
+                           seg_chunks, warm_chunks);
     LLZ_LAUNCH_CHECK("k_iir_cascade_pipe_f32");
     return LLZ_OK;
 }

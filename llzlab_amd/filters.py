@@ -195,6 +195,7 @@ class IirCascadeMC:
         self.channels = channels
         self.handle = check_handle(self._L.llz_iir_cascade_mc_init(channels, self.stages, coef.ctypes.data),
                                    "llz_iir_cascade_mc_init")
+        self.precision = self._L.llz_iir_cascade_mc_precision(self.handle)      # 32 or 64 (arithmetic of the fast kernel)
         if stream is not None:
             check(self._L.llz_iir_cascade_mc_set_stream(self.handle, _stream_ptr(stream)), "set_stream")
 

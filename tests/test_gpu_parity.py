@@ -473,6 +473,33 @@ def test_fft_fixed_wraps_like_the_reference_arithmetic(dev, oracle):
     f.close()
 
 
+@pytest.mark.parametrize("radius,theta", [(0.44, 1.1), (0.7, 0.5), (0.8, 2.0), (0.9, 0.3)])
+@pytest.mark.parametrize("channels,n", [(3, 1024 * 6), (2, 1024 * 200)])
+def test_iir_cascade_low_q_float32_path(dev, oracle, radius, theta, channels, n):
+    """cascades whose sections all have a small rounding-noise gain (measured at init) run the pipelined kernel in
+    float32; the 0.9-radius set fails that check and stays in double.  Either way the result must meet the tolerance
+    against the double oracle, in one call, split along time (2 channels x 200 chunks) and across calls"""
+    a1, a2 = -2 * radius * np.cos(theta), radius ** 2
+    g = (1 + a1 + a2) / 4                                               # unit DC gain with b = g * [1, 2, 1]
+    coef = np.tile(np.array([g, 2 * g, g, 1.0, a1, a2]), (8, 1))
+    x = oracle.synth_f32(channels, n + 2048, seed=int(radius * 100))
+    ref = oracle.iir_cascade_batch_f32(x, coef)
+    f = filters.IirCascadeMC(channels, coef)
+    assert f.precision == (64 if radius >= 0.9 else 32)
+    outs = []
+    for (o, e) in ((0, n), (n, n + 2048)):
+        xi = torch.from_numpy(np.ascontiguousarray(x[:, o:e])).to(dev)
+        yi = torch.empty_like(xi)
+        f.filter(xi, yi)
+        outs.append(yi.cpu().numpy())
+    f.close()
+    got = np.concatenate(outs, axis=1).astype(np.float64)
+    err, scale = float(np.sqrt(np.mean((got - ref) ** 2))), float(np.sqrt(np.mean(ref ** 2)))
+    # (radius 0.8 at 2 rad resonates far above the DC gain: eight sections give an output RMS of ~60, so the bound is
+    # relative to the signal there and absolute at unit scale)
+    assert err <= TOL * max(1.0, scale) and err / scale <= TOL, (radius, theta, err, scale)
+
+
 def test_iir_cascade_few_channels_split_along_time(dev, oracle):
     """few channels and a long frame: the pipelined kernel splits each channel into time segments that start a measured
     warm-up early from the zero state (the cascade's memory, probed at init); the result must still match the sequential
