@@ -132,7 +132,7 @@ static void mat2_mul(const double *a, const double *b, double *o)
 
 /* transition matrices of the feedback recurrence (y[n-1], y[n-2]) -> 16 samples later, its powers of two for the
  * lane scan and its lane-th powers: see k_iir_cascade_pipe_f32 */
-static int iirm_build_powers(iirm_t *f, const double *c5)
+static int iirm_build_powers(iirm_t *f, const double *c5, int lane_run)
 {
     const int S = f->stages;
     double *pd = (double *)malloc(sizeof(double) * (size_t)S * 6 * 4);
@@ -142,7 +142,7 @@ static int iirm_build_powers(iirm_t *f, const double *c5)
         for (int s = 0; s < S; s++) {
             const double A[4] = {-c5[5 * s + 3], -c5[5 * s + 4], 1.0, 0.0};
             double P[4] = {1.0, 0.0, 0.0, 1.0};
-            for (int i = 0; i < 16; i++) mat2_mul(A, P, P);            /* P = A^16 */
+            for (int i = 0; i < lane_run; i++) mat2_mul(A, P, P);      /* P = A^lane_run (16 or 32 samples per lane) */
             double *d = pd + (size_t)s * 24;
             memcpy(d, P, sizeof(P));
             for (int k = 1; k < 6; k++) mat2_mul(d + 4 * (k - 1), d + 4 * (k - 1), d + 4 * k);
@@ -253,9 +253,9 @@ unsigned long llz_iir_cascade_mc_init(int channels, int stages, const double *co
     }
     if (rc == LLZ_OK) rc = llzs_h2d(f->d_coef, c5, sizeof(double) * 5 * (size_t)stages, NULL);
     if (rc == LLZ_OK) rc = llzs_memset(f->d_state, 0, st_bytes, NULL);
-    if (rc == LLZ_OK) rc = iirm_build_powers(f, c5);
+    if (rc == LLZ_OK) f->float32_ok = iirm_float32_ok(c5, stages) && !getenv("LLZ_IIR_F64");   /* env: A/B runs */
+    if (rc == LLZ_OK) rc = iirm_build_powers(f, c5, 16);
     if (rc == LLZ_OK) f->warm_chunks = iirm_memory_chunks(c5, stages);
-    if (rc == LLZ_OK) f->float32_ok = iirm_float32_ok(c5, stages);
     if (rc == LLZ_OK) rc = llzs_sync(NULL);
     free(c5);
     if (rc != LLZ_OK) {
@@ -310,7 +310,8 @@ int llz_iir_cascade_mc(unsigned long handle, const float *x, float *y, int frame
     /* whole 1024-sample chunks go through the pipelined kernel (needs 16-byte aligned rows), the ragged remainder
      * through the one-lane-per-channel kernel; both read and write the same per-section state */
     const int aligned = (frame_len % 4 == 0) && (((size_t)d_in | (size_t)d_out) % 16 == 0);
-    const int n_fast = aligned ? frame_len - frame_len % LLZS_IIR_PIPE_CHUNK : 0;
+    const int chunk = LLZS_IIR_PIPE_CHUNK;
+    const int n_fast = aligned ? frame_len - frame_len % chunk : 0;
     if (rc == LLZ_OK && n_fast > 0)
         rc = llzs_iir_cascade_pipe_f32(d_in, d_out, f->d_coef, f->d_pd, f->d_pl, f->d_state, f->channels, n_fast,
                                        frame_len, frame_len, f->stages, f->warm_chunks, f->float32_ok, f->stream);

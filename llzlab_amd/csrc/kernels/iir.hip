@@ -154,8 +154,6 @@ k_iir_cascade_f32(const float *__restrict__ in, float *__restrict__ out, const d
 //
 // Bound: FP64 VALU (56 DFMA per sample for 8 sections) is within a factor ~1 of the HBM time for 8 B/sample; the
 // kernel is compute/latency bound, not a streaming kernel.
-constexpr int PIPE_R = 16;                       // samples per lane and chunk
-constexpr int PIPE_CHUNK = 64 * PIPE_R;          // 1024
 
 // cross-lane moves of a double as two DPP dword moves (VALU, no LDS round trip). Lanes whose source is out of
 // range, or whose row is masked off, receive 0.0.
@@ -194,7 +192,8 @@ __device__ __forceinline__ float lane63_(float v) { return __int_as_float(__buil
 
 // R = double: the general form.  R = float: taken only when the host has checked every section of the cascade for a low
 // rounding-noise gain (see llz_iir_cascade_mc_init): same algorithm, float32 arithmetic and 4 KB hand-over slots.
-template <typename R>
+// RR samples per lane and chunk (16 in both shipped instantiations)
+template <typename R, int RR>
 __global__ void __launch_bounds__(1024)
 k_iir_cascade_pipe(const float *__restrict__ in, float *__restrict__ out, const double *__restrict__ coef,
                        const double *__restrict__ pd /* [S][6][4] */, const double *__restrict__ pl /* [S][64][12] */,
@@ -202,7 +201,7 @@ k_iir_cascade_pipe(const float *__restrict__ in, float *__restrict__ out, const 
                        int segs, int seg_chunks, int warm)
 {
     extern __shared__ __attribute__((aligned(16))) char slots_raw[];
-    R *slots = reinterpret_cast<R *>(slots_raw);        // [stages-1][PIPE_CHUNK]: one per section boundary
+    R *slots = reinterpret_cast<R *>(slots_raw);        // [stages-1][(64 * RR)]: one per section boundary
     const int lane = threadIdx.x & 63;
     const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // this wave's section (wave-uniform)
     // (3) segments along time when there are too few channels to fill the chip: workgroup (c, seg) owns chunks
@@ -229,50 +228,50 @@ k_iir_cascade_pipe(const float *__restrict__ in, float *__restrict__ out, const 
     R su1 = 0, su2 = 0, sy1 = 0, sy2 = 0;                   // x(n-1), x(n-2), y(n-1), y(n-2)
     if (seg == 0) { su1 = (R)st[0]; su2 = (R)st[1]; sy1 = (R)st[2]; sy2 = (R)st[3]; }
 
-    const float *row = in + (size_t)c * in_pitch + (size_t)chunk0 * PIPE_CHUNK + lane * PIPE_R;
-    float *orow = out + (size_t)c * out_pitch + (size_t)chunk0 * PIPE_CHUNK + lane * PIPE_R;
-    R *my_in = slots + (size_t)(s > 0 ? s - 1 : 0) * PIPE_CHUNK + lane;    // boundary s-1 | s
-    R *my_out = slots + (size_t)s * PIPE_CHUNK + lane;                      // boundary s | s+1 (unused by the last)
+    const float *row = in + (size_t)c * in_pitch + (size_t)chunk0 * (64 * RR) + lane * RR;
+    float *orow = out + (size_t)c * out_pitch + (size_t)chunk0 * (64 * RR) + lane * RR;
+    R *my_in = slots + (size_t)(s > 0 ? s - 1 : 0) * (64 * RR) + lane;    // boundary s-1 | s
+    R *my_out = slots + (size_t)s * (64 * RR) + lane;                      // boundary s | s+1 (unused by the last)
     const bool first = (s == 0), last = (s == stages - 1);
 
-    float4 pre[4];
+    float4 pre[RR / 4];
     if (first && nchunks > 0) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) pre[q] = *reinterpret_cast<const float4 *>(row + 4 * q);
+        for (int q = 0; q < RR / 4; q++) pre[q] = *reinterpret_cast<const float4 *>(row + 4 * q);
     }
     const int steps = nchunks + stages - 1;
     for (int t = 0; t < steps; t++) {
         const int chunk = t - s;
         const bool active = chunk >= 0 && chunk < nchunks;
-        R u[PIPE_R];
+        R u[RR];
         if (active) {
             if (first) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < RR / 4; q++) {
                     u[4 * q + 0] = (R)pre[q].x; u[4 * q + 1] = (R)pre[q].y;
                     u[4 * q + 2] = (R)pre[q].z; u[4 * q + 3] = (R)pre[q].w;
                 }
                 if (chunk + 1 < nchunks) {
 #pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        pre[q] = *reinterpret_cast<const float4 *>(row + (size_t)(chunk + 1) * PIPE_CHUNK + 4 * q);
+                    for (int q = 0; q < RR / 4; q++)
+                        pre[q] = *reinterpret_cast<const float4 *>(row + (size_t)(chunk + 1) * (64 * RR) + 4 * q);
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < PIPE_R; k++) u[k] = my_in[k * 64];
+                for (int k = 0; k < RR; k++) u[k] = my_in[k * 64];
             }
         }
         __syncthreads();                           // every section has taken its input: slots may be rewritten
         if (active) {
             // the two samples in front of this lane: from lane-1, or from the previous chunk for lane 0
-            R um1 = dpp_<DPP_WAVE_SHR1, 0xF>(u[PIPE_R - 1]), um2 = dpp_<DPP_WAVE_SHR1, 0xF>(u[PIPE_R - 2]);
+            R um1 = dpp_<DPP_WAVE_SHR1, 0xF>(u[RR - 1]), um2 = dpp_<DPP_WAVE_SHR1, 0xF>(u[RR - 2]);
             if (lane == 0) { um1 = su1; um2 = su2; }
-            const R nu1 = lane63_(u[PIPE_R - 1]), nu2 = lane63_(u[PIPE_R - 2]);
+            const R nu1 = lane63_(u[RR - 1]), nu2 = lane63_(u[RR - 2]);
             // feed-forward part in place: u[k] <- b0 u[k] + b1 u[k-1] + b2 u[k-2]   (same association as the oracle)
             {
                 R p1 = um1, p2 = um2;
 #pragma unroll
-                for (int k = 0; k < PIPE_R; k++) {
+                for (int k = 0; k < RR; k++) {
                     const R x = u[k];
                     R acc = b0 * x;
                     acc = fma_(b1, p1, acc);
@@ -284,7 +283,7 @@ k_iir_cascade_pipe(const float *__restrict__ in, float *__restrict__ out, const 
             // zero-state response of this lane's 16 samples -> z = (y[15], y[14])
             R z1 = 0.0, z2 = 0.0;
 #pragma unroll
-            for (int k = 0; k < PIPE_R; k++) {
+            for (int k = 0; k < RR; k++) {
                 // the term with the OLDER output first: one DFMA latency per sample on the critical path, not two
                 const R y = fma_(-a1, z1, fma_(-a2, z2, u[k]));
                 z2 = z1; z1 = y;
@@ -317,7 +316,7 @@ k_iir_cascade_pipe(const float *__restrict__ in, float *__restrict__ out, const 
             R y2 = fma_(L10, sy1, fma_(L11, sy2, e2));
             // the true recurrence from that state
 #pragma unroll
-            for (int k = 0; k < PIPE_R; k++) {
+            for (int k = 0; k < RR; k++) {
                 const R y = fma_(-a1, y1, fma_(-a2, y2, u[k]));
                 u[k] = y;
                 y2 = y1; y1 = y;
@@ -325,16 +324,16 @@ k_iir_cascade_pipe(const float *__restrict__ in, float *__restrict__ out, const 
             su1 = nu1; su2 = nu2;
             sy1 = lane63_(y1); sy2 = lane63_(y2);
             if (last) {
-                float *dst = orow + (size_t)chunk * PIPE_CHUNK;
+                float *dst = orow + (size_t)chunk * (64 * RR);
                 if (chunk >= skip) {                              // warm-up chunks of a later segment are not written
 #pragma unroll
-                    for (int q = 0; q < 4; q++)
+                    for (int q = 0; q < RR / 4; q++)
                         *reinterpret_cast<float4 *>(dst + 4 * q) = make_float4((float)u[4 * q], (float)u[4 * q + 1],
                                                                                 (float)u[4 * q + 2], (float)u[4 * q + 3]);
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < PIPE_R; k++) my_out[k * 64] = u[k];
+                for (int k = 0; k < RR; k++) my_out[k * 64] = u[k];
             }
         }
         __syncthreads();                           // outputs visible before the next step's reads
@@ -385,40 +384,48 @@ extern "C" int llzs_iir_cascade_f32(const float *in, float *out, const double *c
 // the rows 16-byte aligned (pitches % 4 == 0); the caller runs the remainder through llzs_iir_cascade_f32.
 extern "C" int llzs_iir_cascade_pipe_f32(const float *in, float *out, const double *coef, const double *pd,
                                          const double *pl, double *state, int channels, int n, long in_pitch,
-                                         long out_pitch, int stages, int warm_chunks, int float32_ok, void *stream)
+                                         long out_pitch, int stages, int warm_chunks, int float32, void *stream)
 {
-    if (!in || !out || !coef || !pd || !pl || !state || channels <= 0 || n <= 0 || (n % PIPE_CHUNK) ||
+    // 16 samples per lane in both precisions: 32 in float32 measured slower (4.27 vs 3.62 ms: 128 VGPRs with spills under
+    // the 1024-thread bound, and twice as long dependent recurrences per lane)
+    const int RR = 16, chunk = 64 * RR;
+    if (!in || !out || !coef || !pd || !pl || !state || channels <= 0 || n <= 0 || (n % chunk) ||
         stages < 1 || stages > 16 || in_pitch < n || out_pitch < n || (in_pitch & 3) || (out_pitch & 3) ||
         (reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) {
         llzs_set_error("iir_cascade_pipe_f32: bad arguments (n=%d must be a multiple of %d, rows 16-byte aligned)", n,
-                       PIPE_CHUNK);
+                       chunk);
         return LLZ_ERR_ARG;
     }
-    const bool f32 = float32_ok && !getenv("LLZ_IIR_F64");
-    const size_t lds = (size_t)(stages > 1 ? stages - 1 : 1) * PIPE_CHUNK * (f32 ? sizeof(float) : sizeof(double));
-    if (lds > 64 * 1024)
-        LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_iir_cascade_pipe<double>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = (size_t)(stages > 1 ? stages - 1 : 1) * chunk * (float32 ? sizeof(float) : sizeof(double));
+    if (lds > 64 * 1024) {
+        if (float32)
+            LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_iir_cascade_pipe<float, 16>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else
+            LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_iir_cascade_pipe<double, 16>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     // time segments: only when the channels alone leave most of the chip idle (fewer than two workgroups per CU) and the
-    // warm-up stays a small part of a segment
-    const int nchunks = n / PIPE_CHUNK;
+    // warm-up stays a small part of a segment.  warm_chunks counts 1024-sample chunks.
+    const int nchunks = n / chunk;
+    const int warm = (warm_chunks * 1024 + chunk - 1) / chunk;
     int segs = 1;
     if (warm_chunks > 0 && channels < 512) {
         segs = (512 + channels - 1) / channels;
         if (segs > 16) segs = 16;
-        while (segs > 1 && nchunks / segs < 8 * warm_chunks) segs--;
+        while (segs > 1 && nchunks / segs < 8 * warm) segs--;
     }
     if (const char *e = getenv("LLZ_IIR_SEGS")) { const int v = atoi(e); if (v >= 1 && v <= 64 && (v == 1 || warm_chunks > 0)) segs = v; }
     const int seg_chunks = (nchunks + segs - 1) / segs;
     segs = (nchunks + seg_chunks - 1) / seg_chunks;
-    if (f32)
-        hipLaunchKernelGGL(k_iir_cascade_pipe<float>, dim3((unsigned)((long)channels * segs)), dim3(64 * stages), lds,
+    if (float32)
+        hipLaunchKernelGGL((k_iir_cascade_pipe<float, 16>), dim3((unsigned)((long)channels * segs)), dim3(64 * stages), lds,
                            as_stream(stream), in, out, coef, pd, pl, state, nchunks, in_pitch, out_pitch, stages, segs,
-                           seg_chunks, warm_chunks);
+                           seg_chunks, warm);
     else
-        hipLaunchKernelGGL(k_iir_cascade_pipe<double>, dim3((unsigned)((long)channels * segs)), dim3(64 * stages), lds,
+        hipLaunchKernelGGL((k_iir_cascade_pipe<double, 16>), dim3((unsigned)((long)channels * segs)), dim3(64 * stages), lds,
                            as_stream(stream), in, out, coef, pd, pl, state, nchunks, in_pitch, out_pitch, stages, segs,
-                           seg_chunks, warm_chunks);
-    LLZ_LAUNCH_CHECK("k_iir_cascade_pipe_f32");
+                           seg_chunks, warm);
+    LLZ_LAUNCH_CHECK("k_iir_cascade_pipe");
     return LLZ_OK;
 }

@@ -63,11 +63,12 @@ int llzs_iir_cascade_f32(const float *in, float *out, const double *coef, double
                          int channels, int n, long in_pitch, long out_pitch, int stages, void *stream);
 /* fast path (stage pipeline + lanes along time): n % 1024 == 0, 16-byte aligned rows.  pd = [stages][6][4] powers
  * P^(2^d) of P = A^16 with A = [[-a1,-a2],[1,0]], pl = [stages][64][12] = P^lane, P^(lane%16+1), P^(lane%32+1); same coef / state layout as above. */
-#define LLZS_IIR_PIPE_CHUNK 1024
+#define LLZS_IIR_PIPE_CHUNK 1024     /* 64 lanes x 16 samples */
 int llzs_iir_cascade_pipe_f32(const float *in, float *out, const double *coef, const double *pd, const double *pl,
                               double *state, int channels, int n, long in_pitch, long out_pitch, int stages,
                               int warm_chunks /* 0: never split a channel along time */,
-                              int float32_ok /* 1: every section passed the host's noise-gain check */, void *stream);
+                              int float32 /* 1: float32 arithmetic (every section passed the host's noise-gain check) */,
+                              void *stream);
 /* general direct form I, one channel, double, the reference's exact operation order (llz_iir.c:103-132).
  * xs: N+1 doubles, ys: M+1 doubles (delay lines, read and written) */
 int llzs_iir_df1_f64(const double *in, double *out, const double *a, const double *b, double *xs, double *ys,
