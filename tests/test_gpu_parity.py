@@ -818,3 +818,55 @@ def test_fir_ols_chain_form_forced(dev):
     env = dict(os.environ, LLZ_OLS_VARIANT="7", LLZ_REPO=ROOT)
     r = subprocess.run([sys.executable, "-c", _CHAIN_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "CHAIN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------ limits and degenerate calls
+def test_limits_and_degenerate_calls(dev, oracle):
+    """the largest channel count the batch handles accept, one-sample frames, and refused calls: zero-length frames and
+    out-of-range shapes come back as errors (negative code / (unsigned long)-1 with a message), never as a crash"""
+    taps = oracle.fir_design(po.LPF, 5, 0.3, 0.0, po.HAMMING)
+    # 65535 channels (the grid.y limit of the tile kernels) x 64 samples; spot-check the ends and the middle
+    ch, n = 65535, 64
+    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+    filters.synth_f32(x[:1000], seed=3)
+    x[1000:] = x[:1000].repeat(65, 1)[:ch - 1000]
+    y = torch.empty_like(x)
+    f = filters.FirFilterMC(ch, n, taps)
+    f.filter(x, y)
+    sel = [0, 1, 32767, 65533, 65534]
+    ref = oracle.fir_batch_f32(x[sel].cpu().numpy(), taps.astype(np.float32).astype(np.float64))
+    rms_check(y[sel].cpu().numpy(), ref, "fir 65535 channels")
+    f.close()
+    with pytest.raises(capi.LlzError):
+        filters.FirFilterMC(65536, n, taps)
+    # one-sample frames stream correctly
+    f = filters.FirFilterMC(2, 1, taps)
+    xs = oracle.synth_f32(2, 40, seed=9)
+    out = np.zeros_like(xs)
+    for i in range(40):
+        xi = torch.from_numpy(np.ascontiguousarray(xs[:, i:i + 1])).to(dev)
+        yi = torch.empty_like(xi)
+        f.filter(xi, yi)
+        out[:, i] = yi.cpu().numpy()[:, 0]
+    f.close()
+    rms_check(out, oracle.fir_batch_f32(xs, taps.astype(np.float32).astype(np.float64)), "fir one-sample frames")
+    # refused: zero-length frame, zero channels, zero taps, absurd resample ratio, IIR without stages
+    L = capi.lib()
+    f = filters.FirFilterMC(2, 8, taps)
+    z = torch.empty(2, 8, dtype=torch.float32, device=dev)
+    assert L.llz_fir_filter_mc(f.handle, z.data_ptr(), z.data_ptr(), 0) < 0 and capi.last_error()
+    f.close()
+    for bad in (lambda: filters.FirFilterMC(0, 8, taps), lambda: filters.FirFilterMC(2, 8, np.zeros(0)),
+                lambda: filters.ResampleMC(2, 1, 17, 1.0, po.BLACKMAN, filters.PCM_F32),
+                lambda: filters.IirCascadeMC(2, np.zeros((0, 6))), lambda: filters.FftBatch(48),
+                lambda: filters.StftMC(2, 0, 3), lambda: filters.MdctBatch(100)):
+        with pytest.raises(capi.LlzError):
+            bad()
+    q = filters.IirCascadeMC(70000, np.array([[0.2066, 0.4131, 0.2066, 1.0, -0.3695, 0.1958]]))   # no channel limit here
+    xi = torch.zeros(70000, 16, dtype=torch.float32, device=dev)
+    xi[:, 0] = 1.0
+    yi = torch.empty_like(xi)
+    q.filter(xi, yi)
+    q.close()
+    h = oracle.iir_cascade_batch_f32(xi[:1].cpu().numpy(), np.array([[0.2066, 0.4131, 0.2066, 1.0, -0.3695, 0.1958]]))
+    assert np.abs(yi[[0, 69999]].cpu().numpy() - h).max() < 1e-6
