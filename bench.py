@@ -276,6 +276,24 @@ def sharded_configs(torch, filters, capi, shard, dev, comm_dev, stream, rank, wo
     del x, y
     torch.cuda.empty_cache()
 
+    # config 5, int16 PCM in and out (the reference resampler's own sample format): the bit-exact form (double accumulate
+    # in the reference's order) and the matrix-core form (within 1 LSB of it), same sharding and matrix broadcast
+    xi = torch.empty(ch, n, dtype=torch.int16, device=dev)
+    yi = torch.empty(ch, n // 3, dtype=torch.int16, device=dev)
+    filters.synth_i16(xi, SEED, chan0=lo, stream=stream)
+    for key, fmt, steps in (("resample_1to3_i16_exact_8192ch_sharded", filters.PCM_I16, 1),
+                            ("resample_1to3_i16_fast_8192ch_sharded", filters.PCM_I16_FAST, 3)):
+        r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, fmt, stream=stream)
+        r.set_matrix(mat)
+        ms = timed(lambda: r.process(xi, yi), steps)
+        out[key] = {"Msamples_in_s": total_ch * n / ms / 1e3, "GBs_per_gpu": (2 + 2 / 3) * ch * n / ms / 1e6,
+                    "hbm_frac_per_gpu": (2 + 2 / 3) * ch * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms,
+                    "channels_per_gpu": ch, "scaling": "strong",
+                    "parity": "bit-exact" if fmt == filters.PCM_I16 else "within 1 LSB of the reference"}
+        r.close()
+    del xi, yi
+    torch.cuda.empty_cache()
+
     # config 4: 1024-ch IIR, 8-biquad cascade, 1 Mi samples/ch
     total_ch = 1024
     lo, hi = shard.channel_range(total_ch, rank, world)
