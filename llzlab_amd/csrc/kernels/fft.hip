@@ -526,6 +526,38 @@ __device__ __forceinline__ void fftE(cf (&v)[E])
     }
 }
 
+// the E x E core shared by the square-size kernels: E-point transform, transpose inside the lane group, inter-pass twiddle
+// W_(E*E)^(k1 * l) read as contiguous rows of the symmetric table, E-point transform.  In: v[j] = element lg + E j of the
+// group's transform; out: v[q] = bin lg + E brevE(q).
+template <int E, bool INV>
+__device__ __forceinline__ void square_core(cf (&v)[E], float *buf, const float2 *__restrict__ tw2d, int lg)
+{
+    constexpr int PITCH = E + 1;
+    fftE<E, INV>(v);
+#pragma unroll
+    for (int q = 0; q < E; q++) buf[brevE<E>(q) * PITCH + lg] = v[q].x;
+    OLS_WAVE_SYNC();
+#pragma unroll
+    for (int cidx = 0; cidx < E; cidx++) v[cidx].x = buf[lg * PITCH + cidx];
+    OLS_WAVE_SYNC();
+#pragma unroll
+    for (int q = 0; q < E; q++) buf[brevE<E>(q) * PITCH + lg] = v[q].y;
+    OLS_WAVE_SYNC();
+#pragma unroll
+    for (int cidx = 0; cidx < E; cidx++) v[cidx].y = buf[lg * PITCH + cidx];
+    OLS_WAVE_SYNC();
+#pragma unroll
+    for (int l0 = 0; l0 < E; l0 += 8) {
+#pragma unroll
+        for (int l = l0; l < l0 + 8; l++) {
+            const float2 w = tw2d[l * E + lg];
+            v[l] = cmul<INV>(v[l], cf{w.x, w.y});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    fftE<E, INV>(v);
+}
+
 // tw2d: [E][E] float2, entry [k1][l] = exp(-2 pi j k1 l / N); one transform per group of E lanes, 256 / E per workgroup
 template <int E, bool INV>
 __global__ void __launch_bounds__(256)
@@ -549,35 +581,78 @@ k_fft_square_f32(float *__restrict__ data, int count, const float2 *__restrict__
         const f32x2 x = __builtin_nontemporal_load(&g[lg + E * j]);
         v[j] = INV ? cf{x.x * (1.0f / N), x.y * (1.0f / N)} : cf{x.x, x.y};
     }
-    fftE<E, INV>(v);                                            // v[q] = Y[k1 = brevE(q)] of column lg
-    // two single-plane E x E transposes inside the group (the lanes of a group run in lockstep inside one wave)
-#pragma unroll
-    for (int q = 0; q < E; q++) buf[brevE<E>(q) * PITCH + lg] = v[q].x;
-    OLS_WAVE_SYNC();
-#pragma unroll
-    for (int cidx = 0; cidx < E; cidx++) v[cidx].x = buf[lg * PITCH + cidx];
-    OLS_WAVE_SYNC();
-#pragma unroll
-    for (int q = 0; q < E; q++) buf[brevE<E>(q) * PITCH + lg] = v[q].y;
-    OLS_WAVE_SYNC();
-#pragma unroll
-    for (int cidx = 0; cidx < E; cidx++) v[cidx].y = buf[lg * PITCH + cidx];
-    OLS_WAVE_SYNC();
-    // inter-pass twiddle after the transpose: lane k1 = lg needs W^(k1 * l) for l = 0..E-1 = tw2d[l][k1] (the table is
-    // symmetric), a contiguous row per l across the group.  In chunks of eight so that the loads do not all go live at once
-#pragma unroll
-    for (int l0 = 0; l0 < E; l0 += 8) {
-#pragma unroll
-        for (int l = l0; l < l0 + 8; l++) {
-            const float2 w = tw2d[l * E + lg];
-            v[l] = cmul<INV>(v[l], cf{w.x, w.y});
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    fftE<E, INV>(v);                                            // v[q] = X[lg + E brevE(q)]
+    square_core<E, INV>(v, buf, tw2d, lg);                      // v[q] = X[lg + E brevE(q)]
 #pragma unroll
     for (int q = 0; q < E; q++)
         __builtin_nontemporal_store((f32x2){v[q].x, v[q].y}, &g[lg + E * brevE<E>(q)]);
+}
+
+// N = 2 E^2 (E = 16: 512, E = 32: 2048): one radix-2 step around two E x E transforms held by the same lane group.
+//   forward: s = x[n] + x[n + N/2], d = (x[n] - x[n + N/2]) W_N^n;  X[2k] = F(s)[k], X[2k+1] = F(d)[k]  (stored as one
+//            16-byte pair per lane);
+//   inverse: the mirror image, 1/N folded into the loads.
+// tw1: [E][E] float2, entry [j][l] = W_N^(l + E j).
+template <int E, bool INV>
+__global__ void __launch_bounds__(256)
+k_fft_2xsquare_f32(float *__restrict__ data, int count, const float2 *__restrict__ tw2d, const float2 *__restrict__ tw1)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int H = E * E, N = 2 * H, GROUPS = 256 / E, PITCH = E + 1;
+    __shared__ float bufs[GROUPS][E * PITCH];
+    const int tid = threadIdx.x, grp = tid / E, lg = tid % E;
+    const long t = (long)blockIdx.x * GROUPS + grp;
+    if (t >= count) return;
+    float *base = data + t * (2 * N);
+    f32x2 *g2 = reinterpret_cast<f32x2 *>(base);
+    f32x4 *g4 = reinterpret_cast<f32x4 *>(base);
+    float *buf = bufs[grp];
+    cf s[E], d[E];
+    if (!INV) {
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const f32x2 a = __builtin_nontemporal_load(&g2[lg + E * j]);
+            const f32x2 b = __builtin_nontemporal_load(&g2[lg + E * j + H]);
+            const float2 w = tw1[j * E + lg];
+            s[j] = cf{a.x + b.x, a.y + b.y};
+            d[j] = cmul<false>(cf{a.x - b.x, a.y - b.y}, cf{w.x, w.y});
+        }
+        square_core<E, false>(s, buf, tw2d, lg);
+        square_core<E, false>(d, buf, tw2d, lg);
+#pragma unroll
+        for (int q = 0; q < E; q++)                                   // bins 2k and 2k+1, k = lg + E brevE(q)
+            __builtin_nontemporal_store((f32x4){s[q].x, s[q].y, d[q].x, d[q].y}, &g4[lg + E * brevE<E>(q)]);
+    } else {
+        constexpr float sc = 1.0f / N;
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const f32x4 x = __builtin_nontemporal_load(&g4[lg + E * j]);
+            s[j] = cf{x.x * sc, x.y * sc};
+            d[j] = cf{x.z * sc, x.w * sc};
+        }
+        square_core<E, true>(s, buf, tw2d, lg);
+        square_core<E, true>(d, buf, tw2d, lg);
+#pragma unroll
+        for (int q = 0; q < E; q++) {                                 // n = lg + E brevE(q)
+            const float2 w = tw1[brevE<E>(q) * E + lg];
+            const cf wd = cmul<true>(d[q], cf{w.x, w.y});             // d * conj(W_N^n)
+            __builtin_nontemporal_store((f32x2){s[q].x + wd.x, s[q].y + wd.y}, &g2[lg + E * brevE<E>(q)]);
+            __builtin_nontemporal_store((f32x2){s[q].x - wd.x, s[q].y - wd.y}, &g2[lg + E * brevE<E>(q) + H]);
+        }
+    }
+}
+
+// tables of the 2 E^2 kernel from the caller's table cs of size N = 2 E^2: tw2d[k1][l] = W_(E^2)^(k1 l) = W_N^(2 k1 l),
+// tw1[j][l] = W_N^(l + E j)
+__global__ void k_fft_2xsquare_tables(float2 *__restrict__ tw2d, float2 *__restrict__ tw1, const float *__restrict__ cs,
+                                      int E)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, H = E * E, N = 2 * H;
+    if (i >= H) return;
+    const int m2 = (2 * (i / E) * (i % E)) & (N - 1);
+    tw2d[i] = make_float2(cs[m2], -cs[N + m2]);
+    const int m1 = (i % E) + E * (i / E);
+    tw1[i] = make_float2(cs[m1], -cs[N + m1]);
 }
 
 // fills tw2d from the handle's table cs (cos then sin of 2 pi i / N): exactly the host-built values
@@ -661,6 +736,35 @@ extern "C" int llzs_fft_f32(float *data, int count, int size, const float *cs, i
             else hipLaunchKernelGGL((k_fft_square_f32<64, false>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d);
         }
         LLZ_LAUNCH_CHECK("k_fft_square_f32");
+        return LLZ_OK;
+    }
+    if ((size == 512 || size == 2048) && data && cs && count >= 1 && !getenv("LLZ_FFT_GENERIC")) {
+        static float2 *tables2[16][2][2];                           // [device][size][tw2d, tw1]
+        int dev = 0;
+        LLZ_HIP_CHECK(hipGetDevice(&dev));
+        const int E = size == 512 ? 16 : 32, slot = size == 512 ? 0 : 1, H = E * E;
+        if (dev < 0 || dev >= 16) dev = 0;
+        if (!tables2[dev][slot][0]) {
+            float2 *a = nullptr, *b = nullptr;
+            LLZ_HIP_CHECK(hipMalloc(&a, sizeof(float2) * (size_t)H));
+            LLZ_HIP_CHECK(hipMalloc(&b, sizeof(float2) * (size_t)H));
+            hipLaunchKernelGGL(k_fft_2xsquare_tables, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, as_stream(stream), a,
+                               b, cs, E);
+            LLZ_LAUNCH_CHECK("k_fft_2xsquare_tables");
+            LLZ_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+            tables2[dev][slot][1] = b;
+            tables2[dev][slot][0] = a;
+        }
+        const float2 *tw2d = tables2[dev][slot][0], *tw1 = tables2[dev][slot][1];
+        const unsigned blocks = (unsigned)((count + (256 / E) - 1) / (256 / E));
+        if (E == 16) {
+            if (inverse) hipLaunchKernelGGL((k_fft_2xsquare_f32<16, true>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d, tw1);
+            else hipLaunchKernelGGL((k_fft_2xsquare_f32<16, false>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d, tw1);
+        } else {
+            if (inverse) hipLaunchKernelGGL((k_fft_2xsquare_f32<32, true>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d, tw1);
+            else hipLaunchKernelGGL((k_fft_2xsquare_f32<32, false>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d, tw1);
+        }
+        LLZ_LAUNCH_CHECK("k_fft_2xsquare_f32");
         return LLZ_OK;
     }
     if (size == 1024 && data && cs && count >= 1 && !getenv("LLZ_FFT_GENERIC")) {
