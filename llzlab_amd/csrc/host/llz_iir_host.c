@@ -107,6 +107,7 @@ typedef struct {
     int channels, stages;
     double *d_coef;      /* stages x {b0,b1,b2,a1,a2} */
     double *d_pd, *d_pl; /* state-transition powers for the pipelined kernel: [S][6][4] and [S][64][12] */
+    float *d_coef32, *d_pd32, *d_pl32;   /* float copies for the wave-autonomous float32 kernel: [S][5], [S][16], [S][64][12] */
     double *d_state;     /* [channels][stages][x1,x2,y1,y2] */
     int warm_chunks;     /* 1024-sample chunks after which any state error has decayed below 1e-13 (0: unknown / too long) */
     int float32_ok;      /* every section's rounding-noise gain is small enough for float32 arithmetic */
@@ -118,6 +119,7 @@ static void iirm_destroy(iirm_t *f)
 {
     if (!f) return;
     llzs_free(f->d_coef); llzs_free(f->d_state); llzs_free(f->d_pd); llzs_free(f->d_pl);
+    llzs_free(f->d_coef32); llzs_free(f->d_pd32); llzs_free(f->d_pl32);
     llz_stage_release(&f->st_in); llz_stage_release(&f->st_out);
     f->tag = 0;
     free(f);
@@ -161,6 +163,25 @@ static int iirm_build_powers(iirm_t *f, const double *c5, int lane_run)
         rc = (f->d_pd && f->d_pl) ? LLZ_OK : LLZ_ERR_NOMEM;
         if (rc == LLZ_OK) rc = llzs_h2d(f->d_pd, pd, sizeof(double) * (size_t)S * 24, NULL);
         if (rc == LLZ_OK) rc = llzs_h2d(f->d_pl, pl, sizeof(double) * (size_t)S * 768, NULL);
+        if (rc == LLZ_OK && f->float32_ok) {                           /* float copies for k_iir_cascade_wave_f32 */
+            float *t = (float *)malloc(sizeof(float) * (size_t)S * (5 + 16 + 768));
+            if (!t) rc = LLZ_ERR_NOMEM;
+            if (rc == LLZ_OK) {
+                float *c32 = t, *pd32 = t + 5 * S, *pl32 = pd32 + 16 * S;
+                for (int i = 0; i < 5 * S; i++) c32[i] = (float)c5[i];
+                for (int s = 0; s < S; s++)
+                    for (int i = 0; i < 16; i++) pd32[16 * s + i] = (float)pd[24 * s + i];
+                for (int i = 0; i < 768 * S; i++) pl32[i] = (float)pl[i];
+                f->d_coef32 = (float *)llzs_malloc(sizeof(float) * 5 * (size_t)S);
+                f->d_pd32 = (float *)llzs_malloc(sizeof(float) * 16 * (size_t)S);
+                f->d_pl32 = (float *)llzs_malloc(sizeof(float) * 768 * (size_t)S);
+                if (!f->d_coef32 || !f->d_pd32 || !f->d_pl32) rc = LLZ_ERR_NOMEM;
+                if (rc == LLZ_OK) rc = llzs_h2d(f->d_coef32, c32, sizeof(float) * 5 * (size_t)S, NULL);
+                if (rc == LLZ_OK) rc = llzs_h2d(f->d_pd32, pd32, sizeof(float) * 16 * (size_t)S, NULL);
+                if (rc == LLZ_OK) rc = llzs_h2d(f->d_pl32, pl32, sizeof(float) * 768 * (size_t)S, NULL);
+            }
+            free(t);
+        }
     }
     free(pd); free(pl);
     return rc;
@@ -312,7 +333,15 @@ int llz_iir_cascade_mc(unsigned long handle, const float *x, float *y, int frame
     const int aligned = (frame_len % 4 == 0) && (((size_t)d_in | (size_t)d_out) % 16 == 0);
     const int chunk = LLZS_IIR_PIPE_CHUNK;
     const int n_fast = aligned ? frame_len - frame_len % chunk : 0;
-    if (rc == LLZ_OK && n_fast > 0)
+    /* short-memory float32 cascades: a wave per (channel, time segment), all sections in registers */
+    const char *kern = getenv("LLZ_IIR_KERNEL");
+    /* (needs enough (channel, segment) items to fill the chip: segments are at least 8 x the warm-up long) */
+    const long seg_items = f->warm_chunks > 0 ? (long)f->channels * (n_fast / LLZS_IIR_PIPE_CHUNK / (8 * f->warm_chunks)) : 0;
+    const int wave_form = f->float32_ok && f->d_pl32 && seg_items >= 4096 && !(kern && strcmp(kern, "pipe") == 0);
+    if (rc == LLZ_OK && n_fast > 0 && wave_form)
+        rc = llzs_iir_cascade_wave_f32(d_in, d_out, f->d_coef32, f->d_pd32, f->d_pl32, f->d_state, f->channels, n_fast,
+                                       frame_len, frame_len, f->stages, f->warm_chunks, f->stream);
+    else if (rc == LLZ_OK && n_fast > 0)
         rc = llzs_iir_cascade_pipe_f32(d_in, d_out, f->d_coef, f->d_pd, f->d_pl, f->d_state, f->channels, n_fast,
                                        frame_len, frame_len, f->stages, f->warm_chunks, f->float32_ok, f->stream);
     if (rc == LLZ_OK && n_fast < frame_len)

@@ -71,6 +71,11 @@ int llzs_iir_cascade_pipe_f32(const float *in, float *out, const double *coef, c
                               void *stream);
 /* general direct form I, one channel, double, the reference's exact operation order (llz_iir.c:103-132).
  * xs: N+1 doubles, ys: M+1 doubles (delay lines, read and written) */
+/* float32 cascades with a short memory: a wave owns a (channel, time segment) and runs all sections in registers.
+ * coef32: [S][5], pd32: [S][16] = P^(2^d) d<4, pl32: [S][64][12], all float; state as above (double). */
+int llzs_iir_cascade_wave_f32(const float *in, float *out, const float *coef32, const float *pd32, const float *pl32,
+                              double *state, int channels, int n, long in_pitch, long out_pitch, int stages,
+                              int warm_chunks, void *stream);
 int llzs_iir_df1_f64(const double *in, double *out, const double *a, const double *b, double *xs, double *ys,
                      int M, int N, int n, void *stream);
 

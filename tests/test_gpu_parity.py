@@ -500,6 +500,33 @@ def test_iir_cascade_low_q_float32_path(dev, oracle, radius, theta, channels, n)
     assert err <= TOL * max(1.0, scale) and err / scale <= TOL, (radius, theta, err, scale)
 
 
+@pytest.mark.parametrize("stages,radius,theta", [(8, 0.44, 1.1), (3, 0.7, 0.5), (16, 0.5, 2.5)])
+def test_iir_cascade_wave_form(dev, oracle, stages, radius, theta):
+    """many channels x a short-memory float32 cascade: a wave owns a (channel, time segment) and runs all sections in
+    registers (k_iir_cascade_wave_f32).  Two calls (state hand-over), ragged tail through the per-channel kernel, spot
+    channels against the double oracle"""
+    a1, a2 = -2 * radius * np.cos(theta), radius ** 2
+    g = (1 + a1 + a2) / 4
+    coef = np.tile(np.array([g, 2 * g, g, 1.0, a1, a2]), (stages, 1))
+    channels, n = 2048, 1024 * 64 + 100
+    f = filters.IirCascadeMC(channels, coef)
+    assert f.precision == 32
+    sel = [0, 1, 1000, 2047]
+    xs, ys = [], []
+    for call in range(2):
+        x = torch.empty(channels, n, dtype=torch.float32, device=dev)
+        filters.synth_f32(x, seed=40 + call)
+        y = torch.empty_like(x)
+        f.filter(x, y)
+        xs.append(x[sel].cpu().numpy())
+        ys.append(y[sel].cpu().numpy())
+    f.close()
+    ref = oracle.iir_cascade_batch_f32(np.concatenate(xs, axis=1), coef)
+    got = np.concatenate(ys, axis=1).astype(np.float64)
+    err, scale = float(np.sqrt(np.mean((got - ref) ** 2))), float(np.sqrt(np.mean(ref ** 2)))
+    assert err <= TOL * max(1.0, scale) and err / scale <= TOL, (err, scale)
+
+
 def test_iir_cascade_few_channels_split_along_time(dev, oracle):
     """few channels and a long frame: the pipelined kernel splits each channel into time segments that start a measured
     warm-up early from the zero state (the cascade's memory, probed at init); the result must still match the sequential
