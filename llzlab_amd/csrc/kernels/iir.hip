@@ -350,14 +350,14 @@ k_iir_cascade_pipe(const float *__restrict__ in, float *__restrict__ out, const 
 // segments (a later segment starts `warm` chunks early from the zero state, as in the pipelined kernel).
 // Per-lane powers P^lane, P^(lane%16+1), P^(lane%32+1) of every section sit in LDS ([S][64][12] floats, conflict-free
 // 16-byte reads); section coefficients and the scan powers are wave-uniform and come through the scalar cache.
-template <int S>
+template <typename R, int S>
 __global__ void __launch_bounds__(256)
-k_iir_cascade_wave_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ coef32,
-                       const float *__restrict__ pd32 /* [S][16] */, const float *__restrict__ pl32 /* [S][64][12] */,
-                       double *__restrict__ state, int nchunks_total, long in_pitch, long out_pitch, int stages,
-                       int segs, int seg_chunks, int warm, long items)
+k_iir_cascade_wave(const float *__restrict__ in, float *__restrict__ out, const R *__restrict__ coef32,
+                   const R *__restrict__ pd32 /* [S][pd_stride], P^(2^d) d < 4 first */, const R *__restrict__ pl32 /* [S][64][12] */,
+                   double *__restrict__ state, int nchunks_total, long in_pitch, long out_pitch, int stages,
+                   int segs, int seg_chunks, int warm, long items, int pd_stride)
 {
-    __shared__ __attribute__((aligned(16))) float s_pl[S * 64 * 12];
+    __shared__ __attribute__((aligned(16))) R s_pl[S * 64 * 12];
     for (int e = threadIdx.x; e < stages * 768; e += 256) s_pl[e] = pl32[e];
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -368,13 +368,13 @@ k_iir_cascade_wave_f32(const float *__restrict__ in, float *__restrict__ out, co
     const int chunk0 = seg * seg_chunks - skip;
     const int nchunks = min(nchunks_total, (seg + 1) * seg_chunks) - chunk0;
 
-    float su1[S], su2[S], sy1[S], sy2[S];
+    R su1[S], su2[S], sy1[S], sy2[S];
 #pragma unroll
     for (int s = 0; s < S; s++) {
-        su1[s] = su2[s] = sy1[s] = sy2[s] = 0.f;
+        su1[s] = su2[s] = sy1[s] = sy2[s] = 0;
         if (s < stages && seg == 0) {
             const double *st = state + ((size_t)c * stages + s) * 4;
-            su1[s] = (float)st[0]; su2[s] = (float)st[1]; sy1[s] = (float)st[2]; sy2[s] = (float)st[3];
+            su1[s] = (R)st[0]; su2[s] = (R)st[1]; sy1[s] = (R)st[2]; sy2[s] = (R)st[3];
         }
     }
     const float *row = in + (size_t)c * in_pitch + (size_t)chunk0 * 1024 + lane * 16;
@@ -385,11 +385,11 @@ k_iir_cascade_wave_f32(const float *__restrict__ in, float *__restrict__ out, co
         for (int q = 0; q < 4; q++) pre[q] = *reinterpret_cast<const float4 *>(row + 4 * q);
     }
     for (int chunk = 0; chunk < nchunks; chunk++) {
-        const float *tabs = s_pl;    // (the compiler hoists these reads out of the chunk loop: 171 VGPRs, two waves per
+        const R *tabs = s_pl;    // (the compiler hoists these reads out of the chunk loop: 171 VGPRs, two waves per
                                      //  SIMD; forcing them back inside measured 6 % slower and no fewer registers)
-        float u[16];
+        R u[16];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { u[4 * q] = pre[q].x; u[4 * q + 1] = pre[q].y; u[4 * q + 2] = pre[q].z; u[4 * q + 3] = pre[q].w; }
+        for (int q = 0; q < 4; q++) { u[4 * q] = (R)pre[q].x; u[4 * q + 1] = (R)pre[q].y; u[4 * q + 2] = (R)pre[q].z; u[4 * q + 3] = (R)pre[q].w; }
         if (chunk + 1 < nchunks) {
 #pragma unroll
             for (int q = 0; q < 4; q++) pre[q] = *reinterpret_cast<const float4 *>(row + (size_t)(chunk + 1) * 1024 + 4 * q);
@@ -397,57 +397,57 @@ k_iir_cascade_wave_f32(const float *__restrict__ in, float *__restrict__ out, co
 #pragma unroll
         for (int s = 0; s < S; s++) {
             if (s < stages) {
-                const float b0 = coef32[5 * s], b1 = coef32[5 * s + 1], b2 = coef32[5 * s + 2];
-                const float a1 = coef32[5 * s + 3], a2 = coef32[5 * s + 4];
-                const float *P = pd32 + 16 * s;                     // P^(2^d), d = 0..3, row major 2x2 each (uniform)
-                const float4 t0 = *reinterpret_cast<const float4 *>(&tabs[(s * 64 + lane) * 12]);
-                const float4 t1 = *reinterpret_cast<const float4 *>(&tabs[(s * 64 + lane) * 12 + 4]);
-                const float4 t2 = *reinterpret_cast<const float4 *>(&tabs[(s * 64 + lane) * 12 + 8]);
-                float um1 = dpp_<DPP_WAVE_SHR1, 0xF>(u[15]), um2 = dpp_<DPP_WAVE_SHR1, 0xF>(u[14]);
+                const R b0 = coef32[5 * s], b1 = coef32[5 * s + 1], b2 = coef32[5 * s + 2];
+                const R a1 = coef32[5 * s + 3], a2 = coef32[5 * s + 4];
+                const R *P = pd32 + pd_stride * s;                     // P^(2^d), d = 0..3, row major 2x2 each (uniform)
+                const R *tl = tabs + (s * 64 + lane) * 12;
+                struct q4 { R x, y, z, w; };
+                const q4 t0 = {tl[0], tl[1], tl[2], tl[3]}, t1 = {tl[4], tl[5], tl[6], tl[7]}, t2 = {tl[8], tl[9], tl[10], tl[11]};
+                R um1 = dpp_<DPP_WAVE_SHR1, 0xF>(u[15]), um2 = dpp_<DPP_WAVE_SHR1, 0xF>(u[14]);
                 if (lane == 0) { um1 = su1[s]; um2 = su2[s]; }
-                const float nu1 = lane63_(u[15]), nu2 = lane63_(u[14]);
+                const R nu1 = lane63_(u[15]), nu2 = lane63_(u[14]);
                 {
-                    float p1 = um1, p2 = um2;
+                    R p1 = um1, p2 = um2;
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
-                        const float x = u[k];
-                        float acc = b0 * x;
+                        const R x = u[k];
+                        R acc = b0 * x;
                         acc = fma_(b1, p1, acc);
                         acc = fma_(b2, p2, acc);
                         u[k] = acc;
                         p2 = p1; p1 = x;
                     }
                 }
-                float z1 = 0.f, z2 = 0.f;
+                R z1 = 0.f, z2 = 0.f;
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
-                    const float y = fma_(-a1, z1, fma_(-a2, z2, u[k]));
+                    const R y = fma_(-a1, z1, fma_(-a2, z2, u[k]));
                     z2 = z1; z1 = y;
                 }
 #define LLZ_ROW_STEP(D, SH)                                                                               \
                 {                                                                                             \
-                    const float q1 = dpp_<DPP_ROW_SHR + SH, 0xF>(z1), q2 = dpp_<DPP_ROW_SHR + SH, 0xF>(z2);   \
+                    const R q1 = dpp_<DPP_ROW_SHR + SH, 0xF>(z1), q2 = dpp_<DPP_ROW_SHR + SH, 0xF>(z2);   \
                     z1 = fma_(P[4 * D], q1, fma_(P[4 * D + 1], q2, z1));                                      \
                     z2 = fma_(P[4 * D + 2], q1, fma_(P[4 * D + 3], q2, z2));                                  \
                 }
                 LLZ_ROW_STEP(0, 1) LLZ_ROW_STEP(1, 2) LLZ_ROW_STEP(2, 4) LLZ_ROW_STEP(3, 8)
 #undef LLZ_ROW_STEP
                 {
-                    const float q1 = dpp_<DPP_BCAST15, 0xA>(z1), q2 = dpp_<DPP_BCAST15, 0xA>(z2);
+                    const R q1 = dpp_<DPP_BCAST15, 0xA>(z1), q2 = dpp_<DPP_BCAST15, 0xA>(z2);
                     z1 = fma_(t1.x, q1, fma_(t1.y, q2, z1));
                     z2 = fma_(t1.z, q1, fma_(t1.w, q2, z2));
                 }
                 {
-                    const float q1 = dpp_<DPP_BCAST31, 0xC>(z1), q2 = dpp_<DPP_BCAST31, 0xC>(z2);
+                    const R q1 = dpp_<DPP_BCAST31, 0xC>(z1), q2 = dpp_<DPP_BCAST31, 0xC>(z2);
                     z1 = fma_(t2.x, q1, fma_(t2.y, q2, z1));
                     z2 = fma_(t2.z, q1, fma_(t2.w, q2, z2));
                 }
-                const float e1 = dpp_<DPP_WAVE_SHR1, 0xF>(z1), e2 = dpp_<DPP_WAVE_SHR1, 0xF>(z2);
-                float y1 = fma_(t0.x, sy1[s], fma_(t0.y, sy2[s], e1));
-                float y2 = fma_(t0.z, sy1[s], fma_(t0.w, sy2[s], e2));
+                const R e1 = dpp_<DPP_WAVE_SHR1, 0xF>(z1), e2 = dpp_<DPP_WAVE_SHR1, 0xF>(z2);
+                R y1 = fma_(t0.x, sy1[s], fma_(t0.y, sy2[s], e1));
+                R y2 = fma_(t0.z, sy1[s], fma_(t0.w, sy2[s], e2));
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
-                    const float y = fma_(-a1, y1, fma_(-a2, y2, u[k]));
+                    const R y = fma_(-a1, y1, fma_(-a2, y2, u[k]));
                     u[k] = y;
                     y2 = y1; y1 = y;
                 }
@@ -459,7 +459,7 @@ k_iir_cascade_wave_f32(const float *__restrict__ in, float *__restrict__ out, co
             float *dst = orow + (size_t)chunk * 1024;
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                *reinterpret_cast<float4 *>(dst + 4 * q) = make_float4(u[4 * q], u[4 * q + 1], u[4 * q + 2], u[4 * q + 3]);
+                *reinterpret_cast<float4 *>(dst + 4 * q) = make_float4((float)u[4 * q], (float)u[4 * q + 1], (float)u[4 * q + 2], (float)u[4 * q + 3]);
         }
     }
     if (lane == 0 && seg == segs - 1) {
@@ -562,15 +562,16 @@ extern "C" int llzs_iir_cascade_pipe_f32(const float *in, float *out, const doub
     return LLZ_OK;
 }
 
-// float32, wave-autonomous (see k_iir_cascade_wave_f32).  n a multiple of 1024, rows 16-byte aligned, warm_chunks > 0.
-extern "C" int llzs_iir_cascade_wave_f32(const float *in, float *out, const float *coef32, const float *pd32,
-                                         const float *pl32, double *state, int channels, int n, long in_pitch,
-                                         long out_pitch, int stages, int warm_chunks, void *stream)
+// wave-autonomous form (see k_iir_cascade_wave).  n a multiple of 1024, rows 16-byte aligned, warm_chunks > 0.
+template <typename R>
+static int launch_iir_wave(const float *in, float *out, const R *coef, const R *pd, const R *pl, double *state,
+                           int channels, int n, long in_pitch, long out_pitch, int stages, int warm_chunks, int pd_stride,
+                           void *stream)
 {
-    if (!in || !out || !coef32 || !pd32 || !pl32 || !state || channels <= 0 || n <= 0 || (n % 1024) || stages < 1 ||
-        stages > 16 || warm_chunks < 1 || in_pitch < n || out_pitch < n || (in_pitch & 3) || (out_pitch & 3) ||
+    if (!in || !out || !coef || !pd || !pl || !state || channels <= 0 || n <= 0 || (n % 1024) || stages < 1 ||
+        stages > 8 /* 16 sections in registers spill */ || warm_chunks < 1 || in_pitch < n || out_pitch < n || (in_pitch & 3) || (out_pitch & 3) ||
         (reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) {
-        llzs_set_error("iir_cascade_wave_f32: bad arguments");
+        llzs_set_error("iir_cascade_wave: bad arguments");
         return LLZ_ERR_ARG;
     }
     const int nchunks = n / 1024;
@@ -584,13 +585,29 @@ extern "C" int llzs_iir_cascade_wave_f32(const float *in, float *out, const floa
     const long items = (long)channels * segs;
     const dim3 grid((unsigned)((items + 3) / 4));
 #define LLZ_WAVE_LAUNCH(S)                                                                                           \
-    hipLaunchKernelGGL(k_iir_cascade_wave_f32<S>, grid, dim3(256), 0, as_stream(stream), in, out, coef32, pd32, pl32,    \
-                       state, nchunks, in_pitch, out_pitch, stages, segs, seg_chunks, warm_chunks, items)
+    hipLaunchKernelGGL((k_iir_cascade_wave<R, S>), grid, dim3(256), 0, as_stream(stream), in, out, coef, pd, pl,        \
+                       state, nchunks, in_pitch, out_pitch, stages, segs, seg_chunks, warm_chunks, items, pd_stride)
     if (stages <= 2) LLZ_WAVE_LAUNCH(2);
     else if (stages <= 4) LLZ_WAVE_LAUNCH(4);
-    else if (stages <= 8) LLZ_WAVE_LAUNCH(8);
-    else LLZ_WAVE_LAUNCH(16);
+    else LLZ_WAVE_LAUNCH(8);
 #undef LLZ_WAVE_LAUNCH
-    LLZ_LAUNCH_CHECK("k_iir_cascade_wave_f32");
+    LLZ_LAUNCH_CHECK("k_iir_cascade_wave");
     return LLZ_OK;
+}
+
+extern "C" int llzs_iir_cascade_wave_f32(const float *in, float *out, const float *coef32, const float *pd32,
+                                         const float *pl32, double *state, int channels, int n, long in_pitch,
+                                         long out_pitch, int stages, int warm_chunks, void *stream)
+{
+    return launch_iir_wave<float>(in, out, coef32, pd32, pl32, state, channels, n, in_pitch, out_pitch, stages,
+                                  warm_chunks, 16, stream);
+}
+
+// the same in double, from the pipelined kernel's own tables (pd: [S][6][4])
+extern "C" int llzs_iir_cascade_wave_f64(const float *in, float *out, const double *coef, const double *pd,
+                                         const double *pl, double *state, int channels, int n, long in_pitch,
+                                         long out_pitch, int stages, int warm_chunks, void *stream)
+{
+    return launch_iir_wave<double>(in, out, coef, pd, pl, state, channels, n, in_pitch, out_pitch, stages, warm_chunks,
+                                   24, stream);
 }

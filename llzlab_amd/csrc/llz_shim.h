@@ -76,6 +76,10 @@ int llzs_iir_cascade_pipe_f32(const float *in, float *out, const double *coef, c
 int llzs_iir_cascade_wave_f32(const float *in, float *out, const float *coef32, const float *pd32, const float *pl32,
                               double *state, int channels, int n, long in_pitch, long out_pitch, int stages,
                               int warm_chunks, void *stream);
+/* the same in double from the pipelined kernel's tables; at most 8 sections */
+int llzs_iir_cascade_wave_f64(const float *in, float *out, const double *coef, const double *pd, const double *pl,
+                              double *state, int channels, int n, long in_pitch, long out_pitch, int stages,
+                              int warm_chunks, void *stream);
 int llzs_iir_df1_f64(const double *in, double *out, const double *a, const double *b, double *xs, double *ys,
                      int M, int N, int n, void *stream);
 
