@@ -242,8 +242,9 @@ def sharded_configs(torch, filters, capi, shard, dev, comm_dev, stream, rank, wo
     sptr = stream.cuda_stream
     out = {}
 
-    def timed(fn, steps):
-        fn()
+    def timed(fn, steps, warm=1):
+        for _ in range(warm):
+            fn()
         torch.cuda.synchronize()
         barrier()
         t = L.llz_hip_timer_new()
@@ -305,7 +306,7 @@ def sharded_configs(torch, filters, capi, shard, dev, comm_dev, stream, rank, wo
     coef = np.tile(np.array([0.2066, 0.4131, 0.2066, 1.0, -0.3695, 0.1958]), (8, 1)) if rank == 0 else np.zeros((8, 6))
     coef = shard.broadcast_table(coef, device=comm_dev)
     q = filters.IirCascadeMC(ch, coef, stream=stream)
-    ms = timed(lambda: q.filter(x, y), 3)
+    ms = timed(lambda: q.filter(x, y), 20, warm=10)      # a 2 ms kernel: clocks need tens of ms to settle after idling
     out["iir8_1024ch_sharded"] = {
         "Msamples_s": total_ch * n / ms / 1e3, "GBs_per_gpu": 8 * ch * n / ms / 1e6,
         "hbm_frac_per_gpu": 8 * ch * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "channels_per_gpu": ch,

@@ -108,6 +108,7 @@ typedef struct {
     double *d_coef;      /* stages x {b0,b1,b2,a1,a2} */
     double *d_pd, *d_pl; /* state-transition powers for the pipelined kernel: [S][6][4] and [S][64][12] */
     float *d_coef32, *d_pd32, *d_pl32;   /* float copies for the wave-autonomous float32 kernel: [S][5], [S][16], [S][64][12] */
+    float *d_ph32;       /* [S][24]: (h1[k], h2[k]) k < 8 = zero-input outputs of the unit start states, b0 b1 b2 a1 a2, pad */
     double *d_state;     /* [channels][stages][x1,x2,y1,y2] */
     int warm_chunks;     /* 1024-sample chunks after which any state error has decayed below 1e-13 (0: unknown / too long) */
     int float32_ok;      /* every section's rounding-noise gain is small enough for float32 arithmetic */
@@ -119,7 +120,7 @@ static void iirm_destroy(iirm_t *f)
 {
     if (!f) return;
     llzs_free(f->d_coef); llzs_free(f->d_state); llzs_free(f->d_pd); llzs_free(f->d_pl);
-    llzs_free(f->d_coef32); llzs_free(f->d_pd32); llzs_free(f->d_pl32);
+    llzs_free(f->d_coef32); llzs_free(f->d_pd32); llzs_free(f->d_pl32); llzs_free(f->d_ph32);
     llz_stage_release(&f->st_in); llz_stage_release(&f->st_out);
     f->tag = 0;
     free(f);
@@ -164,7 +165,7 @@ static int iirm_build_powers(iirm_t *f, const double *c5, int lane_run)
         if (rc == LLZ_OK) rc = llzs_h2d(f->d_pd, pd, sizeof(double) * (size_t)S * 24, NULL);
         if (rc == LLZ_OK) rc = llzs_h2d(f->d_pl, pl, sizeof(double) * (size_t)S * 768, NULL);
         if (rc == LLZ_OK && f->float32_ok) {                           /* float copies for k_iir_cascade_wave_f32 */
-            float *t = (float *)malloc(sizeof(float) * (size_t)S * (5 + 16 + 768));
+            float *t = (float *)malloc(sizeof(float) * (size_t)S * (5 + 16 + 768 + 24));
             if (!t) rc = LLZ_ERR_NOMEM;
             if (rc == LLZ_OK) {
                 float *c32 = t, *pd32 = t + 5 * S, *pl32 = pd32 + 16 * S;
@@ -172,13 +173,26 @@ static int iirm_build_powers(iirm_t *f, const double *c5, int lane_run)
                 for (int s = 0; s < S; s++)
                     for (int i = 0; i < 16; i++) pd32[16 * s + i] = (float)pd[24 * s + i];
                 for (int i = 0; i < 768 * S; i++) pl32[i] = (float)pl[i];
+                float *ph32 = pl32 + 768 * S;
+                for (int s = 0; s < S; s++) {                          /* y[k] from (y[-1], y[-2]) = (1,0) and (0,1) */
+                    const double a1 = c5[5 * s + 3], a2 = c5[5 * s + 4];
+                    double p1 = 1.0, p2 = 0.0, q1 = 0.0, q2 = 1.0;
+                    for (int k = 0; k < 8; k++) {
+                        const double h1 = -a1 * p1 - a2 * p2, h2 = -a1 * q1 - a2 * q2;
+                        ph32[24 * s + 2 * k] = (float)h1; ph32[24 * s + 2 * k + 1] = (float)h2;
+                        p2 = p1; p1 = h1; q2 = q1; q1 = h2;
+                    }
+                    for (int k = 0; k < 8; k++) ph32[24 * s + 16 + k] = k < 5 ? (float)c5[5 * s + k] : 0.f;
+                }
                 f->d_coef32 = (float *)llzs_malloc(sizeof(float) * 5 * (size_t)S);
                 f->d_pd32 = (float *)llzs_malloc(sizeof(float) * 16 * (size_t)S);
                 f->d_pl32 = (float *)llzs_malloc(sizeof(float) * 768 * (size_t)S);
-                if (!f->d_coef32 || !f->d_pd32 || !f->d_pl32) rc = LLZ_ERR_NOMEM;
+                f->d_ph32 = (float *)llzs_malloc(sizeof(float) * 24 * (size_t)S);
+                if (!f->d_coef32 || !f->d_pd32 || !f->d_pl32 || !f->d_ph32) rc = LLZ_ERR_NOMEM;
                 if (rc == LLZ_OK) rc = llzs_h2d(f->d_coef32, c32, sizeof(float) * 5 * (size_t)S, NULL);
                 if (rc == LLZ_OK) rc = llzs_h2d(f->d_pd32, pd32, sizeof(float) * 16 * (size_t)S, NULL);
                 if (rc == LLZ_OK) rc = llzs_h2d(f->d_pl32, pl32, sizeof(float) * 768 * (size_t)S, NULL);
+                if (rc == LLZ_OK) rc = llzs_h2d(f->d_ph32, ph32, sizeof(float) * 24 * (size_t)S, NULL);
             }
             free(t);
         }
@@ -341,7 +355,8 @@ int llz_iir_cascade_mc(unsigned long handle, const float *x, float *y, int frame
     const int wave_form = f->stages <= 8 && seg_items >= 4096 && !(kern && strcmp(kern, "pipe") == 0) &&
                           (!f->float32_ok || f->d_pl32);
     if (rc == LLZ_OK && n_fast > 0 && wave_form && f->float32_ok)
-        rc = llzs_iir_cascade_wave_f32(d_in, d_out, f->d_coef32, f->d_pd32, f->d_pl32, f->d_state, f->channels, n_fast,
+        rc = llzs_iir_cascade_wave_f32(d_in, d_out, f->d_coef32, f->d_pd32, f->d_pl32,
+                                       getenv("LLZ_IIR_UNPACKED") ? NULL : f->d_ph32, f->d_state, f->channels, n_fast,
                                        frame_len, frame_len, f->stages, f->warm_chunks, f->stream);
     else if (rc == LLZ_OK && n_fast > 0 && wave_form)
         rc = llzs_iir_cascade_wave_f64(d_in, d_out, f->d_coef, f->d_pd, f->d_pl, f->d_state, f->channels, n_fast,

@@ -10,6 +10,7 @@
 //                        LDS in 64x64 tiles so HBM sees 256-byte rows although lanes own channels. State and
 //                        arithmetic are double (the recurrence amplifies rounding by ~1/(1-r)^2 for pole radius r).
 #include "common.hpp"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -473,6 +474,191 @@ k_iir_cascade_wave(const float *__restrict__ in, float *__restrict__ out, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_iir_cascade_wave_pk: the float32 wave-autonomous cascade on PACKED float32 arithmetic (v_pk_fma_f32: two FMAs per
+// lane and issue slot).  The kernel above is bound by VALU issue (about 160 instructions per section and 1024-sample
+// chunk), so the lane's 16 samples are held as 8 pairs U[j] = (u[j], u[j+8]) and every part of the section step is
+// rewritten so that both halves of a pair do the same thing:
+//   * feed-forward part: acc[j] = b0*U[j] + b1*U[j-1] + b2*U[j-2] is pair-aligned by construction (U[-1] = (u[-1], u[7]));
+//   * feedback part: the two half runs [0,8) and [8,16) run as ONE packed 8-step recurrence from the zero state; a half
+//     run's true start state then enters through the section's homogeneous responses h1[k], h2[k] (k < 8, wave-uniform,
+//     host-computed): y[k] = w[k] + h1[k]*y[-1] + h2[k]*y[-2] -- again two independent packed FMAs per pair;
+//   * the lane scan carries (z1, z2) as one pair: each step is two packed FMAs on broadcast halves.
+// About 100 instructions per section and chunk instead of 160.  Tables: pl32 [S][64][12] as above (read into LDS with the
+// 2x2 matrices transposed so that matrix columns are register pairs), ph32 [S][24] = (h1[k], h2[k]) k < 8, then the
+// section's b0 b1 b2 a1 a2 and 3 pad.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f8v __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ f2 dpp2_(f2 v) { return f2{dpp_<CTRL, ROW_MASK>(v.x), dpp_<CTRL, ROW_MASK>(v.y)}; }
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const volatile f4v lds_cv_f4v;
+struct pk_tabs { f4v l0, l1, l2, p0, p1, p2, p3; };   // per lane: P^lane, P^(lane%16+1), P^(lane%32+1); uniform: P^(2^d), d < 4
+
+// one section over the lane's 16 samples U[j] = (u[j], u[j + 8]); H = (h1[k], h2[k]) k < 8, cc = b0 b1 b2 a1 a2
+__device__ __forceinline__ void pk_section(f2 (&U)[8], const f16v H, const f8v cc, const pk_tabs &T, const int lane,
+                                           float &su1, float &su2, float &sy1, float &sy2)
+{
+    const float b0 = cc[0], b1 = cc[1], b2 = cc[2], a1 = cc[3], a2 = cc[4];
+    float um1 = dpp_<DPP_WAVE_SHR1, 0xF>(U[7].y), um2 = dpp_<DPP_WAVE_SHR1, 0xF>(U[6].y);
+    if (lane == 0) { um1 = su1; um2 = su2; }
+    su1 = lane63_(U[7].y); su2 = lane63_(U[6].y);
+    {   // feed-forward part in place, from the top so that U[j-1], U[j-2] are still the inputs
+        const f2 Um1 = f2{um1, U[7].x}, Um2 = f2{um2, U[6].x};
+        const f2 B0 = splat(b0), B1 = splat(b1), B2 = splat(b2);
+#pragma unroll
+        for (int j = 7; j >= 2; j--) U[j] = pk_fma(B2, U[j - 2], pk_fma(B1, U[j - 1], B0 * U[j]));
+        U[1] = pk_fma(B2, Um1, pk_fma(B1, U[0], B0 * U[1]));
+        U[0] = pk_fma(B2, Um2, pk_fma(B1, Um1, B0 * U[0]));
+    }
+    {   // both half runs from the zero state: U[j] <- (w[j], w[j + 8])
+        const f2 A1 = splat(-a1), A2 = splat(-a2);
+        f2 Z1 = U[0], Z2 = splat(0.f);
+        U[1] = pk_fma(A1, U[0], U[1]);
+        Z2 = Z1; Z1 = U[1];
+#pragma unroll
+        for (int j = 2; j < 8; j++) {
+            const f2 Y = pk_fma(A1, Z1, pk_fma(A2, Z2, U[j]));
+            U[j] = Y;
+            Z2 = Z1; Z1 = Y;
+        }
+    }
+    // the lane's zero-state end state (yz[15], yz[14]): the second half run started from (w[7], w[6])
+    f2 ZZ;
+    ZZ.x = fma_(H[14], U[7].x, fma_(H[15], U[6].x, U[7].y));
+    ZZ.y = fma_(H[12], U[7].x, fma_(H[13], U[6].x, U[6].y));
+#define LLZ_SCAN_STEP(CTRL, MASK, M)                                                                                 \
+    {                                                                                                                \
+        const f2 Q = dpp2_<CTRL, MASK>(ZZ);                                                                          \
+        ZZ = pk_fma(f2{M.x, M.y}, splat(Q.x), pk_fma(f2{M.z, M.w}, splat(Q.y), ZZ));                                 \
+    }
+    LLZ_SCAN_STEP(DPP_ROW_SHR + 1, 0xF, T.p0) LLZ_SCAN_STEP(DPP_ROW_SHR + 2, 0xF, T.p1)
+    LLZ_SCAN_STEP(DPP_ROW_SHR + 4, 0xF, T.p2) LLZ_SCAN_STEP(DPP_ROW_SHR + 8, 0xF, T.p3)
+    LLZ_SCAN_STEP(DPP_BCAST15, 0xA, T.l1) LLZ_SCAN_STEP(DPP_BCAST31, 0xC, T.l2)
+#undef LLZ_SCAN_STEP
+    // the lane's start state (y[-1], y[-2])
+    const f2 Y0 = pk_fma(f2{T.l0.x, T.l0.y}, splat(sy1), pk_fma(f2{T.l0.z, T.l0.w}, splat(sy2), dpp2_<DPP_WAVE_SHR1, 0xF>(ZZ)));
+    // the true (y[7], y[6]): the start state of the second half run
+    const float y7 = fma_(H[14], Y0.x, fma_(H[15], Y0.y, U[7].x));
+    const float y6 = fma_(H[12], Y0.x, fma_(H[13], Y0.y, U[6].x));
+    const f2 SA = f2{Y0.x, y7}, SB = f2{Y0.y, y6};
+#pragma unroll
+    for (int j = 0; j < 8; j++) U[j] = pk_fma(splat(H[2 * j]), SA, pk_fma(splat(H[2 * j + 1]), SB, U[j]));
+    sy1 = lane63_(U[7].y); sy2 = lane63_(U[6].y);
+}
+
+// S = the number of sections exactly (even)
+template <int S>
+__global__ void __launch_bounds__(256)
+k_iir_cascade_wave_pk(const float *__restrict__ in, float *__restrict__ out,
+                      const float *__restrict__ pd32 /* [S][16], P^(2^d) d < 4, row major 2x2 each */,
+                      const float *__restrict__ pl32 /* [S][64][12] */, const float *__restrict__ ph32 /* [S][24] */,
+                      double *__restrict__ state, int nchunks_total, long in_pitch, long out_pitch,
+                      int segs, int seg_chunks, int warm, long items)
+{
+    static_assert(S % 2 == 0, "sections are processed in pairs");
+    __shared__ __attribute__((aligned(16))) float s_pl[S * 64 * 12];
+    __shared__ __attribute__((aligned(16))) float s_pd[S * 16];
+    // (m00, m01, m10, m11) -> (m00, m10, m01, m11): columns become aligned pairs
+    for (int e = threadIdx.x; e < S * 768; e += 256) s_pl[e] = pl32[(e & ~3) | ((e & 1) << 1) | ((e >> 1) & 1)];
+    if (threadIdx.x < S * 16) {
+        const int e = threadIdx.x;
+        s_pd[e] = pd32[(e & ~3) | ((e & 1) << 1) | ((e >> 1) & 1)];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+    if (item >= items) return;
+    const int c = (int)(item / segs), seg = (int)(item - (long)c * segs);
+    const int skip = seg > 0 ? warm : 0;
+    const int chunk0 = seg * seg_chunks - skip;
+    const int nchunks = min(nchunks_total, (seg + 1) * seg_chunks) - chunk0;
+
+    float su1[S], su2[S], sy1[S], sy2[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        su1[s] = su2[s] = sy1[s] = sy2[s] = 0;
+        if (seg == 0) {
+            const double *st = state + ((size_t)c * S + s) * 4;
+            su1[s] = (float)st[0]; su2[s] = (float)st[1]; sy1[s] = (float)st[2]; sy2[s] = (float)st[3];
+        }
+    }
+    const float *row = in + (size_t)c * in_pitch + (size_t)chunk0 * 1024 + lane * 16;
+    float *orow = out + (size_t)c * out_pitch + (size_t)chunk0 * 1024 + lane * 16;
+    float4 pre[4];
+    if (nchunks > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) pre[q] = *reinterpret_cast<const float4 *>(row + 4 * q);
+    }
+    // A section's constants are fetched one section AHEAD into the other of two register sets: 24 wave-uniform dwords
+    // through the scalar cache, 7 x 16 bytes of powers from LDS.  With two waves per SIMD a load that is waited for where
+    // it is issued costs its whole latency in every section, and the compiler sinks invariant loads to their first use:
+    // hence the volatile LDS reads and the written-out scalar loads, whose wait names the registers (which orders
+    // their users behind it).  Both kinds count on lgkmcnt; one wait per section covers all of them.
+    f16v hA, hB; f8v cA, cB;
+    pk_tabs TA, TB;
+#define LLZ_PK_TIE asm volatile("" : "+v"(U[0]), "+v"(U[7]))
+#define LLZ_PK_FETCH(SEC, HX, CX, TX)                                                                                \
+    {                                                                                                                \
+        const lds_cv_f4v *tl = (const lds_cv_f4v *)(s_pl + ((SEC) * 64 + lane) * 12);                                \
+        const lds_cv_f4v *tp = (const lds_cv_f4v *)(s_pd + (SEC) * 16);                                              \
+        TX.l0 = tl[0]; TX.l1 = tl[1]; TX.l2 = tl[2];                                                                 \
+        TX.p0 = tp[0]; TX.p1 = tp[1]; TX.p2 = tp[2]; TX.p3 = tp[3];                                                  \
+        asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx8 %1, %2, %4"                                        \
+                     : "=&s"(HX), "=&s"(CX) : "s"(ph32), "n"((SEC) * 96), "n"((SEC) * 96 + 64) : "memory");           \
+        LLZ_PK_TIE;                                                                                                  \
+    }
+    // (volatile asm statements keep their order; the empty ones name U[0] and U[7] so that the scheduler cannot move a
+    //  section's arithmetic across its wait and the next section's fetch)
+#define LLZ_PK_WAIT(HX, CX)                                                                                          \
+    {                                                                                                                \
+        LLZ_PK_TIE;                                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(HX), "+s"(CX));                                                   \
+    }
+    f2 U[8];                                                           // U[j] = (u[j], u[j + 8])
+    U[0] = U[7] = splat(0.f);
+    LLZ_PK_FETCH(0, hA, cA, TA)
+    for (int chunk = 0; chunk < nchunks; chunk++) {
+        U[0] = f2{pre[0].x, pre[2].x}; U[1] = f2{pre[0].y, pre[2].y}; U[2] = f2{pre[0].z, pre[2].z}; U[3] = f2{pre[0].w, pre[2].w};
+        U[4] = f2{pre[1].x, pre[3].x}; U[5] = f2{pre[1].y, pre[3].y}; U[6] = f2{pre[1].z, pre[3].z}; U[7] = f2{pre[1].w, pre[3].w};
+        if (chunk + 1 < nchunks) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) pre[q] = *reinterpret_cast<const float4 *>(row + (size_t)(chunk + 1) * 1024 + 4 * q);
+        }
+#pragma unroll
+        for (int s = 0; s < S; s += 2) {
+            LLZ_PK_WAIT(hA, cA);
+            LLZ_PK_FETCH(s + 1, hB, cB, TB)
+            pk_section(U, hA, cA, TA, lane, su1[s], su2[s], sy1[s], sy2[s]);
+            LLZ_PK_WAIT(hB, cB);
+            LLZ_PK_FETCH((s + 2 < S ? s + 2 : 0), hA, cA, TA)
+            pk_section(U, hB, cB, TB, lane, su1[s + 1], su2[s + 1], sy1[s + 1], sy2[s + 1]);
+        }
+        if (chunk >= skip) {
+            float *dst = orow + (size_t)chunk * 1024;
+            *reinterpret_cast<float4 *>(dst) = make_float4(U[0].x, U[1].x, U[2].x, U[3].x);
+            *reinterpret_cast<float4 *>(dst + 4) = make_float4(U[4].x, U[5].x, U[6].x, U[7].x);
+            *reinterpret_cast<float4 *>(dst + 8) = make_float4(U[0].y, U[1].y, U[2].y, U[3].y);
+            *reinterpret_cast<float4 *>(dst + 12) = make_float4(U[4].y, U[5].y, U[6].y, U[7].y);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // nothing in flight when the wave ends
+#undef LLZ_PK_FETCH
+#undef LLZ_PK_TIE
+#undef LLZ_PK_WAIT
+    if (lane == 0 && seg == segs - 1) {
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            double *st = state + ((size_t)c * S + s) * 4;
+            st[0] = (double)su1[s]; st[1] = (double)su2[s]; st[2] = (double)sy1[s]; st[3] = (double)sy2[s];
+        }
+    }
+}
+
 } // namespace
 
 extern "C" int llzs_iir_df1_f64(const double *in, double *out, const double *a, const double *b, double *xs,
@@ -564,9 +750,9 @@ extern "C" int llzs_iir_cascade_pipe_f32(const float *in, float *out, const doub
 
 // wave-autonomous form (see k_iir_cascade_wave).  n a multiple of 1024, rows 16-byte aligned, warm_chunks > 0.
 template <typename R>
-static int launch_iir_wave(const float *in, float *out, const R *coef, const R *pd, const R *pl, double *state,
-                           int channels, int n, long in_pitch, long out_pitch, int stages, int warm_chunks, int pd_stride,
-                           void *stream)
+static int launch_iir_wave(const float *in, float *out, const R *coef, const R *pd, const R *pl, const float *ph32,
+                           double *state, int channels, int n, long in_pitch, long out_pitch, int stages, int warm_chunks,
+                           int pd_stride, void *stream)
 {
     if (!in || !out || !coef || !pd || !pl || !state || channels <= 0 || n <= 0 || (n % 1024) || stages < 1 ||
         stages > 8 /* 16 sections in registers spill */ || warm_chunks < 1 || in_pitch < n || out_pitch < n || (in_pitch & 3) || (out_pitch & 3) ||
@@ -575,15 +761,59 @@ static int launch_iir_wave(const float *in, float *out, const R *coef, const R *
         return LLZ_ERR_ARG;
     }
     const int nchunks = n / 1024;
-    // enough (channel, segment) items for ~8 waves per SIMD, segments at least 8 x the warm-up
-    int segs = (int)((8192 + channels - 1) / channels);
-    if (segs > 64) segs = 64;
+    // Time segments per channel.  `slots` = waves the chip holds of this kernel.  Measured on config 4 (1024 channels) and
+    // on 128 channels: about three rounds of items are best while a segment stays long (>= 64 chunks: the per-item cost
+    // of warm-up and table load, ~1.4 chunks, stays small and the hardware balances the rounds), otherwise exactly one
+    // round; segments at least 8 x the warm-up.
+    const bool packed = std::is_same<R, float>::value && ph32 && (stages == 2 || stages == 4 || stages == 6 || stages == 8);
+    const void *kfn = nullptr;
+    if constexpr (std::is_same<R, float>::value) {
+        if (packed)
+            kfn = stages == 2 ? (const void *)k_iir_cascade_wave_pk<2> : stages == 4 ? (const void *)k_iir_cascade_wave_pk<4>
+                : stages == 6 ? (const void *)k_iir_cascade_wave_pk<6> : (const void *)k_iir_cascade_wave_pk<8>;
+    }
+    if (!kfn)
+        kfn = stages <= 2 ? (const void *)k_iir_cascade_wave<R, 2> : stages <= 4 ? (const void *)k_iir_cascade_wave<R, 4>
+                                                                                  : (const void *)k_iir_cascade_wave<R, 8>;
+    int blocks_per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kfn, 256, 0) != hipSuccess || blocks_per_cu < 1) {
+        (void)hipGetLastError();
+        blocks_per_cu = 2;
+    }
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+        (void)hipGetLastError();
+        cus = 256;
+    }
+    const long slots = 4L * blocks_per_cu * cus;
+    int segs = 1;
+    for (int rounds = 3; rounds >= 1; rounds--) {
+        segs = (int)((rounds * slots + channels / 2) / channels);
+        if (segs < 1) segs = 1;
+        if (segs > 64) segs = 64;
+        if (rounds == 1 || nchunks / segs >= 64) break;
+    }
     while (segs > 1 && nchunks / segs < 8 * warm_chunks) segs--;
     if (const char *e = getenv("LLZ_IIR_SEGS")) { const int v = atoi(e); if (v >= 1 && v <= 64) segs = v; }
     const int seg_chunks = (nchunks + segs - 1) / segs;
     segs = (nchunks + seg_chunks - 1) / seg_chunks;
     const long items = (long)channels * segs;
     const dim3 grid((unsigned)((items + 3) / 4));
+    if constexpr (std::is_same<R, float>::value) {
+        if (packed) {                                                  // packed kernel: even section counts
+#define LLZ_PK_LAUNCH(S)                                                                                             \
+    hipLaunchKernelGGL((k_iir_cascade_wave_pk<S>), grid, dim3(256), 0, as_stream(stream), in, out, pd, pl, ph32, state, \
+                       nchunks, in_pitch, out_pitch, segs, seg_chunks, warm_chunks, items)
+            if (stages == 2) LLZ_PK_LAUNCH(2);
+            else if (stages == 4) LLZ_PK_LAUNCH(4);
+            else if (stages == 6) LLZ_PK_LAUNCH(6);
+            else LLZ_PK_LAUNCH(8);
+#undef LLZ_PK_LAUNCH
+            LLZ_LAUNCH_CHECK("k_iir_cascade_wave_pk");
+            return LLZ_OK;
+        }
+    }
 #define LLZ_WAVE_LAUNCH(S)                                                                                           \
     hipLaunchKernelGGL((k_iir_cascade_wave<R, S>), grid, dim3(256), 0, as_stream(stream), in, out, coef, pd, pl,        \
                        state, nchunks, in_pitch, out_pitch, stages, segs, seg_chunks, warm_chunks, items, pd_stride)
@@ -596,10 +826,11 @@ static int launch_iir_wave(const float *in, float *out, const R *coef, const R *
 }
 
 extern "C" int llzs_iir_cascade_wave_f32(const float *in, float *out, const float *coef32, const float *pd32,
-                                         const float *pl32, double *state, int channels, int n, long in_pitch,
-                                         long out_pitch, int stages, int warm_chunks, void *stream)
+                                         const float *pl32, const float *ph32 /* NULL: unpacked kernel */,
+                                         double *state, int channels, int n, long in_pitch, long out_pitch, int stages,
+                                         int warm_chunks, void *stream)
 {
-    return launch_iir_wave<float>(in, out, coef32, pd32, pl32, state, channels, n, in_pitch, out_pitch, stages,
+    return launch_iir_wave<float>(in, out, coef32, pd32, pl32, ph32, state, channels, n, in_pitch, out_pitch, stages,
                                   warm_chunks, 16, stream);
 }
 
@@ -608,6 +839,6 @@ extern "C" int llzs_iir_cascade_wave_f64(const float *in, float *out, const doub
                                          const double *pl, double *state, int channels, int n, long in_pitch,
                                          long out_pitch, int stages, int warm_chunks, void *stream)
 {
-    return launch_iir_wave<double>(in, out, coef, pd, pl, state, channels, n, in_pitch, out_pitch, stages, warm_chunks,
+    return launch_iir_wave<double>(in, out, coef, pd, pl, nullptr, state, channels, n, in_pitch, out_pitch, stages, warm_chunks,
                                    24, stream);
 }

@@ -74,6 +74,9 @@ int llzs_iir_cascade_pipe_f32(const float *in, float *out, const double *coef, c
 /* float32 cascades with a short memory: a wave owns a (channel, time segment) and runs all sections in registers.
  * coef32: [S][5], pd32: [S][16] = P^(2^d) d<4, pl32: [S][64][12], all float; state as above (double). */
 int llzs_iir_cascade_wave_f32(const float *in, float *out, const float *coef32, const float *pd32, const float *pl32,
+                              const float *ph32 /* [S][24]: (h1[k], h2[k]) k < 8, the outputs at k of the unit start
+                                                   * states, then b0 b1 b2 a1 a2 and 3 pad; NULL = the
+                                                   * unpacked kernel */,
                               double *state, int channels, int n, long in_pitch, long out_pitch, int stages,
                               int warm_chunks, void *stream);
 /* the same in double from the pipelined kernel's tables; at most 8 sections */

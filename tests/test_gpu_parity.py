@@ -529,6 +529,37 @@ def test_iir_cascade_wave_form(dev, oracle, stages, radius, theta, chunks):
     assert err <= TOL * max(1.0, scale) and err / scale <= TOL, (err, scale)
 
 
+@pytest.mark.parametrize("stages", [2, 4, 5, 6, 7, 8])
+def test_iir_cascade_wave_distinct_sections(dev, oracle, stages):
+    """every section different (radius, angle, zeros): the packed float32 kernel (even counts) fetches a section's tables one
+    section ahead into alternating register sets, so a mix-up between sections must show here; odd counts take the
+    unpacked kernel.  Two calls, segments along time (few channels) and the many-channel shape"""
+    rows = []
+    for k in range(stages):
+        r, th = 0.30 + 0.06 * k, 0.4 + 0.33 * k
+        a1, a2 = -2 * r * np.cos(th), r * r
+        b = np.array([1.0, 0.3 - 0.2 * k, 0.1 * k]) * (1 + a1 + a2) / (1.3 - 0.1 * k)
+        rows.append(np.concatenate([b, [1.0, a1, a2]]))
+    coef = np.array(rows)
+    for channels, n in ((2048, 1024 * 16 + 40), (24, 1024 * 300)):
+        f = filters.IirCascadeMC(channels, coef)
+        assert f.precision == 32
+        sel = [0, channels // 2 + 1, channels - 1]
+        xs, ys = [], []
+        for call in range(2):
+            x = torch.empty(channels, n, dtype=torch.float32, device=dev)
+            filters.synth_f32(x, seed=70 + call + stages)
+            y = torch.empty_like(x)
+            f.filter(x, y)
+            xs.append(x[sel].cpu().numpy())
+            ys.append(y[sel].cpu().numpy())
+        f.close()
+        ref = oracle.iir_cascade_batch_f32(np.concatenate(xs, axis=1), coef)
+        got = np.concatenate(ys, axis=1).astype(np.float64)
+        err, scale = float(np.sqrt(np.mean((got - ref) ** 2))), float(np.sqrt(np.mean(ref ** 2)))
+        assert err <= TOL * max(1.0, scale) and err / scale <= TOL, (stages, channels, err, scale)
+
+
 def test_iir_cascade_few_channels_split_along_time(dev, oracle):
     """few channels and a long frame: the pipelined kernel splits each channel into time segments that start a measured
     warm-up early from the zero state (the cascade's memory, probed at init); the result must still match the sequential
