@@ -355,8 +355,7 @@ int llz_iir_cascade_mc(unsigned long handle, const float *x, float *y, int frame
     const int wave_form = f->stages <= 8 && seg_items >= 4096 && !(kern && strcmp(kern, "pipe") == 0) &&
                           (!f->float32_ok || f->d_pl32);
     if (rc == LLZ_OK && n_fast > 0 && wave_form && f->float32_ok)
-        rc = llzs_iir_cascade_wave_f32(d_in, d_out, f->d_coef32, f->d_pd32, f->d_pl32,
-                                       getenv("LLZ_IIR_UNPACKED") ? NULL : f->d_ph32, f->d_state, f->channels, n_fast,
+        rc = llzs_iir_cascade_wave_f32(d_in, d_out, f->d_coef32, f->d_pd32, f->d_pl32, f->d_ph32, f->d_state, f->channels, n_fast,
                                        frame_len, frame_len, f->stages, f->warm_chunks, f->stream);
     else if (rc == LLZ_OK && n_fast > 0 && wave_form)
         rc = llzs_iir_cascade_wave_f64(d_in, d_out, f->d_coef, f->d_pd, f->d_pl, f->d_state, f->channels, n_fast,

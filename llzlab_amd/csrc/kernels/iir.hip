@@ -551,7 +551,7 @@ __device__ __forceinline__ void pk_section(f2 (&U)[8], const f16v H, const f8v c
     sy1 = lane63_(U[7].y); sy2 = lane63_(U[6].y);
 }
 
-// S = the number of sections exactly (even)
+// S = the number of sections exactly
 template <int S>
 __global__ void __launch_bounds__(256)
 k_iir_cascade_wave_pk(const float *__restrict__ in, float *__restrict__ out,
@@ -560,7 +560,6 @@ k_iir_cascade_wave_pk(const float *__restrict__ in, float *__restrict__ out,
                       double *__restrict__ state, int nchunks_total, long in_pitch, long out_pitch,
                       int segs, int seg_chunks, int warm, long items)
 {
-    static_assert(S % 2 == 0, "sections are processed in pairs");
     __shared__ __attribute__((aligned(16))) float s_pl[S * 64 * 12];
     __shared__ __attribute__((aligned(16))) float s_pd[S * 16];
     // (m00, m01, m10, m11) -> (m00, m10, m01, m11): columns become aligned pairs
@@ -630,13 +629,17 @@ k_iir_cascade_wave_pk(const float *__restrict__ in, float *__restrict__ out,
             for (int q = 0; q < 4; q++) pre[q] = *reinterpret_cast<const float4 *>(row + (size_t)(chunk + 1) * 1024 + 4 * q);
         }
 #pragma unroll
-        for (int s = 0; s < S; s += 2) {
-            LLZ_PK_WAIT(hA, cA);
-            LLZ_PK_FETCH(s + 1, hB, cB, TB)
-            pk_section(U, hA, cA, TA, lane, su1[s], su2[s], sy1[s], sy2[s]);
-            LLZ_PK_WAIT(hB, cB);
-            LLZ_PK_FETCH((s + 2 < S ? s + 2 : 0), hA, cA, TA)
-            pk_section(U, hB, cB, TB, lane, su1[s + 1], su2[s + 1], sy1[s + 1], sy2[s + 1]);
+        for (int s = 0; s < S; s++) {
+            if ((s & 1) == 0) {
+                LLZ_PK_WAIT(hA, cA);
+                if (s + 1 < S) LLZ_PK_FETCH(s + 1, hB, cB, TB)
+                pk_section(U, hA, cA, TA, lane, su1[s], su2[s], sy1[s], sy2[s]);
+                if (s + 1 == S) LLZ_PK_FETCH(0, hA, cA, TA)            // odd S: set A is free only now (once per chunk)
+            } else {
+                LLZ_PK_WAIT(hB, cB);
+                LLZ_PK_FETCH((s + 1 < S ? s + 1 : 0), hA, cA, TA)
+                pk_section(U, hB, cB, TB, lane, su1[s], su2[s], sy1[s], sy2[s]);
+            }
         }
         if (chunk >= skip) {
             float *dst = orow + (size_t)chunk * 1024;
@@ -655,6 +658,157 @@ k_iir_cascade_wave_pk(const float *__restrict__ in, float *__restrict__ out,
         for (int s = 0; s < S; s++) {
             double *st = state + ((size_t)c * S + s) * 4;
             st[0] = (double)su1[s]; st[1] = (double)su2[s]; st[2] = (double)sy1[s]; st[3] = (double)sy2[s];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_iir_cascade_wave_pf64: the double wave-autonomous cascade with the same one-section-ahead fetch.  k_iir_cascade_wave
+// <double, 8> needs 348 VGPRs (the compiler hoists every section's powers out of the chunk loop) and so runs one wave per
+// SIMD with its scalar loads exposed; here a section's powers live in one of two register sets, filled from LDS a section
+// ahead, and the five coefficients come by written-out scalar loads: two waves per SIMD.
+typedef double d2v __attribute__((ext_vector_type(2)));
+typedef double d4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const volatile d2v lds_cv_d2v;
+struct pf_tabs { d2v l[6], p[8]; };     // per lane: P^lane, P^(lane%16+1), P^(lane%32+1) (row major); uniform: P^(2^d), d < 4
+
+__device__ __forceinline__ void pf_section(double (&u)[16], const d4v c4, const double a2, const pf_tabs &T, const int lane,
+                                           double &su1, double &su2, double &sy1, double &sy2)
+{
+    const double b0 = c4[0], b1 = c4[1], b2 = c4[2], a1 = c4[3];
+    double um1 = dpp_<DPP_WAVE_SHR1, 0xF>(u[15]), um2 = dpp_<DPP_WAVE_SHR1, 0xF>(u[14]);
+    if (lane == 0) { um1 = su1; um2 = su2; }
+    su1 = lane63_(u[15]); su2 = lane63_(u[14]);
+    {
+        double p1 = um1, p2 = um2;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const double x = u[k];
+            u[k] = fma_(b2, p2, fma_(b1, p1, b0 * x));
+            p2 = p1; p1 = x;
+        }
+    }
+    double z1 = 0.0, z2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const double y = fma_(-a1, z1, fma_(-a2, z2, u[k]));
+        z2 = z1; z1 = y;
+    }
+#define LLZ_SCAN_STEP(CTRL, MASK, M0, M1)                                                                            \
+    {                                                                                                                \
+        const double q1 = dpp_<CTRL, MASK>(z1), q2 = dpp_<CTRL, MASK>(z2);                                           \
+        z1 = fma_(M0.x, q1, fma_(M0.y, q2, z1));                                                                     \
+        z2 = fma_(M1.x, q1, fma_(M1.y, q2, z2));                                                                     \
+    }
+    LLZ_SCAN_STEP(DPP_ROW_SHR + 1, 0xF, T.p[0], T.p[1]) LLZ_SCAN_STEP(DPP_ROW_SHR + 2, 0xF, T.p[2], T.p[3])
+    LLZ_SCAN_STEP(DPP_ROW_SHR + 4, 0xF, T.p[4], T.p[5]) LLZ_SCAN_STEP(DPP_ROW_SHR + 8, 0xF, T.p[6], T.p[7])
+    LLZ_SCAN_STEP(DPP_BCAST15, 0xA, T.l[2], T.l[3]) LLZ_SCAN_STEP(DPP_BCAST31, 0xC, T.l[4], T.l[5])
+#undef LLZ_SCAN_STEP
+    const double e1 = dpp_<DPP_WAVE_SHR1, 0xF>(z1), e2 = dpp_<DPP_WAVE_SHR1, 0xF>(z2);
+    double y1 = fma_(T.l[0].x, sy1, fma_(T.l[0].y, sy2, e1));
+    double y2 = fma_(T.l[1].x, sy1, fma_(T.l[1].y, sy2, e2));
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const double y = fma_(-a1, y1, fma_(-a2, y2, u[k]));
+        u[k] = y;
+        y2 = y1; y1 = y;
+    }
+    sy1 = lane63_(y1); sy2 = lane63_(y2);
+}
+
+template <int S>
+__global__ void __launch_bounds__(256)
+k_iir_cascade_wave_pf64(const float *__restrict__ in, float *__restrict__ out,
+                        const double *__restrict__ coef /* [S][5] */, const double *__restrict__ pd /* [S][24] */,
+                        const double *__restrict__ pl /* [S][64][12] */, double *__restrict__ state, int nchunks_total,
+                        long in_pitch, long out_pitch, int segs, int seg_chunks, int warm, long items)
+{
+    __shared__ __attribute__((aligned(16))) double s_pl[S * 64 * 12];
+    __shared__ __attribute__((aligned(16))) double s_pd[S * 16];
+    for (int e = threadIdx.x; e < S * 768; e += 256) s_pl[e] = pl[e];
+    if (threadIdx.x < S * 16) s_pd[threadIdx.x] = pd[(threadIdx.x >> 4) * 24 + (threadIdx.x & 15)];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+    if (item >= items) return;
+    const int c = (int)(item / segs), seg = (int)(item - (long)c * segs);
+    const int skip = seg > 0 ? warm : 0;
+    const int chunk0 = seg * seg_chunks - skip;
+    const int nchunks = min(nchunks_total, (seg + 1) * seg_chunks) - chunk0;
+
+    double su1[S], su2[S], sy1[S], sy2[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        su1[s] = su2[s] = sy1[s] = sy2[s] = 0;
+        if (seg == 0) {
+            const double *st = state + ((size_t)c * S + s) * 4;
+            su1[s] = st[0]; su2[s] = st[1]; sy1[s] = st[2]; sy2[s] = st[3];
+        }
+    }
+    const float *row = in + (size_t)c * in_pitch + (size_t)chunk0 * 1024 + lane * 16;
+    float *orow = out + (size_t)c * out_pitch + (size_t)chunk0 * 1024 + lane * 16;
+    float4 pre[4];
+    if (nchunks > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) pre[q] = *reinterpret_cast<const float4 *>(row + 4 * q);
+    }
+    d4v cA, cB; double aA, aB;
+    pf_tabs TA, TB;
+    double u[16];
+    u[0] = u[15] = 0.0;
+#define LLZ_PF_TIE asm volatile("" : "+v"(u[0]), "+v"(u[15]))
+#define LLZ_PF_FETCH(SEC, CX, AX, TX)                                                                                \
+    {                                                                                                                \
+        const lds_cv_d2v *tl = (const lds_cv_d2v *)(s_pl + ((SEC) * 64 + lane) * 12);                                \
+        const lds_cv_d2v *tp = (const lds_cv_d2v *)(s_pd + (SEC) * 16);                                              \
+        _Pragma("unroll") for (int i = 0; i < 6; i++) TX.l[i] = tl[i];                                               \
+        _Pragma("unroll") for (int i = 0; i < 8; i++) TX.p[i] = tp[i];                                               \
+        asm volatile("s_load_dwordx8 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4"                                         \
+                     : "=&s"(CX), "=&s"(AX) : "s"(coef), "n"((SEC) * 40), "n"((SEC) * 40 + 32) : "memory");           \
+        LLZ_PF_TIE;                                                                                                  \
+    }
+#define LLZ_PF_WAIT(CX, AX)                                                                                          \
+    {                                                                                                                \
+        LLZ_PF_TIE;                                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(CX), "+s"(AX));                                                   \
+    }
+    LLZ_PF_FETCH(0, cA, aA, TA)
+    for (int chunk = 0; chunk < nchunks; chunk++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) { u[4 * q] = pre[q].x; u[4 * q + 1] = pre[q].y; u[4 * q + 2] = pre[q].z; u[4 * q + 3] = pre[q].w; }
+        if (chunk + 1 < nchunks) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) pre[q] = *reinterpret_cast<const float4 *>(row + (size_t)(chunk + 1) * 1024 + 4 * q);
+        }
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            if ((s & 1) == 0) {
+                LLZ_PF_WAIT(cA, aA);
+                if (s + 1 < S) LLZ_PF_FETCH(s + 1, cB, aB, TB)
+                pf_section(u, cA, aA, TA, lane, su1[s], su2[s], sy1[s], sy2[s]);
+                if (s + 1 == S) LLZ_PF_FETCH(0, cA, aA, TA)            // odd S: set A is free only now (once per chunk)
+            } else {
+                LLZ_PF_WAIT(cB, aB);
+                LLZ_PF_FETCH((s + 1 < S ? s + 1 : 0), cA, aA, TA)
+                pf_section(u, cB, aB, TB, lane, su1[s], su2[s], sy1[s], sy2[s]);
+            }
+        }
+        if (chunk >= skip) {
+            float *dst = orow + (size_t)chunk * 1024;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                *reinterpret_cast<float4 *>(dst + 4 * q) = make_float4((float)u[4 * q], (float)u[4 * q + 1], (float)u[4 * q + 2], (float)u[4 * q + 3]);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // nothing in flight when the wave ends
+#undef LLZ_PF_FETCH
+#undef LLZ_PF_TIE
+#undef LLZ_PF_WAIT
+    if (lane == 0 && seg == segs - 1) {
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            double *st = state + ((size_t)c * S + s) * 4;
+            st[0] = su1[s]; st[1] = su2[s]; st[2] = sy1[s]; st[3] = sy2[s];
         }
     }
 }
@@ -765,12 +919,24 @@ static int launch_iir_wave(const float *in, float *out, const R *coef, const R *
     // on 128 channels: about three rounds of items are best while a segment stays long (>= 64 chunks: the per-item cost
     // of warm-up and table load, ~1.4 chunks, stays small and the hardware balances the rounds), otherwise exactly one
     // round; segments at least 8 x the warm-up.
-    const bool packed = std::is_same<R, float>::value && ph32 && (stages == 2 || stages == 4 || stages == 6 || stages == 8);
+    // the one-section-ahead kernels (packed float32 / double); LLZ_IIR_UNPACKED=1 keeps the first wave kernels for A/B
+    static const bool first_version = getenv("LLZ_IIR_UNPACKED") != nullptr;
+    const bool ahead = !first_version && (std::is_same<R, double>::value || ph32 != nullptr);
     const void *kfn = nullptr;
-    if constexpr (std::is_same<R, float>::value) {
-        if (packed)
-            kfn = stages == 2 ? (const void *)k_iir_cascade_wave_pk<2> : stages == 4 ? (const void *)k_iir_cascade_wave_pk<4>
-                : stages == 6 ? (const void *)k_iir_cascade_wave_pk<6> : (const void *)k_iir_cascade_wave_pk<8>;
+    if (ahead) {
+        if constexpr (std::is_same<R, float>::value) {
+            static const void *const tab[8] = {
+                (const void *)k_iir_cascade_wave_pk<1>, (const void *)k_iir_cascade_wave_pk<2>, (const void *)k_iir_cascade_wave_pk<3>,
+                (const void *)k_iir_cascade_wave_pk<4>, (const void *)k_iir_cascade_wave_pk<5>, (const void *)k_iir_cascade_wave_pk<6>,
+                (const void *)k_iir_cascade_wave_pk<7>, (const void *)k_iir_cascade_wave_pk<8>};
+            kfn = tab[stages - 1];
+        } else {
+            static const void *const tab[8] = {
+                (const void *)k_iir_cascade_wave_pf64<1>, (const void *)k_iir_cascade_wave_pf64<2>, (const void *)k_iir_cascade_wave_pf64<3>,
+                (const void *)k_iir_cascade_wave_pf64<4>, (const void *)k_iir_cascade_wave_pf64<5>, (const void *)k_iir_cascade_wave_pf64<6>,
+                (const void *)k_iir_cascade_wave_pf64<7>, (const void *)k_iir_cascade_wave_pf64<8>};
+            kfn = tab[stages - 1];
+        }
     }
     if (!kfn)
         kfn = stages <= 2 ? (const void *)k_iir_cascade_wave<R, 2> : stages <= 4 ? (const void *)k_iir_cascade_wave<R, 4>
@@ -800,19 +966,30 @@ static int launch_iir_wave(const float *in, float *out, const R *coef, const R *
     segs = (nchunks + seg_chunks - 1) / seg_chunks;
     const long items = (long)channels * segs;
     const dim3 grid((unsigned)((items + 3) / 4));
-    if constexpr (std::is_same<R, float>::value) {
-        if (packed) {                                                  // packed kernel: even section counts
-#define LLZ_PK_LAUNCH(S)                                                                                             \
+    if (ahead) {
+        if constexpr (std::is_same<R, float>::value) {
+#define LLZ_AHEAD_LAUNCH(S)                                                                                          \
     hipLaunchKernelGGL((k_iir_cascade_wave_pk<S>), grid, dim3(256), 0, as_stream(stream), in, out, pd, pl, ph32, state, \
                        nchunks, in_pitch, out_pitch, segs, seg_chunks, warm_chunks, items)
-            if (stages == 2) LLZ_PK_LAUNCH(2);
-            else if (stages == 4) LLZ_PK_LAUNCH(4);
-            else if (stages == 6) LLZ_PK_LAUNCH(6);
-            else LLZ_PK_LAUNCH(8);
-#undef LLZ_PK_LAUNCH
-            LLZ_LAUNCH_CHECK("k_iir_cascade_wave_pk");
-            return LLZ_OK;
+            switch (stages) {
+            case 1: LLZ_AHEAD_LAUNCH(1); break; case 2: LLZ_AHEAD_LAUNCH(2); break; case 3: LLZ_AHEAD_LAUNCH(3); break;
+            case 4: LLZ_AHEAD_LAUNCH(4); break; case 5: LLZ_AHEAD_LAUNCH(5); break; case 6: LLZ_AHEAD_LAUNCH(6); break;
+            case 7: LLZ_AHEAD_LAUNCH(7); break; default: LLZ_AHEAD_LAUNCH(8); break;
+            }
+#undef LLZ_AHEAD_LAUNCH
+        } else {
+#define LLZ_AHEAD_LAUNCH(S)                                                                                          \
+    hipLaunchKernelGGL((k_iir_cascade_wave_pf64<S>), grid, dim3(256), 0, as_stream(stream), in, out, coef, pd, pl,      \
+                       state, nchunks, in_pitch, out_pitch, segs, seg_chunks, warm_chunks, items)
+            switch (stages) {
+            case 1: LLZ_AHEAD_LAUNCH(1); break; case 2: LLZ_AHEAD_LAUNCH(2); break; case 3: LLZ_AHEAD_LAUNCH(3); break;
+            case 4: LLZ_AHEAD_LAUNCH(4); break; case 5: LLZ_AHEAD_LAUNCH(5); break; case 6: LLZ_AHEAD_LAUNCH(6); break;
+            case 7: LLZ_AHEAD_LAUNCH(7); break; default: LLZ_AHEAD_LAUNCH(8); break;
+            }
+#undef LLZ_AHEAD_LAUNCH
         }
+        LLZ_LAUNCH_CHECK("k_iir_cascade_wave (one section ahead)");
+        return LLZ_OK;
     }
 #define LLZ_WAVE_LAUNCH(S)                                                                                           \
     hipLaunchKernelGGL((k_iir_cascade_wave<R, S>), grid, dim3(256), 0, as_stream(stream), in, out, coef, pd, pl,        \
