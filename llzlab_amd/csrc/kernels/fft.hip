@@ -381,6 +381,103 @@ k_fft1024_f32(float *__restrict__ data, int count, const float *__restrict__ cs 
         __builtin_nontemporal_store((f32x2){v[q].x, v[q].y}, &g[l5 + 32 * brev5(q)]);
 }
 
+// FFT autocorrelation for fft_len = 2048 (frames of 513..1024 samples) on the half-wave machinery.  Both 2048-point
+// transforms of llz_corr.c:155-177 act on real data, so each is ONE 1024-point complex transform:
+//   forward: z[m] = x[2m] + j x[2m+1]; Z = FFT_1024(z); with Zm = Z[1024-k]: Xe = (Z[k] + conj(Zm))/2,
+//            Xo = (Z[k] - conj(Zm))/(2j), T = W_2048^k Xo:  X[k] = Xe + T,  X[1024-k] = conj(Xe - T);
+//   power:   P[b] = |X[b]|^2 / 2048 for b < n (the reference squares only the first n bins), else 0;
+//   inverse: r[k] = 2 Re sum_{b<n} P[b] W^-bk is the real inverse transform of the symmetric spectrum S[b] = S[2048-b] =
+//            P[b] (b >= 1), S[0] = 2 P[0], S[1024] = 0:  G[b] = (S[b] + S[1024-b]) + j conj(W^b) (S[b] - S[1024-b]),
+//            g = IFFT_1024(G) unnormalised, r[2m] = Re g[m], r[2m+1] = Im g[m].
+// The mirrored bin lives in lane (32 - l) of the same half-wave: one more LDS round trip per plane.  For p < 64 only
+// g[0..31] is needed, i.e. bin 0 of the second register pass: 31 complex adds instead of a 32-point transform.
+__global__ void __launch_bounds__(256)
+k_acf2048_f32(const float *__restrict__ x, float *__restrict__ r, int frames, int n, int p,
+              const float *__restrict__ cs /* 2048 cos, then 2048 sin of 2 pi i / 2048 */)
+{
+    __shared__ float2 s_tw[1024];                                  // W_1024^(a*b), [a][b]
+    __shared__ float2 s_w2[1024];                                  // W_2048^k, k < 1024
+    __shared__ float bufs[8][OLS_XBUF];
+    const int tid = threadIdx.x, hw = tid >> 5, l5 = tid & 31;
+    for (int i = tid; i < 1024; i += 256) {
+        const int m = (2 * (i >> 5) * (i & 31)) & 2047;
+        s_tw[i] = make_float2(cs[m], -cs[2048 + m]);
+        s_w2[i] = make_float2(cs[i], -cs[2048 + i]);
+    }
+    __syncthreads();
+    const long t = (long)blockIdx.x * 8 + hw;
+    if (t >= frames) return;
+    const float *g = x + t * n;
+    float *buf = bufs[hw];
+    cf v[32];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {                                 // 2 m < 1024: the upper half of z is padding
+        const int i0 = 2 * (l5 + 32 * j);
+        v[j].x = i0 < n ? g[i0] : 0.f;
+        v[j].y = i0 + 1 < n ? g[i0 + 1] : 0.f;
+    }
+#pragma unroll
+    for (int j = 16; j < 32; j++) v[j] = cf{0.f, 0.f};
+    fft32<false>(v);
+    transpose_twiddle<false>(v, buf, s_tw, l5);
+    fft32<false>(v);                                               // v[q] = Z[l5 + 32 brev5(q)]
+    // mirrored bins: Z[1024 - k] sits in lane (32 - l5) & 31 at column index 31 - j (lane 0: (32 - j) & 31)
+    const int lm = (32 - l5) & 31;
+    float mx[32];
+#pragma unroll
+    for (int q = 0; q < 32; q++) buf[xaddr(brev5(q), l5)] = v[q].x;
+    OLS_WAVE_SYNC();
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+        const int j = brev5(q);
+        mx[q] = buf[l5 ? xaddr(31 - j, lm) : xaddr((32 - j) & 31, 0)];
+    }
+    OLS_WAVE_SYNC();
+#pragma unroll
+    for (int q = 0; q < 32; q++) buf[xaddr(brev5(q), l5)] = v[q].y;
+    OLS_WAVE_SYNC();
+    const float sc = 1.0f / (4.0f * 2048.0f);                      // the two halvings of (Xe, Xo) and llz_ifft's 1/N
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+        const int j = brev5(q);
+        const int k = l5 + 32 * j;
+        const float my = buf[l5 ? xaddr(31 - j, lm) : xaddr((32 - j) & 31, 0)];
+        const float2 w = s_w2[k];                                  // (cos, -sin) of pi k / 1024
+        const cf xe = {v[q].x + mx[q], v[q].y - my};               // 2 Xe
+        const cf xo = {v[q].y + my, mx[q] - v[q].x};               // 2 Xo
+        const cf T = cmul<false>(xo, cf{w.x, w.y});
+        const cf a = cadd(xe, T), b = csub(xe, T);
+        float sk = __builtin_fmaf(a.x, a.x, a.y * a.y) * sc, sm = __builtin_fmaf(b.x, b.x, b.y * b.y) * sc;
+        if (k >= n) sk = 0.f;
+        if (1024 - k >= n) sm = 0.f;
+        if (k == 0) { sk *= 2.f; sm = 0.f; }                       // S[0] = 2 P[0]; the mirror of bin 0 is bin 1024: unused
+        const float dk = sk - sm;
+        v[q] = cf{__builtin_fmaf(w.y, dk, sk + sm), w.x * dk};     // (S + Sm) + j (c + j s) dk,  w.y = -s
+    }
+    OLS_WAVE_SYNC();
+    cf u[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) u[j] = v[brev5(j)];               // bin order -> natural order: register renaming
+    fft32<true>(u);
+    transpose_twiddle<true>(u, buf, s_tw, l5);
+    float *rr = r + t * (p + 1);
+    if (p < 64) {                                                  // only g[l5] = the sum over the column index
+        cf acc = u[0];
+#pragma unroll
+        for (int q = 1; q < 32; q++) acc = cadd(acc, u[q]);
+        if (2 * l5 <= p) rr[2 * l5] = acc.x;
+        if (2 * l5 + 1 <= p) rr[2 * l5 + 1] = acc.y;
+    } else {
+        fft32<true>(u);                                            // u[q] = g[l5 + 32 brev5(q)]
+#pragma unroll
+        for (int q = 0; q < 32; q++) {
+            const int m = l5 + 32 * brev5(q);
+            if (2 * m <= p) rr[2 * m] = u[q].x;
+            if (2 * m + 1 <= p) rr[2 * m + 1] = u[q].y;
+        }
+    }
+}
+
 // fft_len = 1024 synthesis: as k_stft_synthesis_f32, with the inverse transforms on the half-wave machinery (8 frames per
 // group, one per half-wave): bins from HBM straight into registers with the Hermitian upper half taken from the mirrored
 // bin, windowed real output written to an LDS segment image, then the same overlap-add walk.
@@ -801,6 +898,12 @@ extern "C" int llzs_acf_fused_f32(const float *x, float *r, int frames, int n, i
         (1 << log2n) != size || 2 * n > size) {
         llzs_set_error("acf_fused_f32: bad arguments (n=%d p=%d size=%d)", n, p, size);
         return LLZ_ERR_ARG;
+    }
+    if (size == 2048 && !getenv("LLZ_FFT_GENERIC")) {              // two real 2048-point transforms = two complex 1024-point ones
+        hipLaunchKernelGGL(k_acf2048_f32, dim3((unsigned)((frames + 7) / 8)), dim3(256), 0, as_stream(stream), x, r,
+                           frames, n, p, cs);
+        LLZ_LAUNCH_CHECK("k_acf2048_f32");
+        return LLZ_OK;
     }
     const int passes = (log2n + 3) / 4;
     unsigned groups = 0;

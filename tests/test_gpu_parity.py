@@ -631,7 +631,11 @@ def test_autocorr_mc_direct_vs_oracle(dev, oracle, frames, n, p):
     assert np.array_equal(r2, rd.cpu().numpy())
 
 
-@pytest.mark.parametrize("frames,n,p", [(9, 300, 16), (4, 1024, 32), (3, 2048, 100), (70000, 16, 8)])
+@pytest.mark.parametrize("frames,n,p", [(9, 300, 16), (4, 1024, 32), (3, 2048, 100), (70000, 16, 8),
+                                        # fft_len 2048 runs as two 1024-point complex transforms (k_acf2048_f32): even / odd
+                                        # frame lengths, p below and above the pruned-inverse limit of 64, partial groups
+                                        (5000, 1024, 16), (7, 1000, 63), (3, 513, 200), (6, 777, 64), (5, 1023, 1500),
+                                        (11, 600, 0)])
 def test_autocorr_fast_mc_vs_oracle(dev, oracle, frames, n, p):
     if frames > 1000:
         x = np.tile(oracle.synth_f32(8, n, seed=3), (frames // 8, 1))
