@@ -752,6 +752,148 @@ __global__ void k_fft_2xsquare_tables(float2 *__restrict__ tw2d, float2 *__restr
     tw1[i] = make_float2(cs[m1], -cs[N + m1]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// MDCT by the N/4-point FFT (llz_mdct.c:266-353, mdct2 / imdct2) on the register transforms: a group of E lanes per
+// frame, N/4 = E^2 (TWO = false: N = 256, 1024, 4096) or 2 E^2 (TWO = true: N = 512, 2048, 8192).  The pre-twiddled
+// points are formed straight from HBM into the registers of the lane that transforms them and the post-twiddled results
+// go straight back (the rotations 2k / N-1-2k are stride-2 walks up and down the same rows: every line is used whole,
+// half by each walk), so the only LDS traffic left is the transpose inside the group.
+//   forward: in = x [count][N], out = X [count][N/2];   inverse: in = X [count][N/2], out = x [count][N]
+// tc/ts: cos and sin of -2 pi (k + 1/8) / N, k < N/4 (llz_mdct.c:459-462).  Both directions use the FORWARD transform.
+template <int E, bool TWO, bool INVERSE>
+__global__ void __launch_bounds__(256)
+k_mdct_reg_f32(const float *__restrict__ in, float *__restrict__ out, int count, const float *__restrict__ tc,
+               const float *__restrict__ ts, const float2 *__restrict__ tw2d, const float2 *__restrict__ tw1,
+               float sqrt_cof)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int H = E * E, N4 = TWO ? 2 * H : H, N = 4 * N4, N2 = N / 2, GROUPS = 256 / E, PITCH = E + 1;
+    __shared__ float bufs[GROUPS][E * PITCH];
+    const int tid = threadIdx.x, grp = tid / E, lg = tid % E;
+    const long t = (long)blockIdx.x * GROUPS + grp;
+    if (t >= count) return;                                        // whole groups leave together: no barrier below
+    const float *x = in + t * (INVERSE ? N2 : N);
+    float *y = out + t * (INVERSE ? N : N2);
+    float *buf = bufs[grp];
+    // The point k and its mirror N/4-1-k share their rows pairwise: x[2k] goes to k, x[2k+1] to the mirror, and so on.
+    // The mirror of (lane lg, register j) is (lane E-1-lg, register E-1-j) -- in bin order (lane E-1-lg, register q^(E-1))
+    // -- so every HBM access is an aligned pair (or quad) per lane and the other half changes lanes by one swizzle.
+    auto mir = [](float v) {
+        return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), ((E - 1) << 10) | 0x1F));   // lane ^ (E-1)
+    };
+    // rot[i] = -x[i + 3N/4] (i < N/4), x[i - N/4] otherwise (llz_mdct.c:279-283); pairs never straddle N/4
+    auto rot2 = [&](int i) {
+        const f32x2 v = *reinterpret_cast<const f32x2 *>(i < N4 ? x + i + 3 * N4 : x + i - N4);
+        return i < N4 ? -v : v;
+    };
+    // z[k] = 0.5 (re + j im) (c + j s), (c, s) = cos, sin of -2 pi (k + 1/8) / N
+    auto pre = [&](int k, float re, float im) {
+        const float c = tc[k], sn = ts[k];
+        return cf{0.5f * (re * c - im * sn), 0.5f * (re * sn + im * c)};
+    };
+    cf s[E], d[E];                                                 // d: the odd-bin half of TWO (unused otherwise)
+#pragma unroll
+    for (int j = 0; j < E / 2; j++) {
+        const int jm = E - 1 - j;
+        // square: points k = lg + E j and lg + E jm.  TWO: a-points n = lg + E j (registers of s) and b-points n + H (d);
+        // the mirror of an a-point is a b-point and vice versa.
+        const int ka = lg + E * j, kb = lg + E * jm;
+        if (!INVERSE) {
+            // own: r0 = rot[2k], r3 = rot[N/2+2k];  from the mirror: r2 = rot[2k+1] (= rot[N/2-1-2k']), r1 = rot[N/2+2k+1]
+            if (!TWO) {
+                const f32x2 Aa = rot2(2 * ka), Ba = rot2(N2 + 2 * ka), Ab = rot2(2 * kb), Bb = rot2(N2 + 2 * kb);
+                const float r2a = mir(Ab.y), r1a = mir(Bb.y), r2b = mir(Aa.y), r1b = mir(Ba.y);
+                s[j] = pre(ka, Aa.x - r1a, r2a - Ba.x);
+                s[jm] = pre(kb, Ab.x - r1b, r2b - Bb.x);
+            } else {
+                const f32x2 Aa = rot2(2 * ka), Ba = rot2(N2 + 2 * ka), Ab = rot2(2 * kb), Bb = rot2(N2 + 2 * kb);
+                const f32x2 Ca = rot2(2 * (ka + H)), Da = rot2(N2 + 2 * (ka + H));
+                const f32x2 Cb = rot2(2 * (kb + H)), Db = rot2(N2 + 2 * (kb + H));
+                // a-point ka <- mirror lane's b-point kb + H (its register jm = our j's partner): C/D of index b
+                const cf a0 = pre(ka, Aa.x - mir(Db.y), mir(Cb.y) - Ba.x);
+                const cf b0 = pre(ka + H, Ca.x - mir(Bb.y), mir(Ab.y) - Da.x);
+                const cf a1 = pre(kb, Ab.x - mir(Da.y), mir(Ca.y) - Bb.x);
+                const cf b1 = pre(kb + H, Cb.x - mir(Ba.y), mir(Aa.y) - Db.x);
+                const float2 w0 = tw1[j * E + lg], w1 = tw1[jm * E + lg];
+                s[j] = cadd(a0, b0); d[j] = cmul<false>(csub(a0, b0), cf{w0.x, w0.y});
+                s[jm] = cadd(a1, b1); d[jm] = cmul<false>(csub(a1, b1), cf{w1.x, w1.y});
+            }
+        } else {
+            // re = X[2k] (own), im = X[N/2-1-2k] = X[2k'+1] of the mirror (llz_mdct.c:322-324)
+            if (!TWO) {
+                const f32x2 Pa = *reinterpret_cast<const f32x2 *>(x + 2 * ka), Pb = *reinterpret_cast<const f32x2 *>(x + 2 * kb);
+                s[j] = pre(ka, Pa.x, mir(Pb.y));
+                s[jm] = pre(kb, Pb.x, mir(Pa.y));
+            } else {
+                const f32x2 Pa = *reinterpret_cast<const f32x2 *>(x + 2 * ka), Pb = *reinterpret_cast<const f32x2 *>(x + 2 * kb);
+                const f32x2 Qa = *reinterpret_cast<const f32x2 *>(x + 2 * (ka + H)), Qb = *reinterpret_cast<const f32x2 *>(x + 2 * (kb + H));
+                const cf a0 = pre(ka, Pa.x, mir(Qb.y)), b0 = pre(ka + H, Qa.x, mir(Pb.y));
+                const cf a1 = pre(kb, Pb.x, mir(Qa.y)), b1 = pre(kb + H, Qb.x, mir(Pa.y));
+                const float2 w0 = tw1[j * E + lg], w1 = tw1[jm * E + lg];
+                s[j] = cadd(a0, b0); d[j] = cmul<false>(csub(a0, b0), cf{w0.x, w0.y});
+                s[jm] = cadd(a1, b1); d[jm] = cmul<false>(csub(a1, b1), cf{w1.x, w1.y});
+            }
+        }
+    }
+    square_core<E, false>(s, buf, tw2d, lg);                       // square: s[q] = Z[lg + E brevE(q)]
+    if constexpr (TWO) square_core<E, false>(d, buf, tw2d, lg);    // TWO: s[q] = Z[2 kq], d[q] = Z[2 kq + 1], kq = lg + E brevE(q)
+    // post-twiddle: (c + j s) v
+    auto post = [&](int k, cf v) {
+        const float c = tc[k], sn = ts[k];
+        return cf{v.x * c - v.y * sn, v.x * sn + v.y * c};
+    };
+    // rot[ri], rot[ri+1] = (v0, v1) -> x (llz_mdct.c:331-352): x[i] = rot[N/4 + i] cof (i < 3N/4), -rot[i - 3N/4] cof else
+    auto unrot2 = [&](int ri, float v0, float v1) {
+        if (ri >= N4) *reinterpret_cast<f32x2 *>(y + ri - N4) = (f32x2){v0 * sqrt_cof, v1 * sqrt_cof};
+        else *reinterpret_cast<f32x2 *>(y + ri + 3 * N4) = (f32x2){-v0 * sqrt_cof, -v1 * sqrt_cof};
+    };
+    auto unrot4 = [&](int ri, float v0, float v1, float v2, float v3) {
+        if (ri >= N4) *reinterpret_cast<f32x4 *>(y + ri - N4) = (f32x4){v0, v1, v2, v3} * sqrt_cof;
+        else *reinterpret_cast<f32x4 *>(y + ri + 3 * N4) = (f32x4){v0, v1, v2, v3} * -sqrt_cof;
+    };
+#pragma unroll
+    for (int q = 0; q < E; q++) {
+        const int qm = q ^ (E - 1);
+        if (q > qm) continue;                                      // pairs (q, qm): bins kq and (on the mirror lane) N4-1-kq
+        const int kq = lg + E * brevE<E>(q), km = lg + E * brevE<E>(qm);
+        if (!INVERSE) {
+            // X[2b] = 2 Re', X[N/2-1-2b] = -2 Im' (llz_mdct.c:296-301); X[2b+1] is the -2 Im' of the mirror bin
+            if (!TWO) {
+                const cf pa = post(kq, s[q]), pb = post(km, s[qm]);
+                const float oa = mir(-2.f * pb.y), ob = mir(-2.f * pa.y);
+                *reinterpret_cast<f32x2 *>(y + 2 * kq) = (f32x2){2.f * pa.x, oa};
+                *reinterpret_cast<f32x2 *>(y + 2 * km) = (f32x2){2.f * pb.x, ob};
+            } else {
+                const cf sa = post(2 * kq, s[q]), da = post(2 * kq + 1, d[q]), sb = post(2 * km, s[qm]), db = post(2 * km + 1, d[qm]);
+                // the mirror of an even bin is an odd bin of the mirror lane's partner register, and vice versa
+                const float e0 = mir(-2.f * db.y), e1 = mir(-2.f * sb.y), f0 = mir(-2.f * da.y), f1 = mir(-2.f * sa.y);
+                *reinterpret_cast<f32x4 *>(y + 4 * kq) = (f32x4){2.f * sa.x, e0, 2.f * da.x, e1};
+                *reinterpret_cast<f32x4 *>(y + 4 * km) = (f32x4){2.f * sb.x, f0, 2.f * db.x, f1};
+            }
+        } else {
+            // rot[2b] = re', rot[N/2+2b] = im', rot[2b+1] = -im' of the mirror bin, rot[N/2+2b+1] = -re' of the mirror bin
+            const float g = 8.f * sqrt_cof;
+            if (!TWO) {
+                const cf pa = post(kq, s[q]), pb = post(km, s[qm]);
+                const float ia = mir(pb.y), ra = mir(pb.x), ib = mir(pa.y), rb = mir(pa.x);
+                unrot2(2 * kq, g * pa.x, -g * ia);
+                unrot2(N2 + 2 * kq, g * pa.y, -g * ra);
+                unrot2(2 * km, g * pb.x, -g * ib);
+                unrot2(N2 + 2 * km, g * pb.y, -g * rb);
+            } else {
+                const cf sa = post(2 * kq, s[q]), da = post(2 * kq + 1, d[q]), sb = post(2 * km, s[qm]), db = post(2 * km + 1, d[qm]);
+                const float dbi = mir(db.y), dbr = mir(db.x), sbi = mir(sb.y), sbr = mir(sb.x);
+                const float dai = mir(da.y), dar = mir(da.x), sai = mir(sa.y), sar = mir(sa.x);
+                unrot4(4 * kq, g * sa.x, -g * dbi, g * da.x, -g * sbi);
+                unrot4(N2 + 4 * kq, g * sa.y, -g * dbr, g * da.y, -g * sbr);
+                unrot4(4 * km, g * sb.x, -g * dai, g * db.x, -g * sai);
+                unrot4(N2 + 4 * km, g * sb.y, -g * dar, g * db.y, -g * sar);
+            }
+        }
+    }
+}
+
 // fills tw2d from the handle's table cs (cos then sin of 2 pi i / N): exactly the host-built values
 __global__ void k_fft_square_table(float2 *__restrict__ tw2d, const float *__restrict__ cs, int E)
 {
@@ -876,6 +1018,62 @@ extern "C" int llzs_fft_f32(float *data, int count, int size, const float *cs, i
         return LLZ_OK;
     }
     return launch_fft<arith_f32>(data, count, size, cs, inverse, stream, "k_fft_radix2<f32>");
+}
+
+// MDCT frames on the register transforms (see k_mdct_reg_f32).  N in {256, 512, 1024, 2048, 4096, 8192}; cs: the FFT
+// table of size N/4 the twiddle tables are derived from once per device and size.  Returns LLZ_ERR_RANGE for other N.
+extern "C" int llzs_mdct4_reg_f32(const float *in, float *out, int count, int N, const float *tc, const float *ts,
+                                  const float *cs, int inverse, void *stream)
+{
+    int E = 0, two = 0;
+    switch (N) {
+    case 256: E = 8; break;  case 1024: E = 16; break; case 4096: E = 32; break;
+    case 512: E = 8; two = 1; break; case 2048: E = 16; two = 1; break; case 8192: E = 32; two = 1; break;
+    default: return LLZ_ERR_RANGE;
+    }
+    if (!in || !out || !tc || !ts || !cs || count < 1) {
+        llzs_set_error("mdct4_reg_f32: bad arguments");
+        return LLZ_ERR_ARG;
+    }
+    static float2 *tabs[16][3][2][2];                              // [device][E = 8, 16, 32][two][tw2d, tw1]
+    int dev = 0;
+    LLZ_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) dev = 0;
+    const int slot = E == 8 ? 0 : E == 16 ? 1 : 2, H = E * E;
+    if (!tabs[dev][slot][two][0]) {
+        float2 *a = nullptr, *b = nullptr;
+        LLZ_HIP_CHECK(hipMalloc(&a, sizeof(float2) * (size_t)H));
+        if (two) {
+            LLZ_HIP_CHECK(hipMalloc(&b, sizeof(float2) * (size_t)H));
+            hipLaunchKernelGGL(k_fft_2xsquare_tables, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, as_stream(stream), a,
+                               b, cs, E);
+        } else {
+            hipLaunchKernelGGL(k_fft_square_table, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, as_stream(stream), a, cs,
+                               E);
+        }
+        LLZ_LAUNCH_CHECK("mdct twiddle tables");
+        LLZ_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));   // published only once complete
+        tabs[dev][slot][two][1] = b;
+        tabs[dev][slot][two][0] = a;
+    }
+    const float2 *tw2d = tabs[dev][slot][two][0], *tw1 = tabs[dev][slot][two][1];
+    const unsigned blocks = (unsigned)((count + (256 / E) - 1) / (256 / E));
+    const float sqrt_cof = (float)(1.0 / sqrt((double)N));
+#define LLZ_MDCT_LAUNCH(EE, TT, II)                                                                                  \
+    hipLaunchKernelGGL((k_mdct_reg_f32<EE, TT, II>), dim3(blocks), dim3(256), 0, as_stream(stream), in, out, count, tc,  \
+                       ts, tw2d, tw1, sqrt_cof)
+#define LLZ_MDCT_PICK(EE)                                                                                            \
+    do {                                                                                                             \
+        if (two) { if (inverse) LLZ_MDCT_LAUNCH(EE, true, true); else LLZ_MDCT_LAUNCH(EE, true, false); }            \
+        else { if (inverse) LLZ_MDCT_LAUNCH(EE, false, true); else LLZ_MDCT_LAUNCH(EE, false, false); }              \
+    } while (0)
+    if (E == 8) LLZ_MDCT_PICK(8);
+    else if (E == 16) LLZ_MDCT_PICK(16);
+    else LLZ_MDCT_PICK(32);
+#undef LLZ_MDCT_PICK
+#undef LLZ_MDCT_LAUNCH
+    LLZ_LAUNCH_CHECK("k_mdct_reg_f32");
+    return LLZ_OK;
 }
 
 extern "C" int llzs_fft_f64(double *data, int size, const double *cs, int inverse, void *stream)

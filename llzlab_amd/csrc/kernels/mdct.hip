@@ -153,6 +153,10 @@ extern "C" int llzs_mdct4_f32(const float *in, float *out, int count, int N, con
         llzs_set_error("mdct4_f32: bad arguments (N=%d must be a power of two in 32..8192, count=%d)", N, count);
         return LLZ_ERR_ARG;
     }
+    if (!getenv("LLZ_FFT_GENERIC")) {                              // the six sizes with a register-transform kernel
+        const int rc = llzs_mdct4_reg_f32(in, out, count, N, tc, ts, cs, inverse, stream);
+        if (rc != LLZ_ERR_RANGE) return rc;
+    }
     const int N4 = N >> 2, log2n4 = log2n - 2;
     int tpw = 2048 / N4;
     if (tpw > count) tpw = count;

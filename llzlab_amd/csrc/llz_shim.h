@@ -149,6 +149,9 @@ int llzs_matvec_q15(const short *A, const int *x, int *y, int rows, int cols, vo
  * tc/ts: cos/sin of -2*pi*(k+1/8)/N, k < N/4; cs: cos then sin of 2*pi*i/(N/4) */
 int llzs_mdct4_f32(const float *in, float *out, int count, int N, const float *tc, const float *ts, const float *cs,
                    int inverse, void *stream);
+/* the same on the register transforms for N in {256, 512, 1024, 2048, 4096, 8192}; LLZ_ERR_RANGE for other N */
+int llzs_mdct4_reg_f32(const float *in, float *out, int count, int N, const float *tc, const float *ts, const float *cs,
+                       int inverse, void *stream);
 
 /* ---- PCM ingest / egress ---- */
 int llzs_pcm_deinterleave_i16_f32(const short *in, float *out, int channels, long n, float scale, void *stream);

@@ -809,7 +809,9 @@ def test_mdct_reference_symbols_exact(dev):
         filters.Mdct(5, 64)
 
 
-@pytest.mark.parametrize("n,count", [(32, 5), (64, 1000), (256, 33), (2048, 9), (8192, 3)])
+@pytest.mark.parametrize("n,count", [(32, 5), (64, 1000), (256, 33), (2048, 9), (8192, 3),
+                                     # all six register-transform sizes (k_mdct_reg_f32), counts that leave partial workgroups
+                                     (256, 1000), (512, 77), (1024, 50), (2048, 130), (4096, 21), (8192, 19)])
 def test_mdct_batch_vs_oracle(dev, oracle, n, count):
     rng = np.random.default_rng(n + count)
     x = rng.uniform(-1, 1, (count, n)).astype(np.float32)
