@@ -752,6 +752,75 @@ __global__ void k_fft_2xsquare_tables(float2 *__restrict__ tw2d, float2 *__restr
     tw1[i] = make_float2(cs[m1], -cs[N + m1]);
 }
 
+// FFT autocorrelation for fft_len = 2 E^2 on a group of E lanes (E = 8: frames of 33..64 samples, E = 16: 129..256): the
+// scheme of k_acf2048_f32 (which is the E = 32 case on the half-wave functions, with the pruned inverse) written on
+// square_core.  tw2d: [E][E] table of the E^2-point transform; w2: W_(2 E^2)^k, k < E^2.
+template <int E>
+__global__ void __launch_bounds__(256)
+k_acf_sq_f32(const float *__restrict__ x, float *__restrict__ r, int frames, int n, int p,
+             const float2 *__restrict__ tw2d, const float *__restrict__ cs /* 2H cos, then 2H sin of 2 pi i / (2H) */)
+{
+    constexpr int H = E * E, F = 2 * H, GROUPS = 256 / E, PITCH = E + 1;
+    __shared__ float bufs[GROUPS][E * PITCH];
+    const int tid = threadIdx.x, grp = tid / E, lg = tid % E;
+    const long t = (long)blockIdx.x * GROUPS + grp;
+    if (t >= frames) return;
+    const float *g = x + t * n;
+    float *buf = bufs[grp];
+    cf v[E];
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const int i0 = 2 * (lg + E * j);
+        v[j].x = (j < E / 2 && i0 < n) ? g[i0] : 0.f;              // 2 m < H: the upper half of z is padding
+        v[j].y = (j < E / 2 && i0 + 1 < n) ? g[i0 + 1] : 0.f;
+    }
+    square_core<E, false>(v, buf, tw2d, lg);                       // v[q] = Z[lg + E brevE(q)]
+    const int lm = (E - lg) % E;
+    float mx[E];
+#pragma unroll
+    for (int q = 0; q < E; q++) buf[brevE<E>(q) * PITCH + lg] = v[q].x;
+    OLS_WAVE_SYNC();
+#pragma unroll
+    for (int q = 0; q < E; q++) {
+        const int j = brevE<E>(q);
+        mx[q] = buf[lg ? (E - 1 - j) * PITCH + lm : ((E - j) % E) * PITCH];
+    }
+    OLS_WAVE_SYNC();
+#pragma unroll
+    for (int q = 0; q < E; q++) buf[brevE<E>(q) * PITCH + lg] = v[q].y;
+    OLS_WAVE_SYNC();
+    const float sc = 1.0f / (4.0f * (float)F);
+#pragma unroll
+    for (int q = 0; q < E; q++) {
+        const int j = brevE<E>(q);
+        const int k = lg + E * j;
+        const float my = buf[lg ? (E - 1 - j) * PITCH + lm : ((E - j) % E) * PITCH];
+        const float wc = cs[k], ws = -cs[F + k];                   // W_F^k = (cos, -sin)
+        const cf xe = {v[q].x + mx[q], v[q].y - my};
+        const cf xo = {v[q].y + my, mx[q] - v[q].x};
+        const cf T = cmul<false>(xo, cf{wc, ws});
+        const cf a = cadd(xe, T), b = csub(xe, T);
+        float sk = __builtin_fmaf(a.x, a.x, a.y * a.y) * sc, sm = __builtin_fmaf(b.x, b.x, b.y * b.y) * sc;
+        if (k >= n) sk = 0.f;
+        if (H - k >= n) sm = 0.f;
+        if (k == 0) { sk *= 2.f; sm = 0.f; }
+        const float dk = sk - sm;
+        v[q] = cf{__builtin_fmaf(ws, dk, sk + sm), wc * dk};
+    }
+    OLS_WAVE_SYNC();
+    cf u[E];
+#pragma unroll
+    for (int j = 0; j < E; j++) u[j] = v[brevE<E>(j)];
+    square_core<E, true>(u, buf, tw2d, lg);                        // u[q] = g[lg + E brevE(q)]
+    float *rr = r + t * (p + 1);
+#pragma unroll
+    for (int q = 0; q < E; q++) {
+        const int m = lg + E * brevE<E>(q);
+        if (2 * m <= p) rr[2 * m] = u[q].x;
+        if (2 * m + 1 <= p) rr[2 * m + 1] = u[q].y;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // MDCT by the N/4-point FFT (llz_mdct.c:266-353, mdct2 / imdct2) on the register transforms: a group of E lanes per
 // frame, N/4 = E^2 (TWO = false: N = 256, 1024, 4096) or 2 E^2 (TWO = true: N = 512, 2048, 8192).  The pre-twiddled
@@ -892,6 +961,15 @@ k_mdct_reg_f32(const float *__restrict__ in, float *__restrict__ out, int count,
             }
         }
     }
+}
+
+// [E][E] table of the H = E^2 point transform from a table cs of the DOUBLE size F = 2H: W_H^(k1 l) = W_F^(2 k1 l)
+__global__ void k_acf_sq_table(float2 *__restrict__ tw2d, const float *__restrict__ cs, int E)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, H = E * E, F = 2 * H;
+    if (i >= H) return;
+    const int m = (2 * (i / E) * (i % E)) & (F - 1);
+    tw2d[i] = make_float2(cs[m], -cs[F + m]);
 }
 
 // fills tw2d from the handle's table cs (cos then sin of 2 pi i / N): exactly the host-built values
@@ -1096,6 +1174,26 @@ extern "C" int llzs_acf_fused_f32(const float *x, float *r, int frames, int n, i
         (1 << log2n) != size || 2 * n > size) {
         llzs_set_error("acf_fused_f32: bad arguments (n=%d p=%d size=%d)", n, p, size);
         return LLZ_ERR_ARG;
+    }
+    if ((size == 128 || size == 512) && !getenv("LLZ_FFT_GENERIC")) {   // the same on square_core (E = 8, 16)
+        static float2 *tabs[16][2];
+        int dev = 0;
+        LLZ_HIP_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 16) dev = 0;
+        const int E = size == 128 ? 8 : 16, slot = size == 128 ? 0 : 1, H = E * E;
+        if (!tabs[dev][slot]) {
+            float2 *a = nullptr;
+            LLZ_HIP_CHECK(hipMalloc(&a, sizeof(float2) * (size_t)H));
+            hipLaunchKernelGGL(k_acf_sq_table, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, as_stream(stream), a, cs, E);
+            LLZ_LAUNCH_CHECK("k_acf_sq_table");
+            LLZ_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+            tabs[dev][slot] = a;
+        }
+        const unsigned blocks = (unsigned)((frames + (256 / E) - 1) / (256 / E));
+        if (E == 8) hipLaunchKernelGGL(k_acf_sq_f32<8>, dim3(blocks), dim3(256), 0, as_stream(stream), x, r, frames, n, p, tabs[dev][slot], cs);
+        else hipLaunchKernelGGL(k_acf_sq_f32<16>, dim3(blocks), dim3(256), 0, as_stream(stream), x, r, frames, n, p, tabs[dev][slot], cs);
+        LLZ_LAUNCH_CHECK("k_acf_sq_f32");
+        return LLZ_OK;
     }
     if (size == 2048 && !getenv("LLZ_FFT_GENERIC")) {              // two real 2048-point transforms = two complex 1024-point ones
         hipLaunchKernelGGL(k_acf2048_f32, dim3((unsigned)((frames + 7) / 8)), dim3(256), 0, as_stream(stream), x, r,

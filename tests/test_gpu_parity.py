@@ -635,7 +635,9 @@ def test_autocorr_mc_direct_vs_oracle(dev, oracle, frames, n, p):
                                         # fft_len 2048 runs as two 1024-point complex transforms (k_acf2048_f32): even / odd
                                         # frame lengths, p below and above the pruned-inverse limit of 64, partial groups
                                         (5000, 1024, 16), (7, 1000, 63), (3, 513, 200), (6, 777, 64), (5, 1023, 1500),
-                                        (11, 600, 0)])
+                                        (11, 600, 0),
+                                        # fft_len 128 and 512 on the E = 8 / 16 lane groups (k_acf_sq_f32)
+                                        (50, 64, 20), (40, 200, 33), (300, 256, 16), (9, 130, 255), (5, 33, 3), (70, 255, 500)])
 def test_autocorr_fast_mc_vs_oracle(dev, oracle, frames, n, p):
     if frames > 1000:
         x = np.tile(oracle.synth_f32(8, n, seed=3), (frames // 8, 1))
