@@ -102,18 +102,14 @@ constexpr int RSL_R = 8;
 __global__ void __launch_bounds__(RS_THREADS)
 k_resample_f32_lds(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
                    const float *__restrict__ g, long n_in, long n_out, long in_pitch, long out_pitch, int L, int M, int Q,
-                   float gain, long long i0, long long in0, int qpad)
+                   float gain, long long i0, long long in0, int qpad, int tiles_per_block)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *gl = reinterpret_cast<float *>(smem_raw);               // [L][qpad], zero beyond Q
     float *xs = gl + (size_t)L * qpad + 8;                          // 8 zero floats in front: the padded taps read there
     const int c = blockIdx.y;
-    const long o0 = (long)blockIdx.x * (RS_THREADS * RSL_R);
-    const long olast = min(o0 + RS_THREADS * RSL_R, n_out) - 1;
-    const long pos_first = (long)(((i0 + o0) * M) / L - in0);
-    const long pos_last = (long)(((i0 + olast) * M) / L - in0);
-    const long base = pos_first - (Q - 1);
-    const int span = (int)(pos_last - base + 1);
+    // the tap matrix is staged ONCE per workgroup and serves tiles_per_block tiles of RSL_R * 256 outputs (with one tile per
+    // workgroup a 147 x 47 matrix, 30 KB, was re-read from L2 for every 2048 outputs: more bytes than the signal itself)
     for (int e = threadIdx.x; e < L * qpad; e += RS_THREADS) {
         const int l = e / qpad, k = e - l * qpad;
         gl[e] = k < Q ? g[(size_t)l * Q + k] : 0.f;
@@ -121,46 +117,58 @@ k_resample_f32_lds(const float *__restrict__ in, float *__restrict__ out, const 
     if (threadIdx.x < 8) xs[-8 + (int)threadIdx.x] = 0.f;
     const float *row = in + (size_t)c * in_pitch;
     const float *hrow = hist ? hist + (size_t)c * (Q - 1) : nullptr;
-    for (int p = threadIdx.x; p < span; p += RS_THREADS) {
-        const long idx = base + p;
-        float v = 0.f;
-        if (idx >= 0) {
-            if (idx < n_in) v = row[idx];
-        } else if (hrow && idx >= -(long)(Q - 1)) {
-            v = hrow[(Q - 1) + idx];
-        }
-        xs[p] = v;
-    }
-    __syncthreads();
-    // index arithmetic once per lane, then by increments: output i+256 sits (256*M) input-steps/L further, i.e. the
-    // position advances by dq (+1 on a carry of the remainder) and the phase by 256 mod L -- no division per output
-    const long i_first = o0 + threadIdx.x;
-    if (i_first >= n_out) return;
-    const long long gi0 = i0 + i_first;
-    const long long num = gi0 * M;
-    int pos = (int)(num / L - in0 - base);                          // LDS index of x[(gi*M)/L]
-    int rem = (int)(num % L);
-    int ph = (int)(gi0 % L);
     const int dq = (RS_THREADS * M) / L, dr = (RS_THREADS * M) % L, dph = RS_THREADS % L;
 #pragma unroll 1
-    for (int r = 0; r < RSL_R; r++) {
-        const long i = i_first + r * RS_THREADS;
-        if (i >= n_out) break;
-        const float *xp = xs + pos;                                 // taps walk backwards from here
-        const float *trow = gl + (size_t)ph * qpad;
-        float acc = 0.f;
-        for (int k = 0; k < qpad; k += 4) {
-            const float4 t = *reinterpret_cast<const float4 *>(trow + k);
-            acc = __builtin_fmaf(xp[-k], t.x, acc);
-            acc = __builtin_fmaf(xp[-k - 1], t.y, acc);
-            acc = __builtin_fmaf(xp[-k - 2], t.z, acc);
-            acc = __builtin_fmaf(xp[-k - 3], t.w, acc);
+    for (int tile = 0; tile < tiles_per_block; tile++) {
+        const long o0 = ((long)blockIdx.x * tiles_per_block + tile) * (RS_THREADS * RSL_R);
+        if (o0 >= n_out) break;                                     // uniform
+        const long olast = min(o0 + RS_THREADS * RSL_R, n_out) - 1;
+        const long pos_first = (long)(((i0 + o0) * M) / L - in0);
+        const long pos_last = (long)(((i0 + olast) * M) / L - in0);
+        const long base = pos_first - (Q - 1);
+        const int span = (int)(pos_last - base + 1);
+        if (tile) __syncthreads();                                  // the previous tile's readers are done with xs
+        for (int p = threadIdx.x; p < span; p += RS_THREADS) {
+            const long idx = base + p;
+            float v = 0.f;
+            if (idx >= 0) {
+                if (idx < n_in) v = row[idx];
+            } else if (hrow && idx >= -(long)(Q - 1)) {
+                v = hrow[(Q - 1) + idx];
+            }
+            xs[p] = v;
         }
-        out[(size_t)c * out_pitch + i] = acc * gain;
-        pos += dq; rem += dr;
-        if (rem >= L) { rem -= L; pos++; }
-        ph += dph;
-        if (ph >= L) ph -= L;
+        __syncthreads();
+        // index arithmetic once per lane and tile, then by increments: output i+256 sits (256*M) input-steps/L further,
+        // i.e. the position advances by dq (+1 on a carry of the remainder) and the phase by 256 mod L -- no division per
+        // output
+        const long i_first = o0 + threadIdx.x;
+        if (i_first >= n_out) continue;                             // (every lane still reaches the barriers above)
+        const long long gi0 = i0 + i_first;
+        const long long num = gi0 * M;
+        int pos = (int)(num / L - in0 - base);                      // LDS index of x[(gi*M)/L]
+        int rem = (int)(num % L);
+        int ph = (int)(gi0 % L);
+#pragma unroll 1
+        for (int r = 0; r < RSL_R; r++) {
+            const long i = i_first + r * RS_THREADS;
+            if (i >= n_out) break;
+            const float *xp = xs + pos;                             // taps walk backwards from here
+            const float *trow = gl + (size_t)ph * qpad;
+            float acc = 0.f;
+            for (int k = 0; k < qpad; k += 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(trow + k);
+                acc = __builtin_fmaf(xp[-k], t.x, acc);
+                acc = __builtin_fmaf(xp[-k - 1], t.y, acc);
+                acc = __builtin_fmaf(xp[-k - 2], t.z, acc);
+                acc = __builtin_fmaf(xp[-k - 3], t.w, acc);
+            }
+            out[(size_t)c * out_pitch + i] = acc * gain;
+            pos += dq; rem += dr;
+            if (rem >= L) { rem -= L; pos++; }
+            ph += dph;
+            if (ph >= L) ph -= L;
+        }
     }
 }
 
@@ -434,9 +442,17 @@ extern "C" int llzs_resample_f32(const float *in, float *out, const float *hist,
         const int span_max = (int)(((long)(RS_THREADS * RSL_R - 1) * M + L - 1) / L) + 1 + Q;
         const size_t lds = ((size_t)L * qpad + 8 + span_max) * sizeof(float);
         if (lds <= 64 * 1024 && !getenv("LLZ_RS_GENERIC_OLD")) {
-            dim3 grid((unsigned)((n_out + RS_THREADS * RSL_R - 1) / (RS_THREADS * RSL_R)), (unsigned)channels);
+            // tiles per workgroup: enough to amortise the tap matrix (its size in tile-spans, x4), while the grid keeps
+            // at least ~8 workgroups per CU
+            const long tiles = (n_out + RS_THREADS * RSL_R - 1) / (RS_THREADS * RSL_R);
+            long tpb = (4L * L * qpad + span_max - 1) / span_max;
+            const long cap = tiles * channels / 2048;
+            if (tpb > cap) tpb = cap;
+            if (tpb < 1) tpb = 1;
+            if (const char *e = getenv("LLZ_RS_TILES")) { const int v = atoi(e); if (v >= 1) tpb = v; }
+            dim3 grid((unsigned)((tiles + tpb - 1) / tpb), (unsigned)channels);
             hipLaunchKernelGGL(k_resample_f32_lds, grid, dim3(RS_THREADS), lds, as_stream(stream), in, out, hist, g, n_in,
-                               n_out, in_pitch, out_pitch, L, M, Q, gain, i0, in0, qpad);
+                               n_out, in_pitch, out_pitch, L, M, Q, gain, i0, in0, qpad, (int)tpb);
             LLZ_LAUNCH_CHECK("k_resample_f32_lds");
             return LLZ_OK;
         }
