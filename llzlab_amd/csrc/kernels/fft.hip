@@ -752,6 +752,61 @@ __global__ void k_fft_2xsquare_tables(float2 *__restrict__ tw2d, float2 *__restr
     tw1[i] = make_float2(cs[m1], -cs[N + m1]);
 }
 
+// Analysis frames for fft_len = E^2 (E = 16: 256) or 2 E^2 (TWO; E = 16: 512, E = 32: 2048) on a group of E lanes per
+// frame: k_stft_analysis1024_f32's scheme on square_core -- windowed samples from HBM straight into the registers of the
+// lane that transforms them, bins 0..size/2 straight back.
+template <int E, bool TWO>
+__global__ void __launch_bounds__(256)
+k_stft_analysis_reg_f32(const float *__restrict__ x, const float *__restrict__ hist, float *__restrict__ re,
+                        float *__restrict__ im, const float *__restrict__ w, int frames, int F,
+                        const float2 *__restrict__ tw2d, const float2 *__restrict__ tw1, long x_pitch, long total_tr)
+{
+    constexpr int H = E * E, SIZE = TWO ? 2 * H : H, GROUPS = 256 / E, PITCH = E + 1, BINS = SIZE / 2 + 1;
+    __shared__ float bufs[GROUPS][E * PITCH];
+    const int tid = threadIdx.x, grp = tid / E, lg = tid % E;
+    const long g = (long)blockIdx.x * GROUPS + grp;
+    if (g >= total_tr) return;
+    const int c = (int)(g / frames), f = (int)(g - (long)c * frames);
+    const int keep = SIZE - F;
+    const long t0 = (long)(f + 1) * F - SIZE;
+    const float *row = x + (size_t)c * x_pitch;
+    const float *hrow = hist + (size_t)c * keep;
+    float *buf = bufs[grp];
+    auto sample = [&](int i) {
+        const long t = t0 + i;
+        return (t >= 0 ? row[t] : hrow[keep + t]) * w[i];
+    };
+    const size_t o = (size_t)g * BINS;
+    if (!TWO) {
+        cf v[E];
+#pragma unroll
+        for (int j = 0; j < E; j++) v[j] = cf{sample(lg + E * j), 0.f};
+        square_core<E, false>(v, buf, tw2d, lg);                    // v[q] = X[lg + E brevE(q)]
+#pragma unroll
+        for (int q = 0; q < E; q++) {
+            const int bin = lg + E * brevE<E>(q);
+            if (bin < BINS) { re[o + bin] = v[q].x; im[o + bin] = v[q].y; }
+        }
+    } else {
+        cf s[E], d[E];
+#pragma unroll
+        for (int j = 0; j < E; j++) {                               // real input: s, d before the twist are real
+            const float a = sample(lg + E * j), b = sample(lg + E * j + H);
+            const float2 t = tw1[j * E + lg];
+            s[j] = cf{a + b, 0.f};
+            d[j] = cf{(a - b) * t.x, (a - b) * t.y};
+        }
+        square_core<E, false>(s, buf, tw2d, lg);                    // s[q] = X[2 kq], d[q] = X[2 kq + 1], kq = lg + E brevE(q)
+        square_core<E, false>(d, buf, tw2d, lg);
+#pragma unroll
+        for (int q = 0; q < E; q++) {
+            const int bin = 2 * (lg + E * brevE<E>(q));
+            if (bin < BINS) { re[o + bin] = s[q].x; im[o + bin] = s[q].y; }
+            if (bin + 1 < BINS) { re[o + bin + 1] = d[q].x; im[o + bin + 1] = d[q].y; }
+        }
+    }
+}
+
 // FFT autocorrelation for fft_len = 2 E^2 on a group of E lanes (E = 8: frames of 33..64 samples, E = 16: 129..256): the
 // scheme of k_acf2048_f32 (which is the E = 32 case on the half-wave functions, with the pruned inverse) written on
 // square_core.  tw2d: [E][E] table of the E^2-point transform; w2: W_(2 E^2)^k, k < E^2.
@@ -1260,6 +1315,42 @@ extern "C" int llzs_stft_analysis_f32(const float *x, const float *hist, float *
     const int rc = stft_check(channels, frames, F, size, &log2n, "stft_analysis_f32");
     if (rc != LLZ_OK) return rc;
     const long total_tr = (long)channels * frames;
+    if ((size == 256 || size == 512 || size == 2048) && !getenv("LLZ_FFT_GENERIC")) {
+        static float2 *tabs[16][3][2];                              // [device][256, 512, 2048][tw2d, tw1]
+        int dev = 0;
+        LLZ_HIP_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 16) dev = 0;
+        const int slot = size == 256 ? 0 : size == 512 ? 1 : 2, E = size == 2048 ? 32 : 16, H = E * E;
+        if (!tabs[dev][slot][0]) {
+            float2 *a = nullptr, *b = nullptr;
+            LLZ_HIP_CHECK(hipMalloc(&a, sizeof(float2) * (size_t)H));
+            if (size == 256) {
+                hipLaunchKernelGGL(k_fft_square_table, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, as_stream(stream), a,
+                                   cs, E);
+            } else {
+                LLZ_HIP_CHECK(hipMalloc(&b, sizeof(float2) * (size_t)H));
+                hipLaunchKernelGGL(k_fft_2xsquare_tables, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, as_stream(stream),
+                                   a, b, cs, E);
+            }
+            LLZ_LAUNCH_CHECK("stft twiddle tables");
+            LLZ_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+            tabs[dev][slot][1] = b;
+            tabs[dev][slot][0] = a;
+        }
+        const float2 *tw2d = tabs[dev][slot][0], *tw1 = tabs[dev][slot][1];
+        const unsigned blocks = (unsigned)((total_tr + (256 / E) - 1) / (256 / E));
+        if (size == 256)
+            hipLaunchKernelGGL((k_stft_analysis_reg_f32<16, false>), dim3(blocks), dim3(256), 0, as_stream(stream), x, hist,
+                               re, im, w, frames, F, tw2d, tw1, x_pitch, total_tr);
+        else if (size == 512)
+            hipLaunchKernelGGL((k_stft_analysis_reg_f32<16, true>), dim3(blocks), dim3(256), 0, as_stream(stream), x, hist, re,
+                               im, w, frames, F, tw2d, tw1, x_pitch, total_tr);
+        else
+            hipLaunchKernelGGL((k_stft_analysis_reg_f32<32, true>), dim3(blocks), dim3(256), 0, as_stream(stream), x, hist, re,
+                               im, w, frames, F, tw2d, tw1, x_pitch, total_tr);
+        LLZ_LAUNCH_CHECK("k_stft_analysis_reg_f32");
+        return LLZ_OK;
+    }
     if (size == 1024 && !getenv("LLZ_FFT_GENERIC")) {
         hipLaunchKernelGGL(k_stft_analysis1024_f32, dim3((unsigned)((total_tr + 7) / 8)), dim3(256), 0, as_stream(stream),
                            x, hist, re, im, w, frames, F, cs, x_pitch, total_tr);

@@ -709,7 +709,8 @@ def test_stft_reference_symbols_exact(dev):
 
 @pytest.mark.parametrize("hint,frame_len,win", [(0, 2, po.HAMMING), (0, 64, po.BLACKMAN), (0, 512, po.KAISER),
                                                 (1, 4, po.KAISER), (1, 128, po.HAMMING), (1, 1024, po.BLACKMAN),
-                                                (0, 256, po.KAISER), (1, 512, po.HAMMING)])      # fft_len 1024 twice
+                                                (0, 256, po.KAISER), (1, 512, po.HAMMING),       # fft_len 1024 twice
+                                                (0, 128, po.HAMMING), (1, 256, po.KAISER)])      # fft_len 512 twice
 @pytest.mark.parametrize("channels,frames", [(3, 7), (2, 70), (5, 1)])
 def test_stft_mc_vs_oracle_streaming(dev, oracle, hint, frame_len, win, channels, frames):
     """batch analysis and synthesis against the oracle run channel by channel, in TWO calls so that the history and the
