@@ -807,6 +807,101 @@ k_stft_analysis_reg_f32(const float *__restrict__ x, const float *__restrict__ h
     }
 }
 
+// Synthesis frames for the same sizes: k_stft_synthesis1024_f32's walk (bins from HBM into registers with the Hermitian
+// upper half taken from the mirrored bin, inverse transform, windowed real output into an LDS segment image, overlap-add
+// in the reference's order, oldest frame first) with 256 / E frames per group on square_core.
+template <int E, bool TWO>
+__global__ void __launch_bounds__(256)
+k_stft_synthesis_reg_f32(const float *__restrict__ re, const float *__restrict__ im, float *__restrict__ x,
+                         const float *__restrict__ ola_old, float *__restrict__ ola_new, const float *__restrict__ w,
+                         int frames, int F, const float2 *__restrict__ tw2d, const float2 *__restrict__ tw1, long x_pitch,
+                         int run_len, int runs, float magic)
+{
+    constexpr int H = E * E, N = TWO ? 2 * H : H, TPW = 256 / E, PITCH = E + 1, BINS = N / 2 + 1;
+    constexpr int MAXM = ((TPW - 1) * (N / 2) + N + 255) / 256;       // span of a group at the largest hop (N/2)
+    __shared__ float bufs[TPW][E * PITCH];
+    __shared__ float seg[TPW][N];
+    __shared__ float carry[N];                                         // N - F used
+    const int tid = threadIdx.x, grp = tid / E, lg = tid % E;
+    const int c = blockIdx.x / runs, run = blockIdx.x - c * runs;
+    const int b0 = run * run_len, b1 = min(frames, b0 + run_len);
+    const int R = N / F, keep = N - F;
+    const int fs = max(0, b0 - (R - 1));
+    for (int q = tid; q < keep; q += 256) carry[q] = fs == 0 ? ola_old[(size_t)c * keep + q] : 0.f;
+    constexpr float sc = 1.0f / (float)N;
+    for (int g0 = fs; g0 < b1; g0 += TPW) {
+        const int ng = min(TPW, b1 - g0);
+        __syncthreads();                                               // carry and seg of the previous group are consumed
+        if (grp < ng) {
+            const size_t o = ((size_t)c * frames + g0 + grp) * BINS;
+            auto bin = [&](int k) {                                    // upper half: conjugate of the mirrored bin
+                const int kk = k <= N / 2 ? k : N - k;
+                const float a = re[o + kk] * sc, b = im[o + kk] * sc;
+                return cf{a, k <= N / 2 ? b : -b};
+            };
+            float *buf = bufs[grp];
+            if (!TWO) {
+                cf v[E];
+#pragma unroll
+                for (int j = 0; j < E; j++) v[j] = bin(lg + E * j);
+                square_core<E, true>(v, buf, tw2d, lg);                // v[q].x = sample lg + E brevE(q)
+#pragma unroll
+                for (int q = 0; q < E; q++) {
+                    const int n = lg + E * brevE<E>(q);
+                    seg[grp][n] = v[q].x * w[n];
+                }
+            } else {
+                cf s[E], d[E];
+#pragma unroll
+                for (int j = 0; j < E; j++) {
+                    s[j] = bin(2 * (lg + E * j));
+                    d[j] = bin(2 * (lg + E * j) + 1);
+                }
+                square_core<E, true>(s, buf, tw2d, lg);
+                square_core<E, true>(d, buf, tw2d, lg);
+#pragma unroll
+                for (int q = 0; q < E; q++) {                          // n = lg + E brevE(q): x[n], x[n + H] = s +- d conj(W_N^n)
+                    const int n = lg + E * brevE<E>(q);
+                    const float2 t = tw1[brevE<E>(q) * E + lg];
+                    const float wdx = __builtin_fmaf(d[q].y, t.y, d[q].x * t.x);   // Re(d * conj(t))
+                    seg[grp][n] = (s[q].x + wdx) * w[n];
+                    seg[grp][n + H] = (s[q].x - wdx) * w[n + H];
+                }
+            }
+        }
+        __syncthreads();
+        const int span = (ng - 1) * F + N;
+        float acc[MAXM];
+#pragma unroll
+        for (int m = 0; m < MAXM; m++) {
+            const int p = tid + m * 256;
+            float a = 0.f;
+            if (p < span) {
+                a = p < keep ? carry[p] : 0.f;
+                const int k_hi = min(ng - 1, p / F);
+                const int k_lo = p < N ? 0 : (p - N) / F + 1;
+                for (int k = k_lo; k <= k_hi; k++) a += seg[k][p - k * F];
+            }
+            acc[m] = a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MAXM; m++) {
+            const int p = tid + m * 256;
+            if (p < span) {
+                if (p < ng * F) {
+                    if (g0 + p / F >= b0) x[(size_t)c * x_pitch + (size_t)g0 * F + p] = magic * acc[m];
+                } else {
+                    carry[p - ng * F] = acc[m];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (b1 == frames)
+        for (int q = tid; q < keep; q += 256) ola_new[(size_t)c * keep + q] = carry[q];
+}
+
 // FFT autocorrelation for fft_len = 2 E^2 on a group of E lanes (E = 8: frames of 33..64 samples, E = 16: 129..256): the
 // scheme of k_acf2048_f32 (which is the E = 32 case on the half-wave functions, with the pruned inverse) written on
 // square_core.  tw2d: [E][E] table of the E^2-point transform; w2: W_(2 E^2)^k, k < E^2.
@@ -1303,6 +1398,36 @@ static int stft_check(int channels, int frames, int F, int size, int *log2n, con
     return LLZ_OK;
 }
 
+// twiddle tables of the lane-group kernels for fft_len 256 (E = 16), 512 (2 x 16^2), 2048 (2 x 32^2), derived once per
+// device from the handle's table cs
+static int stft_reg_tables(int size, const float *cs, void *stream, const float2 **tw2d, const float2 **tw1)
+{
+    static float2 *tabs[16][3][2];                                  // [device][256, 512, 2048][tw2d, tw1]
+    int dev = 0;
+    LLZ_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) dev = 0;
+    const int slot = size == 256 ? 0 : size == 512 ? 1 : 2, E = size == 2048 ? 32 : 16, H = E * E;
+    if (!tabs[dev][slot][0]) {
+        float2 *a = nullptr, *b = nullptr;
+        LLZ_HIP_CHECK(hipMalloc(&a, sizeof(float2) * (size_t)H));
+        if (size == 256) {
+            hipLaunchKernelGGL(k_fft_square_table, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, as_stream(stream), a, cs,
+                               E);
+        } else {
+            LLZ_HIP_CHECK(hipMalloc(&b, sizeof(float2) * (size_t)H));
+            hipLaunchKernelGGL(k_fft_2xsquare_tables, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, as_stream(stream), a,
+                               b, cs, E);
+        }
+        LLZ_LAUNCH_CHECK("stft twiddle tables");
+        LLZ_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+        tabs[dev][slot][1] = b;
+        tabs[dev][slot][0] = a;
+    }
+    *tw2d = tabs[dev][slot][0];
+    *tw1 = tabs[dev][slot][1];
+    return LLZ_OK;
+}
+
 extern "C" int llzs_stft_analysis_f32(const float *x, const float *hist, float *re, float *im, const float *w,
                                       const float *cs, int channels, int frames, int F, int size, long x_pitch,
                                       void *stream)
@@ -1316,28 +1441,10 @@ extern "C" int llzs_stft_analysis_f32(const float *x, const float *hist, float *
     if (rc != LLZ_OK) return rc;
     const long total_tr = (long)channels * frames;
     if ((size == 256 || size == 512 || size == 2048) && !getenv("LLZ_FFT_GENERIC")) {
-        static float2 *tabs[16][3][2];                              // [device][256, 512, 2048][tw2d, tw1]
-        int dev = 0;
-        LLZ_HIP_CHECK(hipGetDevice(&dev));
-        if (dev < 0 || dev >= 16) dev = 0;
-        const int slot = size == 256 ? 0 : size == 512 ? 1 : 2, E = size == 2048 ? 32 : 16, H = E * E;
-        if (!tabs[dev][slot][0]) {
-            float2 *a = nullptr, *b = nullptr;
-            LLZ_HIP_CHECK(hipMalloc(&a, sizeof(float2) * (size_t)H));
-            if (size == 256) {
-                hipLaunchKernelGGL(k_fft_square_table, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, as_stream(stream), a,
-                                   cs, E);
-            } else {
-                LLZ_HIP_CHECK(hipMalloc(&b, sizeof(float2) * (size_t)H));
-                hipLaunchKernelGGL(k_fft_2xsquare_tables, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, as_stream(stream),
-                                   a, b, cs, E);
-            }
-            LLZ_LAUNCH_CHECK("stft twiddle tables");
-            LLZ_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
-            tabs[dev][slot][1] = b;
-            tabs[dev][slot][0] = a;
-        }
-        const float2 *tw2d = tabs[dev][slot][0], *tw1 = tabs[dev][slot][1];
+        const float2 *tw2d = nullptr, *tw1 = nullptr;
+        const int trc = stft_reg_tables(size, cs, stream, &tw2d, &tw1);
+        if (trc != LLZ_OK) return trc;
+        const int E = size == 2048 ? 32 : 16;
         const unsigned blocks = (unsigned)((total_tr + (256 / E) - 1) / (256 / E));
         if (size == 256)
             hipLaunchKernelGGL((k_stft_analysis_reg_f32<16, false>), dim3(blocks), dim3(256), 0, as_stream(stream), x, hist,
@@ -1387,6 +1494,27 @@ extern "C" int llzs_stft_synthesis_f32(const float *re, const float *im, float *
     int run_len = (int)(want < 8 * R ? 8 * R : want);
     if (run_len < tpw) run_len = tpw;
     if (run_len > frames) run_len = frames;
+    if ((size == 256 || size == 512 || size == 2048) && !getenv("LLZ_FFT_GENERIC")) {
+        const float2 *tw2d = nullptr, *tw1 = nullptr;
+        const int trc = stft_reg_tables(size, cs, stream, &tw2d, &tw1);
+        if (trc != LLZ_OK) return trc;
+        const int gt = size == 2048 ? 8 : 16;                           // frames per group
+        if (run_len < gt * R) run_len = gt * R;
+        if (run_len > frames) run_len = frames;
+        const int runsr = (frames + run_len - 1) / run_len;
+        const dim3 grid((unsigned)((long)channels * runsr));
+        if (size == 256)
+            hipLaunchKernelGGL((k_stft_synthesis_reg_f32<16, false>), grid, dim3(256), 0, as_stream(stream), re, im, x, ola_old,
+                               ola_new, w, frames, F, tw2d, tw1, x_pitch, run_len, runsr, magic);
+        else if (size == 512)
+            hipLaunchKernelGGL((k_stft_synthesis_reg_f32<16, true>), grid, dim3(256), 0, as_stream(stream), re, im, x, ola_old,
+                               ola_new, w, frames, F, tw2d, tw1, x_pitch, run_len, runsr, magic);
+        else
+            hipLaunchKernelGGL((k_stft_synthesis_reg_f32<32, true>), grid, dim3(256), 0, as_stream(stream), re, im, x, ola_old,
+                               ola_new, w, frames, F, tw2d, tw1, x_pitch, run_len, runsr, magic);
+        LLZ_LAUNCH_CHECK("k_stft_synthesis_reg_f32");
+        return LLZ_OK;
+    }
     if (size == 1024 && !getenv("LLZ_FFT_GENERIC")) {
         if (run_len < 8 * R) run_len = 8 * R;
         if (run_len > frames) run_len = frames;
