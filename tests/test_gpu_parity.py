@@ -889,6 +889,52 @@ def test_fir_ols_chain_form_forced(dev):
     assert r.returncode == 0 and "CHAIN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+_IIR_FIRST_SCRIPT = r'''
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.environ["LLZ_REPO"])
+from llzlab_amd import filters
+from oracle import pyoracle as po
+po.build()
+oracle = po.Oracle()
+dev = torch.device("cuda:0")
+for stages, radius, prec in ((8, 0.44, 32), (3, 0.7, 32), (8, 0.99, 64), (5, 0.97, 64)):
+    rows = []
+    for k in range(stages):
+        r, th = radius - 0.01 * k, 0.3 + 0.2 * k
+        a1, a2 = -2 * r * np.cos(th), r * r
+        rows.append([(1 + a1 + a2) / 4, (1 + a1 + a2) / 2, (1 + a1 + a2) / 4, 1.0, a1, a2])
+    coef = np.array(rows)
+    channels, n = 2048, 1024 * (256 if prec == 64 else 24) + 52
+    f = filters.IirCascadeMC(channels, coef)
+    assert f.precision == prec, (stages, radius, f.precision)
+    sel = [0, 1000, 2047]
+    xs, ys = [], []
+    for call in range(2):
+        x = torch.empty(channels, n, dtype=torch.float32, device=dev)
+        filters.synth_f32(x, seed=90 + call)
+        y = torch.empty_like(x)
+        f.filter(x, y)
+        xs.append(x[sel].cpu().numpy()); ys.append(y[sel].cpu().numpy())
+    f.close()
+    ref = oracle.iir_cascade_batch_f32(np.concatenate(xs, axis=1), coef)
+    got = np.concatenate(ys, axis=1).astype(np.float64)
+    err, scale = float(np.sqrt(np.mean((got - ref) ** 2))), float(np.sqrt(np.mean(ref ** 2)))
+    assert err <= 1e-5 * max(1.0, scale) and err / scale <= 1e-5, (stages, radius, err, scale)
+print("IIR_FIRST_OK")
+'''
+
+
+def test_iir_wave_first_version_kernels(dev):
+    """LLZ_IIR_UNPACKED=1 keeps the first wave-autonomous kernels (no one-section-ahead fetch, no packed arithmetic) for A/B
+    runs; they stay checked here in a child process (the knob is read once per process)"""
+    import subprocess
+    env = dict(os.environ, LLZ_IIR_UNPACKED="1", LLZ_REPO=ROOT)
+    r = subprocess.run([sys.executable, "-c", _IIR_FIRST_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "IIR_FIRST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 # ------------------------------------------------------------------------------------------------ limits and degenerate calls
 def test_limits_and_degenerate_calls(dev, oracle):
     """the largest channel count the batch handles accept, one-sample frames, and refused calls: zero-length frames and

@@ -19,16 +19,23 @@ sptr = stream.cuda_stream
 
 
 def timeit(fn, steps):
+    """mean over >= `steps` calls and >= 30 ms, after >= 30 ms of warm-up calls (a sub-millisecond kernel timed right after
+    idling runs on clocks that have not settled: up to 20 % slow)"""
+    def run(k):
+        t = L.llz_hip_timer_new()
+        L.llz_hip_timer_start(t, sptr)
+        for _ in range(k):
+            fn()
+        L.llz_hip_timer_stop(t, sptr)
+        ms = L.llz_hip_timer_ms(t) / k
+        L.llz_hip_timer_free(t)
+        return ms
     fn()
     torch.cuda.synchronize()
-    t = L.llz_hip_timer_new()
-    L.llz_hip_timer_start(t, sptr)
-    for _ in range(steps):
-        fn()
-    L.llz_hip_timer_stop(t, sptr)
-    ms = L.llz_hip_timer_ms(t) / steps
-    L.llz_hip_timer_free(t)
-    return ms
+    once = max(run(1), 1e-3)
+    reps = max(steps, min(2000, int(30.0 / once) + 1))
+    run(reps)
+    return run(reps)
 
 
 which = sys.argv[1:] or ["iir", "resample", "fir63", "td257", "fft", "corr", "pcm", "stft", "mdct"]
