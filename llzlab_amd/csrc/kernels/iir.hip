@@ -942,18 +942,27 @@ static int launch_iir_wave(const float *in, float *out, const R *coef, const R *
     if (!kfn)
         kfn = stages <= 2 ? (const void *)k_iir_cascade_wave<R, 2> : stages <= 4 ? (const void *)k_iir_cascade_wave<R, 4>
                                                                                   : (const void *)k_iir_cascade_wave<R, 8>;
-    int blocks_per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kfn, 256, 0) != hipSuccess || blocks_per_cu < 1) {
-        (void)hipGetLastError();
-        blocks_per_cu = 2;
+    // (queried once per kernel and process: same answer on every device of a node)
+    static struct { const void *fn; long slots; } seen[24];
+    static int nseen = 0;
+    long slots = 0;
+    for (int i = 0; i < nseen; i++)
+        if (seen[i].fn == kfn) slots = seen[i].slots;
+    if (!slots) {
+        int blocks_per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kfn, 256, 0) != hipSuccess || blocks_per_cu < 1) {
+            (void)hipGetLastError();
+            blocks_per_cu = 2;
+        }
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+            (void)hipGetLastError();
+            cus = 256;
+        }
+        slots = 4L * blocks_per_cu * cus;
+        if (nseen < 24) { seen[nseen].slots = slots; seen[nseen].fn = kfn; nseen++; }   // benign if two threads race
     }
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
-        (void)hipGetLastError();
-        cus = 256;
-    }
-    const long slots = 4L * blocks_per_cu * cus;
     int segs = 1;
     for (int rounds = 3; rounds >= 1; rounds--) {
         segs = (int)((rounds * slots + channels / 2) / channels);
