@@ -1177,12 +1177,12 @@ int launch_fft(typename A::data_t *data, int count, int size, const typename A::
 
 extern "C" int llzs_fft_f32(float *data, int count, int size, const float *cs, int inverse, void *stream)
 {
-    if ((size == 256 || size == 4096) && data && cs && count >= 1 && !getenv("LLZ_FFT_GENERIC")) {
+    if ((size == 64 || size == 256 || size == 4096) && data && cs && count >= 1 && !getenv("LLZ_FFT_GENERIC")) {
         // the [E][E] twiddle table is derived once per device and size from the caller's table (kept for the process)
-        static float2 *tables[16][2];
+        static float2 *tables[16][3];
         int dev = 0;
         LLZ_HIP_CHECK(hipGetDevice(&dev));
-        const int E = size == 256 ? 16 : 64, slot = size == 256 ? 0 : 1;
+        const int E = size == 64 ? 8 : size == 256 ? 16 : 64, slot = size == 64 ? 2 : size == 256 ? 0 : 1;
         if (dev < 0 || dev >= 16) dev = 0;
         if (!tables[dev][slot]) {
             float2 *t = nullptr;
@@ -1195,7 +1195,10 @@ extern "C" int llzs_fft_f32(float *data, int count, int size, const float *cs, i
         }
         const float2 *tw2d = tables[dev][slot];
         const unsigned blocks = (unsigned)((count + (256 / E) - 1) / (256 / E));
-        if (E == 16) {
+        if (E == 8) {
+            if (inverse) hipLaunchKernelGGL((k_fft_square_f32<8, true>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d);
+            else hipLaunchKernelGGL((k_fft_square_f32<8, false>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d);
+        } else if (E == 16) {
             if (inverse) hipLaunchKernelGGL((k_fft_square_f32<16, true>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d);
             else hipLaunchKernelGGL((k_fft_square_f32<16, false>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d);
         } else {
@@ -1205,11 +1208,11 @@ extern "C" int llzs_fft_f32(float *data, int count, int size, const float *cs, i
         LLZ_LAUNCH_CHECK("k_fft_square_f32");
         return LLZ_OK;
     }
-    if ((size == 512 || size == 2048) && data && cs && count >= 1 && !getenv("LLZ_FFT_GENERIC")) {
-        static float2 *tables2[16][2][2];                           // [device][size][tw2d, tw1]
+    if ((size == 128 || size == 512 || size == 2048) && data && cs && count >= 1 && !getenv("LLZ_FFT_GENERIC")) {
+        static float2 *tables2[16][3][2];                           // [device][size][tw2d, tw1]
         int dev = 0;
         LLZ_HIP_CHECK(hipGetDevice(&dev));
-        const int E = size == 512 ? 16 : 32, slot = size == 512 ? 0 : 1, H = E * E;
+        const int E = size == 128 ? 8 : size == 512 ? 16 : 32, slot = size == 128 ? 2 : size == 512 ? 0 : 1, H = E * E;
         if (dev < 0 || dev >= 16) dev = 0;
         if (!tables2[dev][slot][0]) {
             float2 *a = nullptr, *b = nullptr;
@@ -1224,7 +1227,10 @@ extern "C" int llzs_fft_f32(float *data, int count, int size, const float *cs, i
         }
         const float2 *tw2d = tables2[dev][slot][0], *tw1 = tables2[dev][slot][1];
         const unsigned blocks = (unsigned)((count + (256 / E) - 1) / (256 / E));
-        if (E == 16) {
+        if (E == 8) {
+            if (inverse) hipLaunchKernelGGL((k_fft_2xsquare_f32<8, true>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d, tw1);
+            else hipLaunchKernelGGL((k_fft_2xsquare_f32<8, false>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d, tw1);
+        } else if (E == 16) {
             if (inverse) hipLaunchKernelGGL((k_fft_2xsquare_f32<16, true>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d, tw1);
             else hipLaunchKernelGGL((k_fft_2xsquare_f32<16, false>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d, tw1);
         } else {

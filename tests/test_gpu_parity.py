@@ -426,7 +426,8 @@ def test_fft_batch_f32_vs_oracle(dev, oracle, n):
     f.close()
 
 
-@pytest.mark.parametrize("n,count", [(2, 5), (4, 3), (16, 130), (32, 65), (128, 17), (512, 5), (512, 70), (1024, 21), (2048, 3), (2048, 19), (4096, 2)])
+@pytest.mark.parametrize("n,count", [(2, 5), (4, 3), (16, 130), (32, 65), (64, 100), (128, 17), (128, 333), (256, 47), (512, 5), (512, 70),
+                                     (1024, 21), (2048, 3), (2048, 19), (4096, 2)])
 def test_fft_batch_all_sizes_fixed_and_float(dev, oracle, n, count):
     """every power of two, batch counts that do not fill the last workgroup: Q15 bit-exact, float within tolerance"""
     rng = np.random.default_rng(n * 1000 + count)

@@ -117,7 +117,7 @@ if "td257" in which:
     f.close()
 
 if "fft" in which:
-    for n in (256, 512, 1024, 2048, 4096):
+    for n in (64, 128, 256, 512, 1024, 2048, 4096):
         count = (1 << 26) // n                                   # 512 MiB of complex64 / int32 pairs
         z = torch.rand(count, 2 * n, dtype=torch.float32, device=dev) * 2 - 1
         f = filters.FftBatch(n, stream=stream)
