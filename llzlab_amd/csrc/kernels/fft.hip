@@ -478,6 +478,61 @@ k_acf2048_f32(const float *__restrict__ x, float *__restrict__ r, int frames, in
     }
 }
 
+// FFT autocorrelation for fft_len = 1024 (frames of 257..512 samples): the two transforms of llz_corr.c:155-177 as they
+// stand (complex, zero imaginary parts) on the half-wave machinery -- twice the arithmetic of the real-input form above,
+// but a half size of 512 = 2 x 16^2 has no single-group register transform with the mirrored bins in reach, and even so
+// this is several times the staged kernel.  For p < 32 the second inverse pass is its bin 0 only.
+__global__ void __launch_bounds__(256)
+k_acf1024_f32(const float *__restrict__ x, float *__restrict__ r, int frames, int n, int p,
+              const float *__restrict__ cs /* 1024 cos, then 1024 sin of 2 pi i / 1024 */)
+{
+    __shared__ float2 s_tw[1024];                                  // W_1024^(a*b), [a][b]
+    __shared__ float bufs[8][OLS_XBUF];
+    const int tid = threadIdx.x, hw = tid >> 5, l5 = tid & 31;
+    for (int i = tid; i < 1024; i += 256) {
+        const int m = ((i >> 5) * (i & 31)) & 1023;
+        s_tw[i] = make_float2(cs[m], -cs[1024 + m]);
+    }
+    __syncthreads();
+    const long t = (long)blockIdx.x * 8 + hw;
+    if (t >= frames) return;
+    const float *g = x + t * n;
+    float *buf = bufs[hw];
+    cf v[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        const int i = l5 + 32 * j;
+        v[j] = cf{(j < 16 && i < n) ? g[i] : 0.f, 0.f};            // n <= 512: the upper half is padding
+    }
+    fft32<false>(v);
+    transpose_twiddle<false>(v, buf, s_tw, l5);
+    fft32<false>(v);                                               // v[q] = X[l5 + 32 brev5(q)]
+    cf u[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) {                                 // bin l5 + 32 j sits in register brev5(j)
+        const cf z = v[brev5(j)];
+        const int bin = l5 + 32 * j;
+        // |X|^2 / F of the first n bins, everything else zero (llz_corr.c:165-170; the 1/F of llz_ifft folded in)
+        u[j] = cf{bin < n ? __builtin_fmaf(z.x, z.x, z.y * z.y) * (1.0f / 1024.0f) : 0.f, 0.f};
+    }
+    fft32<true>(u);
+    transpose_twiddle<true>(u, buf, s_tw, l5);
+    float *rr = r + t * (p + 1);
+    if (p < 32) {                                                  // only g[l5] = the sum over the column index
+        float acc = u[0].x;
+#pragma unroll
+        for (int q = 1; q < 32; q++) acc += u[q].x;
+        if (l5 <= p) rr[l5] = 2.f * acc;                           // llz_corr.c:173
+    } else {
+        fft32<true>(u);                                            // u[q] = g[l5 + 32 brev5(q)]
+#pragma unroll
+        for (int q = 0; q < 32; q++) {
+            const int k = l5 + 32 * brev5(q);
+            if (k <= p) rr[k] = 2.f * u[q].x;
+        }
+    }
+}
+
 // fft_len = 1024 synthesis: as k_stft_synthesis_f32, with the inverse transforms on the half-wave machinery (8 frames per
 // group, one per half-wave): bins from HBM straight into registers with the Hermitian upper half taken from the mirrored
 // bin, windowed real output written to an LDS segment image, then the same overlap-add walk.
@@ -1349,6 +1404,12 @@ extern "C" int llzs_acf_fused_f32(const float *x, float *r, int frames, int n, i
         if (E == 8) hipLaunchKernelGGL(k_acf_sq_f32<8>, dim3(blocks), dim3(256), 0, as_stream(stream), x, r, frames, n, p, tabs[dev][slot], cs);
         else hipLaunchKernelGGL(k_acf_sq_f32<16>, dim3(blocks), dim3(256), 0, as_stream(stream), x, r, frames, n, p, tabs[dev][slot], cs);
         LLZ_LAUNCH_CHECK("k_acf_sq_f32");
+        return LLZ_OK;
+    }
+    if (size == 1024 && !getenv("LLZ_FFT_GENERIC")) {
+        hipLaunchKernelGGL(k_acf1024_f32, dim3((unsigned)((frames + 7) / 8)), dim3(256), 0, as_stream(stream), x, r, frames,
+                           n, p, cs);
+        LLZ_LAUNCH_CHECK("k_acf1024_f32");
         return LLZ_OK;
     }
     if (size == 2048 && !getenv("LLZ_FFT_GENERIC")) {              // two real 2048-point transforms = two complex 1024-point ones

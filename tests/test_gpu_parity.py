@@ -638,7 +638,9 @@ def test_autocorr_mc_direct_vs_oracle(dev, oracle, frames, n, p):
                                         (5000, 1024, 16), (7, 1000, 63), (3, 513, 200), (6, 777, 64), (5, 1023, 1500),
                                         (11, 600, 0),
                                         # fft_len 128 and 512 on the E = 8 / 16 lane groups (k_acf_sq_f32)
-                                        (50, 64, 20), (40, 200, 33), (300, 256, 16), (9, 130, 255), (5, 33, 3), (70, 255, 500)])
+                                        (50, 64, 20), (40, 200, 33), (300, 256, 16), (9, 130, 255), (5, 33, 3), (70, 255, 500),
+                                        # fft_len 1024 (k_acf1024_f32): pruned (p < 32) and full inverse
+                                        (100, 512, 16), (13, 300, 31), (6, 257, 32), (9, 480, 1000)])
 def test_autocorr_fast_mc_vs_oracle(dev, oracle, frames, n, p):
     if frames > 1000:
         x = np.tile(oracle.synth_f32(8, n, seed=3), (frames // 8, 1))

@@ -133,7 +133,7 @@ if "fft" in which:
         del z, q
 
 if "corr" in which:
-    for (frames, n, p) in ((1 << 18, 1024, 16), (1 << 18, 1024, 64), (1 << 20, 256, 16), (4096, 1 << 18, 32)):
+    for (frames, n, p) in ((1 << 18, 1024, 16), (1 << 18, 1024, 64), (1 << 19, 512, 16), (1 << 20, 256, 16), (4096, 1 << 18, 32)):
         x = torch.rand(frames, n, dtype=torch.float32, device=dev) * 2 - 1
         r = torch.empty(frames, p + 1, dtype=torch.float32, device=dev)
         ms = timeit(lambda: filters.autocorr_mc(x, r, p, stream=stream), 3)
