@@ -347,8 +347,8 @@ int llz_iir_cascade_mc(unsigned long handle, const float *x, float *y, int frame
     const int aligned = (frame_len % 4 == 0) && (((size_t)d_in | (size_t)d_out) % 16 == 0);
     const int chunk = LLZS_IIR_PIPE_CHUNK;
     const int n_fast = aligned ? frame_len - frame_len % chunk : 0;
-    /* short-memory cascades of up to 8 sections: a wave per (channel, time segment), all sections in registers (float32:
-     * 3.65 -> 3.1 ms on config 4; double: 4.76 -> 4.45 ms on the 0.99-radius set) */
+    /* short-memory cascades of up to 8 sections: a wave per (channel, time segment), all sections in registers (float32,
+     * packed: 3.65 -> 2.3 ms on config 4; double: 4.76 -> 3.75 ms on the 0.99-radius set) */
     const char *kern = getenv("LLZ_IIR_KERNEL");
     /* (needs enough (channel, segment) items to fill the chip: segments are at least 8 x the warm-up long) */
     const long seg_items = f->warm_chunks > 0 ? (long)f->channels * (n_fast / LLZS_IIR_PIPE_CHUNK / (8 * f->warm_chunks)) : 0;

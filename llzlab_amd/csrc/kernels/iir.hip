@@ -344,7 +344,9 @@ k_iir_cascade_pipe(const float *__restrict__ in, float *__restrict__ out, const 
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_iir_cascade_wave_f32: float32 cascades whose memory is short (the host has measured both: the rounding-noise gain of
+// k_iir_cascade_wave<R, S> (first version; shipped paths: k_iir_cascade_wave_pk / _pf64 below; kept for LLZ_IIR_UNPACKED
+// A/B runs and checked by tests/test_gpu_parity.py::test_iir_wave_first_version_kernels).
+// Cascades whose memory is short (the host has measured both: the rounding-noise gain of
 // every section and the number of chunks after which a state error has died out).  Same lanes-along-time section step as
 // the pipelined kernel, but a WAVE owns a (channel, time segment) and runs ALL sections of a chunk back to back in
 // registers: no LDS hand-over between sections, no barriers, no conversions in between.  Parallelism comes from the time
