@@ -350,9 +350,11 @@ int llz_iir_cascade_mc(unsigned long handle, const float *x, float *y, int frame
     /* short-memory cascades of up to 8 sections: a wave per (channel, time segment), all sections in registers (float32,
      * packed: 3.65 -> 2.3 ms on config 4; double: 4.76 -> 3.75 ms on the 0.99-radius set) */
     const char *kern = getenv("LLZ_IIR_KERNEL");
-    /* (needs enough (channel, segment) items to fill the chip: segments are at least 8 x the warm-up long) */
+    /* (needs enough (channel, segment) items to fill most of the chip, segments at least 8 x the warm-up long; measured
+     * crossover against the stage pipeline, tools/iir_xover.sh: 1024 items pipeline, 2048 items wave form) */
     const long seg_items = f->warm_chunks > 0 ? (long)f->channels * (n_fast / LLZS_IIR_PIPE_CHUNK / (8 * f->warm_chunks)) : 0;
-    const int wave_form = f->stages <= 8 && seg_items >= 4096 && !(kern && strcmp(kern, "pipe") == 0) &&
+    const char *mi = getenv("LLZ_IIR_WAVE_MIN_ITEMS");                /* crossover experiments */
+    const int wave_form = f->stages <= 8 && seg_items >= (mi ? atol(mi) : 2048) && !(kern && strcmp(kern, "pipe") == 0) &&
                           (!f->float32_ok || f->d_pl32);
     if (rc == LLZ_OK && n_fast > 0 && wave_form && f->float32_ok)
         rc = llzs_iir_cascade_wave_f32(d_in, d_out, f->d_coef32, f->d_pd32, f->d_pl32, f->d_ph32, f->d_state, f->channels, n_fast,

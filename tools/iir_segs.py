@@ -24,7 +24,7 @@ row = [0.2066, 0.4131, 0.2066, 1.0, -0.3695, 0.1958]
 if os.environ.get("HIGHQ"):
     row = [0.01, 0.0, -0.01, 1.0, -2 * 0.99 * np.cos(0.3), 0.99 ** 2]
 q = filters.IirCascadeMC(ch, np.tile(np.array(row), (8, 1)), stream=stream)
-for segs in [0] + [int(v) for v in os.environ.get("SEGS", "3,6,8,9,12,18,24,48,64").split(",")]:
+for segs in [0] + [int(v) for v in os.environ.get("SEGS", "3,6,8,9,12,18,24,48,64").split(",") if int(v) > 0]:
     if segs:
         os.environ["LLZ_IIR_SEGS"] = str(segs)
     for _ in range(max(3, 40 * 1024 // ch)):                            # clocks settle over tens of milliseconds
