@@ -807,6 +807,133 @@ __global__ void k_fft_2xsquare_tables(float2 *__restrict__ tw2d, float2 *__restr
     tw1[i] = make_float2(cs[m1], -cs[N + m1]);
 }
 
+// Q15 transforms (llz_fft_fixed.c:61-218) of N = E^2 (E = 8, 16, 32, 64) or 2 E^2 (TWO; E = 8, 16, 32) points on a group
+// of E lanes, the layout of the float32 register kernels: the radix-2 stages run as two register passes of log2 E stages
+// with one LDS transpose between them (TWO: one more stage across the two halves, which the same lanes hold) -- every
+// butterfly is the reference's butterfly on the reference's operands (arith_q15::rot: four separately floored
+// (int64 * int64) >> 15 products, wrapping adds), so the result is bit-identical; what goes is the index arithmetic and
+// the LDS round trips of the staged passes, which is what those were bound by (0.93e12 butterflies/s at every size: ~30
+// vector instructions per butterfly, 12 of them arithmetic).
+// Forward (DIF), one half: element i = l + E j in register j of lane l; stages with half-span E^2/2 .. E pair registers;
+// transpose; lane m then holds i = E m + c and stages E/2 .. 1 pair registers again; the bit-reversed gather becomes the
+// store pattern.  Inverse (DIT): the mirror image, >> log2 N at the end (llz_fft_fixed.c:212-215).
+template <int E, bool TWO, bool INV>
+__global__ void __launch_bounds__(256)
+k_fft_reg_q15(int *__restrict__ data, int count, const short *__restrict__ cs /* N cos, then N sin, Q15 */)
+{
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    constexpr int H = E * E, N = TWO ? 2 * H : H, GROUPS = 256 / E, PITCH = E + 1, NH = TWO ? 2 : 1;
+    constexpr int LOG = E == 8 ? 3 : E == 16 ? 4 : E == 32 ? 5 : 6, LN = 2 * LOG + (TWO ? 1 : 0);
+    __shared__ int s_tw[N / 2];                                    // (cos, sin) of 2 pi e / N as a pair of shorts
+    __shared__ int bufs[GROUPS][E * PITCH];
+    const int tid = threadIdx.x, grp = tid / E, lg = tid % E;
+    for (int e = tid; e < N / 2; e += 256)
+        s_tw[e] = (int)((unsigned)(unsigned short)cs[e] | ((unsigned)(unsigned short)cs[N + e] << 16));
+    __syncthreads();
+    const long t = (long)blockIdx.x * GROUPS + grp;
+    if (t >= count) return;                                        // whole groups leave together: no barrier below
+    i32x2 *g = reinterpret_cast<i32x2 *>(data) + t * N;
+    int *buf = bufs[grp];
+    const int lrev = (int)(__brev((unsigned)lg) >> (32 - LOG));
+    int vr[NH][E], vi[NH][E];
+    auto transpose = [&](int h) {                                  // (lane a, register b) -> (lane b, register a)
+#pragma unroll
+        for (int b = 0; b < E; b++) buf[b * PITCH + lg] = vr[h][b];
+        OLS_WAVE_SYNC();
+#pragma unroll
+        for (int b = 0; b < E; b++) vr[h][b] = buf[lg * PITCH + b];
+        OLS_WAVE_SYNC();
+#pragma unroll
+        for (int b = 0; b < E; b++) buf[b * PITCH + lg] = vi[h][b];
+        OLS_WAVE_SYNC();
+#pragma unroll
+        for (int b = 0; b < E; b++) vi[h][b] = buf[lg * PITCH + b];
+        OLS_WAVE_SYNC();
+    };
+    // one butterfly of the reference on (ar, ai), (br, bi) with the table entry idx
+    auto bfly = [&](int &ar, int &ai, int &br, int &bi, int idx) {
+        const int tw = s_tw[idx];
+        const short wr = (short)(tw & 0xffff), ws = (short)(tw >> 16);
+        const int ur = ar, ui = ai, wre = br, wim = bi;
+        if (!INV) {                                                // llz_fft_fixed.c:76-92
+            int yr, yi;
+            arith_q15::rot(arith_q15::sub(ur, wre), arith_q15::sub(ui, wim), wr, arith_q15::neg(ws), yr, yi);
+            ar = arith_q15::add(ur, wre); ai = arith_q15::add(ui, wim);
+            br = yr; bi = yi;
+        } else {                                                   // llz_fft_fixed.c:122-137
+            int dr, di;
+            arith_q15::rot(wre, wim, wr, ws, dr, di);
+            ar = arith_q15::add(ur, dr); ai = arith_q15::add(ui, di);
+            br = arith_q15::sub(ur, dr); bi = arith_q15::sub(ui, di);
+        }
+    };
+    if (!INV) {
+#pragma unroll
+        for (int h = 0; h < NH; h++)
+#pragma unroll
+            for (int j = 0; j < E; j++) { const i32x2 x = g[lg + E * j + H * h]; vr[h][j] = x.x; vi[h][j] = x.y; }
+        if (TWO) {                                                 // half-span N/2: the two halves of a lane
+#pragma unroll
+            for (int j = 0; j < E; j++) bfly(vr[0][j], vi[0][j], vr[NH - 1][j], vi[NH - 1][j], lg + E * j);
+        }
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+#pragma unroll
+            for (int gq = 0; gq < LOG; gq++) {                     // half-spans E^2/2 .. E: registers hj apart
+                const int hj = (E / 2) >> gq;
+#pragma unroll
+                for (int j = 0; j < E; j++)
+                    if (!(j & hj)) bfly(vr[h][j], vi[h][j], vr[h][j + hj], vi[h][j + hj],
+                                        (lg + E * (j & (hj - 1))) << (gq + (TWO ? 1 : 0)));
+            }
+            transpose(h);                                          // lane m: register c = element E m + c of the half
+#pragma unroll
+            for (int gq = 0; gq < LOG; gq++) {                     // half-spans E/2 .. 1
+                const int hc = (E / 2) >> gq;
+#pragma unroll
+                for (int c = 0; c < E; c++)
+                    if (!(c & hc)) bfly(vr[h][c], vi[h][c], vr[h][c + hc], vi[h][c + hc], (c & (hc - 1)) << (LN - LOG + gq));
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < NH; h++)                               // llz_fft_fixed.c:170-174: out[brev(i)] = work[i]
+#pragma unroll
+            for (int c = 0; c < E; c++) g[((brevE<E>(c) * E + lrev) * NH) + h] = (i32x2){vr[h][c], vi[h][c]};
+    } else {
+#pragma unroll
+        for (int h = 0; h < NH; h++)
+#pragma unroll
+            for (int c = 0; c < E; c++) { const i32x2 x = g[((brevE<E>(c) * E + lrev) * NH) + h]; vr[h][c] = x.x; vi[h][c] = x.y; }
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+#pragma unroll
+            for (int gq = 0; gq < LOG; gq++) {                     // half-spans 1 .. E/2
+                const int hc = 1 << gq;
+#pragma unroll
+                for (int c = 0; c < E; c++)
+                    if (!(c & hc)) bfly(vr[h][c], vi[h][c], vr[h][c + hc], vi[h][c + hc], (c & (hc - 1)) << (LN - 1 - gq));
+            }
+            transpose(h);                                          // lane l: register j = element l + E j of the half
+#pragma unroll
+            for (int gq = 0; gq < LOG; gq++) {                     // half-spans E .. E^2/2
+                const int hj = 1 << gq;
+#pragma unroll
+                for (int j = 0; j < E; j++)
+                    if (!(j & hj)) bfly(vr[h][j], vi[h][j], vr[h][j + hj], vi[h][j + hj],
+                                        (lg + E * (j & (hj - 1))) << (LN - 1 - LOG - gq));
+            }
+        }
+        if (TWO) {
+#pragma unroll
+            for (int j = 0; j < E; j++) bfly(vr[0][j], vi[0][j], vr[NH - 1][j], vi[NH - 1][j], lg + E * j);
+        }
+#pragma unroll
+        for (int h = 0; h < NH; h++)
+#pragma unroll
+            for (int j = 0; j < E; j++) g[lg + E * j + H * h] = (i32x2){vr[h][j] >> LN, vi[h][j] >> LN};   // :212-215
+    }
+}
+
 // Analysis frames for fft_len = E^2 (E = 16: 256) or 2 E^2 (TWO; E = 16: 512, E = 32: 2048) on a group of E lanes per
 // frame: k_stft_analysis1024_f32's scheme on square_core -- windowed samples from HBM straight into the registers of the
 // lane that transforms them, bins 0..size/2 straight back.
@@ -1372,6 +1499,29 @@ extern "C" int llzs_fft_f64(double *data, int size, const double *cs, int invers
 
 extern "C" int llzs_fft_fixed(int *data, int count, int size, const short *cs, int inverse, void *stream)
 {
+    if (data && cs && count >= 1 && !getenv("LLZ_FFT_GENERIC")) {
+#define LLZ_Q15_REG(EE, TT)                                                                                          \
+    do {                                                                                                             \
+        const unsigned blocks = (unsigned)((count + (256 / EE) - 1) / (256 / EE));                                   \
+        if (inverse) hipLaunchKernelGGL((k_fft_reg_q15<EE, TT, true>), dim3(blocks), dim3(256), 0, as_stream(stream),  \
+                                        data, count, cs);                                                            \
+        else hipLaunchKernelGGL((k_fft_reg_q15<EE, TT, false>), dim3(blocks), dim3(256), 0, as_stream(stream), data,  \
+                                count, cs);                                                                          \
+        LLZ_LAUNCH_CHECK("k_fft_reg_q15");                                                                           \
+        return LLZ_OK;                                                                                               \
+    } while (0)
+        switch (size) {
+        case 64: LLZ_Q15_REG(8, false);
+        case 128: LLZ_Q15_REG(8, true);
+        case 256: LLZ_Q15_REG(16, false);
+        case 512: LLZ_Q15_REG(16, true);
+        case 1024: LLZ_Q15_REG(32, false);
+        case 2048: LLZ_Q15_REG(32, true);
+        case 4096: LLZ_Q15_REG(64, false);
+        default: break;
+        }
+#undef LLZ_Q15_REG
+    }
     return launch_fft<arith_q15>(data, count, size, cs, inverse, stream, "k_fft_radix2<q15>");
 }
 
