@@ -172,6 +172,100 @@ k_resample_f32_lds(const float *__restrict__ in, float *__restrict__ out, const 
     }
 }
 
+// Small L and M (2:3, 3:2, 3:4, 4:3, 2:1 ...), float32: the kernel above is bound by LDS reads (a sample and a quarter of
+// a tap row per MAC).  An L:M resampler is L decimators by M interleaved at the output: output L m + f uses tap row f at
+// input position M m + floor(f M / L).  Here a lane computes R consecutive m of one phase at a time: their sample windows
+// overlap (they are M apart), so a chunk of K = M R taps needs M(R-1)+K window samples in registers for K R MACs, and the
+// tap row of the phase is the same for every lane (LDS broadcast, four taps per read): ~0.3 LDS reads per MAC instead of
+// 1.25.  The staged span is laid out column-major in units of M R samples ([M R][SW] floats): window element j of all
+// lanes is one conflict-free run, and because the tap count is padded to a multiple of K with zero taps every window
+// address is the lane's pointer, stepped back one float per chunk, plus a compile-time offset.
+constexpr int RSW_SW = 289;                                         // floats per row: 256 lanes + (Qp + M) / (M R) <= 32, odd
+
+template <int L, int M, int R>
+__global__ void __launch_bounds__(RS_THREADS)
+k_resample_f32_win(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
+                   const float *__restrict__ g, long n_in, long n_out, long in_pitch, long out_pitch, int Q, float gain,
+                   long long i0, long long in0)
+{
+    constexpr int RM = M * R, K = RM, W = M * (R - 1) + K, SW = RSW_SW;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *xs = reinterpret_cast<float *>(smem_raw);                // [RM][SW]
+    const int c = blockIdx.y, tid = threadIdx.x;
+    const int chunks = (Q + K - 1) / K, Qp = chunks * K;
+    float *gs = xs + RM * SW;                                       // [L][Qp], zero beyond Q
+    // m counts periods of L outputs / M inputs from the start of the stream; this workgroup owns 256 R of them
+    const long long m_first = i0 / L;
+    const long long mb = m_first + (long long)blockIdx.x * (RS_THREADS * R);
+    const long base = (long)(mb * M - in0) - (Qp - 1);              // row index of staged sample 0
+    const int span = RS_THREADS * RM + Qp + M;
+    const float *row = in + (size_t)c * in_pitch;
+    const float *hrow = hist ? hist + (size_t)c * (Q - 1) : nullptr;
+    for (int p = tid; p < span; p += RS_THREADS) {
+        const long idx = base + p;
+        float v = 0.f;
+        if (idx >= 0) {
+            if (idx < n_in) v = row[idx];
+        } else if (hrow && idx >= -(long)(Q - 1)) {
+            v = hrow[(Q - 1) + idx];
+        }
+        xs[(p % RM) * SW + p / RM] = v;
+    }
+    for (int e = tid; e < L * Qp; e += RS_THREADS) {
+        const int f = e / Qp, k = e - f * Qp;
+        gs[e] = k < Q ? g[(size_t)f * Q + k] : 0.f;
+    }
+    __syncthreads();
+    // lane tid, period r of it, phase f, tap k read staged sample RM tid + Qp-1 + d_f + M r - k, d_f = floor(f M / L)
+    float *orow = out + (size_t)c * out_pitch;
+    float res[L][R];
+#pragma unroll
+    for (int f = 0; f < L; f++) {
+        const int df = (f * M) / L;
+        const float *wp = xs + tid + (chunks - 1);
+        const float *gp = gs + f * Qp;
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = 0.f;
+        for (int ch = 0; ch < chunks; ch++, wp--, gp += K) {
+            float xw[W];
+#pragma unroll
+            for (int j = 0; j < W; j++) xw[j] = wp[((j + df) % RM) * SW + (j + df) / RM];
+#pragma unroll
+            for (int u4 = 0; u4 < K; u4 += 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(gp + u4);      // same address in every lane
+                const float tk[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int uu = 0; uu < 4; uu++) {
+                    const int u = u4 + uu;
+#pragma unroll
+                    for (int r = 0; r < R; r++) acc[r] = __builtin_fmaf(xw[M * r - u + (K - 1)], tk[uu], acc[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) res[f][r] = acc[r] * gain;
+    }
+    // the workgroup's 256 R L outputs are one contiguous run: through LDS (the sample image is no longer needed) so that
+    // HBM sees whole lines instead of R L stride-L dword stores per lane (those cost more than the arithmetic)
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < L; f++)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int idx = (R * tid + r) * L + f;
+            xs[idx + (idx >> 5)] = res[f][r];
+        }
+    __syncthreads();
+    const long long i_block = mb * L - i0;                          // output index of the run's first element; < 0 in tile 0
+#pragma unroll
+    for (int q = 0; q < R * L; q++) {
+        const int idx = q * RS_THREADS + tid;
+        const long long i = i_block + idx;
+        if (i >= 0 && i < n_out) orow[i] = xs[idx + (idx >> 5)];
+    }
+}
+
 // int16 in/out, the reference's arithmetic (llz_resample.c:583-603) with the per-tap overhead taken out: the input span
 // is converted to double ONCE while it is staged in LDS (the int16 -> double conversion is exact, so converting before
 // or after the LDS round trip gives the same operand), and for L = 1 every lane uses the same tap row, which the
@@ -435,6 +529,32 @@ extern "C" int llzs_resample_f32(const float *in, float *out, const float *hist,
                                  long n_in, long n_out, long in_pitch, long out_pitch, int L, int M, int Q,
                                  float gain, long long i0, long long in0, void *stream)
 {
+    if (in && out && g && channels > 0 && channels <= 65535 && n_in > 0 && n_out > 0 && L >= 1 && M >= 1 && Q >= 1 &&
+        in_pitch >= n_in && out_pitch >= n_out && !getenv("LLZ_RS_GENERIC_OLD") && !getenv("LLZ_RS_NO_WINDOW")) {
+        // small L, M: the register-window kernel (R periods per lane; M R = 8 .. 24 samples per lane and tile)
+#define LLZ_RSW_TRY(LL, MM, RR)                                                                                      \
+    if (L == LL && M == MM) {                                                                                        \
+        const int RM = MM * RR, Qp = (Q + RM - 1) / RM * RM;                                                         \
+        if ((Qp + MM + RM - 1) / RM <= RSW_SW - 1 - RS_THREADS) {                                                    \
+            size_t lds = ((size_t)RM * RSW_SW + (size_t)LL * Qp) * sizeof(float);                                    \
+            const size_t lds_out = ((size_t)RS_THREADS * RR * LL * 33 / 32 + 8) * sizeof(float);   /* the output run */ \
+            if (lds < lds_out) lds = lds_out;                                                                        \
+            const long long m_first = i0 / LL, m_last = (i0 + n_out - 1) / LL;                                       \
+            const long tiles = (long)((m_last - m_first) / (RS_THREADS * RR) + 1);                                   \
+            if (lds > 64 * 1024)                                                                                     \
+                LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resample_f32_win<LL, MM, RR>),    \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+            hipLaunchKernelGGL((k_resample_f32_win<LL, MM, RR>), dim3((unsigned)tiles, (unsigned)channels),          \
+                               dim3(RS_THREADS), lds, as_stream(stream), in, out, hist, g, n_in, n_out, in_pitch,    \
+                               out_pitch, Q, gain, i0, in0);                                                         \
+            LLZ_LAUNCH_CHECK("k_resample_f32_win");                                                                  \
+            return LLZ_OK;                                                                                           \
+        }                                                                                                            \
+    }
+        LLZ_RSW_TRY(2, 3, 8) LLZ_RSW_TRY(3, 2, 8) LLZ_RSW_TRY(3, 4, 4) LLZ_RSW_TRY(4, 3, 8)
+        LLZ_RSW_TRY(2, 1, 8) LLZ_RSW_TRY(3, 1, 8) LLZ_RSW_TRY(4, 1, 8)
+#undef LLZ_RSW_TRY
+    }
     if (in && out && g && channels > 0 && channels <= 65535 && n_in > 0 && n_out > 0 && L >= 1 && M >= 1 && Q >= 1 &&
         in_pitch >= n_in && out_pitch >= n_out) {
         int qpad = (Q + 3) & ~3;

@@ -351,6 +351,32 @@ def test_resample_mc_f32_vs_oracle(dev, oracle, L, M, win):
     assert err <= TOL and err / float(np.sqrt(np.mean(ref ** 2))) <= 3e-5, err
 
 
+@pytest.mark.parametrize("L,M", [(2, 3), (3, 2), (3, 4), (4, 3), (2, 1), (3, 1), (4, 1), (5, 3)])
+def test_resample_mc_f32_small_ratios_streaming(dev, oracle, L, M):
+    """the register-window kernel of the small ratios (k_resample_f32_win; 5:3 stays on the general kernel), streamed in
+    calls of uneven length (history and the handle's stream position in use, tiles that start inside a call, several
+    tiles per channel); against the oracle on the whole signal"""
+    ch = 3
+    lens = [1000 * M, 37 * M, 9001 * M, 5 * M]                          # a call takes whole periods of M inputs
+    x = oracle.synth_f32(ch, sum(lens), seed=L * 10 + M)
+    r = filters.ResampleMC(ch, L, M, 1.0, po.BLACKMAN, filters.PCM_F32)
+    outs, o = [], 0
+    for n_in in lens:
+        n_out = r.out_len(n_in)
+        assert n_out > 0
+        xd = torch.from_numpy(np.ascontiguousarray(x[:, o:o + n_in])).to(dev)
+        yd = torch.empty(ch, n_out, dtype=torch.float32, device=dev)
+        r.process(xd, yd)
+        outs.append(yd.cpu().numpy())
+        o += n_in
+    r.close()
+    got = np.concatenate(outs, axis=1).astype(np.float64)
+    ref = oracle.rs_batch_f32(x, L, M, 1.0, po.BLACKMAN)[:, :got.shape[1]]
+    assert got.shape[1] >= sum(lens) * L // M - 1
+    err = float(np.sqrt(np.mean((got - ref) ** 2)))
+    assert err <= TOL and err / float(np.sqrt(np.mean(ref ** 2))) <= 3e-5, (L, M, err)
+
+
 def test_resample_mc_f32_integer_input_matches_int16_reference(dev, oracle):
     """integer-valued float input: trunc(clamp(float path)) equals the bit-exact int16 path except within ~1e-2
     of an integer boundary (float accumulate), SURVEY.md H3"""
