@@ -147,6 +147,7 @@ typedef struct {
     int channels, frame_len, flt_len, algo;
     float *d_taps;              /* flt_len floats zero-padded to a multiple of 16 */
     float *d_hfreq, *d_twid;    /* overlap-save tables (NULL for the time-domain algorithm) */
+    float *d_hperm2, *d_cs2;    /* 2048-point overlap-save: permuted spectrum (1024 float4) and the cos/sin table */
     float *d_hist[2];           /* [channels][flt_len-1], ping-pong */
     int cur;
     float *d_zero;              /* [channels][flt_len-1] zeros: flush input */
@@ -157,7 +158,7 @@ typedef struct {
 static void firm_destroy(firm_t *f)
 {
     if (!f) return;
-    llzs_free(f->d_taps); llzs_free(f->d_hfreq); llzs_free(f->d_twid);
+    llzs_free(f->d_taps); llzs_free(f->d_hfreq); llzs_free(f->d_twid); llzs_free(f->d_hperm2); llzs_free(f->d_cs2);
     llzs_free(f->d_hist[0]); llzs_free(f->d_hist[1]); llzs_free(f->d_zero);
     llz_stage_release(&f->st_in); llz_stage_release(&f->st_out);
     f->tag = 0;
@@ -206,6 +207,54 @@ static int firm_build_ols_tables(firm_t *f, const float *taps)
     return rc;
 }
 
+/* 2048-point overlap-save: the taps' spectrum / 2048 in the output order of the 2 x 32^2 register transform
+ * ([q][lane] = (H[2k], H[2k+1]), k = lane + 32 brev5(q)) and the size-2048 cos/sin table the device derives its transform
+ * tables from.  Direct DFT in double, setup time only. */
+static int firm_build_ols2048_tables(firm_t *f, const float *taps)
+{
+    const int N = LLZS_OLS2_NFFT;
+    float *hp = (float *)malloc(sizeof(float) * 4 * 1024);
+    float *csf = (float *)malloc(sizeof(float) * 2 * (size_t)N);
+    double *cs = (double *)malloc(sizeof(double) * 2 * (size_t)N);
+    double *hf = (double *)malloc(sizeof(double) * 2 * (size_t)N);
+    int rc = LLZ_ERR_NOMEM;
+    if (hp && csf && cs && hf) {
+        for (int i = 0; i < N; i++) {
+            const double ang = 2.0 * M_PI * (double)i / (double)N;
+            cs[2 * i] = (i == N / 4 || i == 3 * N / 4) ? 0.0 : cos(ang);
+            cs[2 * i + 1] = (i == 0 || i == N / 2) ? 0.0 : sin(ang);
+            csf[i] = (float)cs[2 * i];
+            csf[N + i] = (float)cs[2 * i + 1];
+        }
+        for (int k = 0; k < N; k++) {
+            double re = 0.0, im = 0.0;
+            for (int t = 0; t < f->flt_len; t++) {
+                const int m = (int)(((long)k * t) % N);
+                re += (double)taps[t] * cs[2 * m];
+                im -= (double)taps[t] * cs[2 * m + 1];
+            }
+            hf[2 * k] = re / N;
+            hf[2 * k + 1] = im / N;
+        }
+        for (int q = 0; q < 32; q++) {
+            const int bq = ((q & 1) << 4) | ((q & 2) << 2) | (q & 4) | ((q & 8) >> 2) | ((q & 16) >> 4);
+            for (int l = 0; l < 32; l++) {
+                const int k = l + 32 * bq;
+                float *e = hp + 4 * (q * 32 + l);
+                e[0] = (float)hf[2 * (2 * k)]; e[1] = (float)hf[2 * (2 * k) + 1];
+                e[2] = (float)hf[2 * (2 * k + 1)]; e[3] = (float)hf[2 * (2 * k + 1) + 1];
+            }
+        }
+        f->d_hperm2 = (float *)llzs_malloc(sizeof(float) * 4 * 1024);
+        f->d_cs2 = (float *)llzs_malloc(sizeof(float) * 2 * (size_t)N);
+        rc = (f->d_hperm2 && f->d_cs2) ? LLZ_OK : LLZ_ERR_NOMEM;
+        if (rc == LLZ_OK) rc = llzs_h2d(f->d_hperm2, hp, sizeof(float) * 4 * 1024, NULL);
+        if (rc == LLZ_OK) rc = llzs_h2d(f->d_cs2, csf, sizeof(float) * 2 * (size_t)N, NULL);
+    }
+    free(hp); free(csf); free(cs); free(hf);
+    return rc;
+}
+
 unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *taps, int flt_len, int algo)
 {
     if (channels < 1 || channels > 65535 || frame_len < 1 || !taps || flt_len < 1) {
@@ -218,7 +267,12 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
          * matrix-core form of the time domain (23.7 ms at 257 taps against 31.9 ms on the VALU) */
         if (flt_len <= 32) algo = LLZ_FIR_ALGO_TIME;
         else if (flt_len <= LLZS_OLS_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE;
+        else if (flt_len <= LLZS_OLS2_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_2048;
         else algo = llzs_fir_mfma_f32_fits(flt_len, 1) ? LLZ_FIR_ALGO_TIME_MFMA : LLZ_FIR_ALGO_TIME;
+    }
+    if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048 && (flt_len < 2 || flt_len > LLZS_OLS2_MAX_TAPS)) {
+        llzs_set_error("llz_fir_filter_mc_init: the 2048-point overlap-save takes 2..%d taps", LLZS_OLS2_MAX_TAPS);
+        return LLZ_BAD_HANDLE;
     }
     if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE && flt_len > LLZS_OLS_MAX_TAPS) {
         llzs_set_error("llz_fir_filter_mc_init: overlap-save supports at most %d taps", LLZS_OLS_MAX_TAPS);
@@ -228,7 +282,8 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
         llzs_set_error("llz_fir_filter_mc_init: %d taps do not fit the matrix-core kernel's LDS tile", flt_len);
         return LLZ_BAD_HANDLE;
     }
-    if (algo != LLZ_FIR_ALGO_TIME && algo != LLZ_FIR_ALGO_OVERLAP_SAVE && algo != LLZ_FIR_ALGO_TIME_MFMA) {
+    if (algo != LLZ_FIR_ALGO_TIME && algo != LLZ_FIR_ALGO_OVERLAP_SAVE && algo != LLZ_FIR_ALGO_TIME_MFMA &&
+        algo != LLZ_FIR_ALGO_OVERLAP_SAVE_2048) {
         llzs_set_error("llz_fir_filter_mc_init: unknown algo %d", algo);
         return LLZ_BAD_HANDLE;
     }
@@ -254,6 +309,7 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
     if (rc == LLZ_OK) rc = llzs_memset(f->d_hist[1], 0, hist_bytes, NULL);
     if (rc == LLZ_OK) rc = llzs_memset(f->d_zero, 0, hist_bytes, NULL);
     if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE) rc = firm_build_ols_tables(f, taps);
+    if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048) rc = firm_build_ols2048_tables(f, taps);
     if (rc == LLZ_OK) rc = llzs_sync(NULL);
     free(padded);
     if (rc != LLZ_OK) {
@@ -347,6 +403,9 @@ static int firm_launch(firm_t *f, const float *d_in, float *d_out, int n, long p
     if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE)
         rc = llzs_fir_ols_f32(d_in, d_out, hist, f->d_hfreq, f->d_twid, f->channels, n, pitch_in, pitch_out,
                               f->flt_len, f->stream);
+    else if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048)
+        rc = llzs_fir_ols2048_f32(d_in, d_out, hist, f->d_hperm2, f->d_cs2, f->channels, n, pitch_in, pitch_out,
+                                  f->flt_len, f->stream);
     else if (algo == LLZ_FIR_ALGO_TIME_MFMA)
         rc = llzs_fir_mfma_f32(d_in, d_out, hist, f->d_taps, f->channels, n, n, pitch_in, pitch_out, f->flt_len, 1,
                                1.0f, f->stream);

@@ -38,6 +38,12 @@ int llzs_fir_td_f32(const float *in, float *out, const float *hist, const float 
  * W_1024^(a*b).  Requires flt_len <= 257. */
 int llzs_fir_ols_f32(const float *in, float *out, const float *hist, const float *hfreq, const float *twid,
                      int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream);
+/* overlap-save with 2048-point transforms for 258..1025 taps: hperm [32][32] float4 = (H[2k], H[2k+1]) / 2048 with
+ * k = lane + 32 brev5(q) at [q][lane]; cs: device table, 2048 cos then 2048 sin of 2 pi i / 2048 */
+int llzs_fir_ols2048_f32(const float *in, float *out, const float *hist, const float *hperm, const float *cs,
+                         int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream);
+#define LLZS_OLS2_NFFT 2048
+#define LLZS_OLS2_MAX_TAPS 1025
 /* time domain on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), with optional decimation:
  * y[c][i] = gain * sum_{k<T} taps[k] * x[c][i*M - k], x[c][<0] = hist[c][T-1+idx] (hist NULL = zeros); n_out outputs
  * per channel from n_in inputs, (n_out-1)*M < n_in.  taps: T floats (no padding needed). */

@@ -877,6 +877,31 @@ def test_mdct_batch_vs_oracle(dev, oracle, n, count):
     m.close()
 
 
+# ------------------------------------------------------------------------------------------------ overlap-save, 2048 points
+@pytest.mark.parametrize("taps_n,channels,n", [(258, 3, 5000), (513, 5, 1536 * 4 + 1), (1025, 2, 1024 * 7), (300, 9, 700),
+                                               (1025, 70, 1024 * 40 + 3), (2, 3, 4096)])
+def test_fir_ols2048_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
+    """filters of 258..1025 taps on the 2048-point register-transform overlap-save (k_fir_ols2048_f32): two frames (history
+    carried by the handle) and the flush tail, ragged lengths, blocks that end past the frame, and the automatic choice"""
+    taps = oracle.fir_design(po.LPF, taps_n, 0.2, 0.0, po.KAISER)
+    x = oracle.synth_f32(channels, 2 * n, seed=taps_n)
+    ref = oracle.fir_batch_f32(x, taps.astype(np.float32).astype(np.float64))
+    f = filters.FirFilterMC(channels, n, taps, algo=filters.FIR_ALGO_OVERLAP_SAVE_2048)
+    assert f.algo == filters.FIR_ALGO_OVERLAP_SAVE_2048
+    outs = []
+    for o in (0, n):
+        xd = torch.from_numpy(np.ascontiguousarray(x[:, o:o + n])).to(dev)
+        yd = torch.empty_like(xd)
+        f.filter(xd, yd)
+        outs.append(yd.cpu().numpy())
+    f.close()
+    rms_check(np.concatenate(outs, axis=1), ref, f"fir ols2048 taps={taps_n}")
+    if taps_n > 257:
+        g = filters.FirFilterMC(channels, n, taps)                 # AUTO
+        assert g.algo == filters.FIR_ALGO_OVERLAP_SAVE_2048
+        g.close()
+
+
 # ------------------------------------------------------------------------------------------------ overlap-save, chain form
 _CHAIN_SCRIPT = r'''
 import os, sys

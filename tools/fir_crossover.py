@@ -8,12 +8,15 @@ for ch in (4096,):
     n = 1 << 20
     x = torch.empty(ch, n, dtype=torch.float32, device=dev); y = torch.empty_like(x)
     filters.synth_f32(x, 1, stream=s)
-    for taps_n in (257, 513, 1025):
+    for taps_n in (257, 513, 1025, 1537):
         taps = filters.fir_design("lpf", taps_n, 0.25, 0.0, filters.HAMMING)
-        for algo in (1, 2, 3):
-            if algo == 2 and taps_n > 257:
+        for algo in (1, 2, 3, 4):
+            if (algo == 2 and taps_n > 257) or (algo == 4 and taps_n > 1025):
                 continue
-            f = filters.FirFilterMC(ch, n, taps, algo=algo, stream=s)
+            try:
+                f = filters.FirFilterMC(ch, n, taps, algo=algo, stream=s)
+            except capi.LlzError:
+                continue                                   # this many taps do not fit the algorithm
             f.filter(x, y); torch.cuda.synchronize()
             t = L.llz_hip_timer_new(); L.llz_hip_timer_start(t, sp)
             for _ in range(5): f.filter(x, y)
