@@ -1093,8 +1093,9 @@ k_stft_synthesis_reg_f32(const float *__restrict__ re, const float *__restrict__
 // INTERIOR: jobs first_job .. first_job + jobs_per_channel - 1 of every channel, all of whose samples lie inside the frame
 // (two lane pointers with immediate offsets); otherwise the edge jobs: job 0 (history) and the jobs from first_job on (frame
 // end), each access tested -- a kernel of its own, because the tested accesses cost 120 more VGPRs.
+// (two waves per SIMD: the 44 registers that do not fit are the waiting odd-bin results, spilled once and read once)
 template <bool INTERIOR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_fir_ols2048_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
                   const float4 *__restrict__ hperm, const float *__restrict__ cs /* 2048 cos, 2048 sin */, const float2 *__restrict__ tw1,
                   int n, long in_pitch, long out_pitch, int flt_len, int jobs_per_channel, long total_jobs, int first_job)
