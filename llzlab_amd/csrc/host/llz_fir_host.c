@@ -147,7 +147,7 @@ typedef struct {
     int channels, frame_len, flt_len, algo;
     float *d_taps;              /* flt_len floats zero-padded to a multiple of 16 */
     float *d_hfreq, *d_twid;    /* overlap-save tables (NULL for the time-domain algorithm) */
-    float *d_hperm2, *d_cs2;    /* 2048-point overlap-save: permuted spectrum (1024 float4) and the cos/sin table */
+    float *d_hperm2, *d_cs2;    /* 2048- / 4096-point overlap-save: permuted spectrum and the cos/sin table */
     float *d_hist[2];           /* [channels][flt_len-1], ping-pong */
     int cur;
     float *d_zero;              /* [channels][flt_len-1] zeros: flush input */
@@ -207,13 +207,12 @@ static int firm_build_ols_tables(firm_t *f, const float *taps)
     return rc;
 }
 
-/* 2048-point overlap-save: the taps' spectrum / 2048 in the output order of the 2 x 32^2 register transform
- * ([q][lane] = (H[2k], H[2k+1]), k = lane + 32 brev5(q)) and the size-2048 cos/sin table the device derives its transform
- * tables from.  Direct DFT in double, setup time only. */
-static int firm_build_ols2048_tables(firm_t *f, const float *taps)
+/* 2048- and 4096-point overlap-save: the taps' spectrum / N in the output order of the register transform and the size-N
+ * cos/sin table the device derives its transform tables from.  N = 2048 (2 x 32^2): [q][lane] = (H[2k], H[2k+1]),
+ * k = lane + 32 brev5(q);  N = 4096 (64^2): [q][lane] = H[lane + 64 brev6(q)].  Direct DFT in double, setup time only. */
+static int firm_build_ols_big_tables(firm_t *f, const float *taps, int N)
 {
-    const int N = LLZS_OLS2_NFFT;
-    float *hp = (float *)malloc(sizeof(float) * 4 * 1024);
+    float *hp = (float *)malloc(sizeof(float) * 2 * (size_t)N);
     float *csf = (float *)malloc(sizeof(float) * 2 * (size_t)N);
     double *cs = (double *)malloc(sizeof(double) * 2 * (size_t)N);
     double *hf = (double *)malloc(sizeof(double) * 2 * (size_t)N);
@@ -236,19 +235,32 @@ static int firm_build_ols2048_tables(firm_t *f, const float *taps)
             hf[2 * k] = re / N;
             hf[2 * k + 1] = im / N;
         }
-        for (int q = 0; q < 32; q++) {
-            const int bq = ((q & 1) << 4) | ((q & 2) << 2) | (q & 4) | ((q & 8) >> 2) | ((q & 16) >> 4);
-            for (int l = 0; l < 32; l++) {
-                const int k = l + 32 * bq;
-                float *e = hp + 4 * (q * 32 + l);
-                e[0] = (float)hf[2 * (2 * k)]; e[1] = (float)hf[2 * (2 * k) + 1];
-                e[2] = (float)hf[2 * (2 * k + 1)]; e[3] = (float)hf[2 * (2 * k + 1) + 1];
+        if (N == 2048) {
+            for (int q = 0; q < 32; q++) {
+                const int bq = ((q & 1) << 4) | ((q & 2) << 2) | (q & 4) | ((q & 8) >> 2) | ((q & 16) >> 4);
+                for (int l = 0; l < 32; l++) {
+                    const int k = l + 32 * bq;
+                    float *e = hp + 4 * (q * 32 + l);
+                    e[0] = (float)hf[2 * (2 * k)]; e[1] = (float)hf[2 * (2 * k) + 1];
+                    e[2] = (float)hf[2 * (2 * k + 1)]; e[3] = (float)hf[2 * (2 * k + 1) + 1];
+                }
+            }
+        } else {
+            for (int q = 0; q < 64; q++) {
+                int bq = 0;
+                for (int b = 0; b < 6; b++)
+                    if (q & (1 << b)) bq |= 1 << (5 - b);
+                for (int l = 0; l < 64; l++) {
+                    const int k = l + 64 * bq;
+                    hp[2 * (q * 64 + l)] = (float)hf[2 * k];
+                    hp[2 * (q * 64 + l) + 1] = (float)hf[2 * k + 1];
+                }
             }
         }
-        f->d_hperm2 = (float *)llzs_malloc(sizeof(float) * 4 * 1024);
+        f->d_hperm2 = (float *)llzs_malloc(sizeof(float) * 2 * (size_t)N);
         f->d_cs2 = (float *)llzs_malloc(sizeof(float) * 2 * (size_t)N);
         rc = (f->d_hperm2 && f->d_cs2) ? LLZ_OK : LLZ_ERR_NOMEM;
-        if (rc == LLZ_OK) rc = llzs_h2d(f->d_hperm2, hp, sizeof(float) * 4 * 1024, NULL);
+        if (rc == LLZ_OK) rc = llzs_h2d(f->d_hperm2, hp, sizeof(float) * 2 * (size_t)N, NULL);
         if (rc == LLZ_OK) rc = llzs_h2d(f->d_cs2, csf, sizeof(float) * 2 * (size_t)N, NULL);
     }
     free(hp); free(csf); free(cs); free(hf);
@@ -268,10 +280,15 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
         if (flt_len <= 32) algo = LLZ_FIR_ALGO_TIME;
         else if (flt_len <= LLZS_OLS_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE;
         else if (flt_len <= LLZS_OLS2_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_2048;
+        else if (flt_len <= LLZS_OLS4_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_4096;
         else algo = llzs_fir_mfma_f32_fits(flt_len, 1) ? LLZ_FIR_ALGO_TIME_MFMA : LLZ_FIR_ALGO_TIME;
     }
     if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048 && (flt_len < 2 || flt_len > LLZS_OLS2_MAX_TAPS)) {
         llzs_set_error("llz_fir_filter_mc_init: the 2048-point overlap-save takes 2..%d taps", LLZS_OLS2_MAX_TAPS);
+        return LLZ_BAD_HANDLE;
+    }
+    if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_4096 && (flt_len < 2 || flt_len > LLZS_OLS4_MAX_TAPS)) {
+        llzs_set_error("llz_fir_filter_mc_init: the 4096-point overlap-save takes 2..%d taps", LLZS_OLS4_MAX_TAPS);
         return LLZ_BAD_HANDLE;
     }
     if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE && flt_len > LLZS_OLS_MAX_TAPS) {
@@ -283,7 +300,7 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
         return LLZ_BAD_HANDLE;
     }
     if (algo != LLZ_FIR_ALGO_TIME && algo != LLZ_FIR_ALGO_OVERLAP_SAVE && algo != LLZ_FIR_ALGO_TIME_MFMA &&
-        algo != LLZ_FIR_ALGO_OVERLAP_SAVE_2048) {
+        algo != LLZ_FIR_ALGO_OVERLAP_SAVE_2048 && algo != LLZ_FIR_ALGO_OVERLAP_SAVE_4096) {
         llzs_set_error("llz_fir_filter_mc_init: unknown algo %d", algo);
         return LLZ_BAD_HANDLE;
     }
@@ -309,7 +326,8 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
     if (rc == LLZ_OK) rc = llzs_memset(f->d_hist[1], 0, hist_bytes, NULL);
     if (rc == LLZ_OK) rc = llzs_memset(f->d_zero, 0, hist_bytes, NULL);
     if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE) rc = firm_build_ols_tables(f, taps);
-    if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048) rc = firm_build_ols2048_tables(f, taps);
+    if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048) rc = firm_build_ols_big_tables(f, taps, LLZS_OLS2_NFFT);
+    if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE_4096) rc = firm_build_ols_big_tables(f, taps, LLZS_OLS4_NFFT);
     if (rc == LLZ_OK) rc = llzs_sync(NULL);
     free(padded);
     if (rc != LLZ_OK) {
@@ -405,6 +423,9 @@ static int firm_launch(firm_t *f, const float *d_in, float *d_out, int n, long p
                               f->flt_len, f->stream);
     else if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048)
         rc = llzs_fir_ols2048_f32(d_in, d_out, hist, f->d_hperm2, f->d_cs2, f->channels, n, pitch_in, pitch_out,
+                                  f->flt_len, f->stream);
+    else if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_4096)
+        rc = llzs_fir_ols4096_f32(d_in, d_out, hist, f->d_hperm2, f->d_cs2, f->channels, n, pitch_in, pitch_out,
                                   f->flt_len, f->stream);
     else if (algo == LLZ_FIR_ALGO_TIME_MFMA)
         rc = llzs_fir_mfma_f32(d_in, d_out, hist, f->d_taps, f->channels, n, n, pitch_in, pitch_out, f->flt_len, 1,

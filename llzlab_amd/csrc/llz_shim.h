@@ -44,6 +44,12 @@ int llzs_fir_ols2048_f32(const float *in, float *out, const float *hist, const f
                          int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream);
 #define LLZS_OLS2_NFFT 2048
 #define LLZS_OLS2_MAX_TAPS 1025
+/* the same with 4096-point transforms for up to 3073 taps: hperm [64][64] float2 = H[lane + 64 brev6(q)] / 4096; cs: device
+ * table, 4096 cos then 4096 sin */
+int llzs_fir_ols4096_f32(const float *in, float *out, const float *hist, const float *hperm, const float *cs,
+                         int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream);
+#define LLZS_OLS4_NFFT 4096
+#define LLZS_OLS4_MAX_TAPS 3073
 /* time domain on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), with optional decimation:
  * y[c][i] = gain * sum_{k<T} taps[k] * x[c][i*M - k], x[c][<0] = hist[c][T-1+idx] (hist NULL = zeros); n_out outputs
  * per channel from n_in inputs, (n_out-1)*M < n_in.  taps: T floats (no padding needed). */

@@ -902,6 +902,30 @@ def test_fir_ols2048_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
         g.close()
 
 
+@pytest.mark.parametrize("taps_n,channels,n", [(1026, 3, 9000), (2049, 2, 2048 * 5 + 1), (3073, 2, 1024 * 9), (1500, 40, 1024 * 30 + 3),
+                                               (2, 3, 8192), (400, 5, 1000)])
+def test_fir_ols4096_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
+    """filters of up to 3073 taps on the 4096-point overlap-save (k_fir_ols4096_f32, a whole wave per pair of blocks): two
+    frames, ragged lengths, blocks that end past the frame, and the automatic choice beyond 1025 taps"""
+    taps = oracle.fir_design(po.LPF, taps_n, 0.2, 0.0, po.KAISER)
+    x = oracle.synth_f32(channels, 2 * n, seed=taps_n)
+    ref = oracle.fir_batch_f32(x, taps.astype(np.float32).astype(np.float64))
+    f = filters.FirFilterMC(channels, n, taps, algo=filters.FIR_ALGO_OVERLAP_SAVE_4096)
+    assert f.algo == filters.FIR_ALGO_OVERLAP_SAVE_4096
+    outs = []
+    for o in (0, n):
+        xd = torch.from_numpy(np.ascontiguousarray(x[:, o:o + n])).to(dev)
+        yd = torch.empty_like(xd)
+        f.filter(xd, yd)
+        outs.append(yd.cpu().numpy())
+    f.close()
+    rms_check(np.concatenate(outs, axis=1), ref, f"fir ols4096 taps={taps_n}")
+    if taps_n > 1025:
+        g = filters.FirFilterMC(channels, n, taps)                 # AUTO
+        assert g.algo == filters.FIR_ALGO_OVERLAP_SAVE_4096
+        g.close()
+
+
 # ------------------------------------------------------------------------------------------------ overlap-save, chain form
 _CHAIN_SCRIPT = r'''
 import os, sys

@@ -8,10 +8,10 @@ for ch in (4096,):
     n = 1 << 20
     x = torch.empty(ch, n, dtype=torch.float32, device=dev); y = torch.empty_like(x)
     filters.synth_f32(x, 1, stream=s)
-    for taps_n in (257, 513, 1025, 1537):
+    for taps_n in (257, 513, 1025, 1537, 2049, 3073):
         taps = filters.fir_design("lpf", taps_n, 0.25, 0.0, filters.HAMMING)
-        for algo in (1, 2, 3, 4):
-            if (algo == 2 and taps_n > 257) or (algo == 4 and taps_n > 1025):
+        for algo in (1, 2, 3, 4, 5):
+            if (algo == 1 and taps_n > 1025) or (algo == 5 and taps_n < 1025):
                 continue
             try:
                 f = filters.FirFilterMC(ch, n, taps, algo=algo, stream=s)
