@@ -894,8 +894,13 @@ def test_fir_ols2048_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
         yd = torch.empty_like(xd)
         f.filter(xd, yd)
         outs.append(yd.cpu().numpy())
+    tail = torch.empty(channels, taps_n - 1, dtype=torch.float32, device=dev)
+    f.flush(tail)                                                  # flt_len - 1 outputs of the zero-padded stream
     f.close()
     rms_check(np.concatenate(outs, axis=1), ref, f"fir ols2048 taps={taps_n}")
+    full = oracle.fir_batch_f32(np.concatenate([x, np.zeros((channels, taps_n - 1), np.float32)], axis=1),
+                                taps.astype(np.float32).astype(np.float64))
+    assert np.sqrt(np.mean((tail.cpu().numpy() - full[:, 2 * n:]) ** 2)) <= TOL
     if taps_n > 257:
         g = filters.FirFilterMC(channels, n, taps)                 # AUTO
         assert g.algo == filters.FIR_ALGO_OVERLAP_SAVE_2048
@@ -918,8 +923,13 @@ def test_fir_ols4096_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
         yd = torch.empty_like(xd)
         f.filter(xd, yd)
         outs.append(yd.cpu().numpy())
+    tail = torch.empty(channels, taps_n - 1, dtype=torch.float32, device=dev)
+    f.flush(tail)                                                  # flt_len - 1 outputs of the zero-padded stream
     f.close()
     rms_check(np.concatenate(outs, axis=1), ref, f"fir ols4096 taps={taps_n}")
+    full = oracle.fir_batch_f32(np.concatenate([x, np.zeros((channels, taps_n - 1), np.float32)], axis=1),
+                                taps.astype(np.float32).astype(np.float64))
+    assert np.sqrt(np.mean((tail.cpu().numpy() - full[:, 2 * n:]) ** 2)) <= TOL
     if taps_n > 1025:
         g = filters.FirFilterMC(channels, n, taps)                 # AUTO
         assert g.algo == filters.FIR_ALGO_OVERLAP_SAVE_4096
