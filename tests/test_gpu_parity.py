@@ -149,7 +149,9 @@ def test_fir_mc_host_pointers_and_errors(dev, oracle):
     assert filters.FirFilterMC(2, 64, np.ones(257)).algo == filters.FIR_ALGO_OVERLAP_SAVE
     assert filters.FirFilterMC(2, 64, np.ones(63)).algo == filters.FIR_ALGO_OVERLAP_SAVE      # AUTO: 33..257 taps
     assert filters.FirFilterMC(2, 64, np.ones(32)).algo == filters.FIR_ALGO_TIME
-    assert filters.FirFilterMC(2, 64, np.ones(300)).algo == filters.FIR_ALGO_TIME_MFMA
+    assert filters.FirFilterMC(2, 64, np.ones(300)).algo == filters.FIR_ALGO_OVERLAP_SAVE_2048   # 258..1025
+    assert filters.FirFilterMC(2, 64, np.ones(2000)).algo == filters.FIR_ALGO_OVERLAP_SAVE_4096  # 1026..3073
+    assert filters.FirFilterMC(2, 64, np.ones(300), algo=filters.FIR_ALGO_TIME_MFMA).algo == filters.FIR_ALGO_TIME_MFMA
 
 
 def test_fir_linearity_and_impulse_large(dev):
