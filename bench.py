@@ -72,7 +72,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--channels", type=int, default=CHANNELS, help="channels per GPU (weak scaling)")
     ap.add_argument("--samples", type=int, default=N_SAMPLES)
-    ap.add_argument("--algo", type=int, default=0, help="0 auto (overlap-save), 1 time domain, 2 overlap-save, 3 time domain on the matrix cores")
+    ap.add_argument("--algo", type=int, default=0, help="0 auto (overlap-save), 1 time domain, 2 overlap-save, 3 time domain on the matrix cores, 4 / 5 overlap-save with\n"
+                         "2048- / 4096-point transforms")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--extra", action="store_true", help="also time the 63-tap time-domain FIR on one GPU (under 'also')")
     ap.add_argument("--no-also", action="store_true",
@@ -207,7 +208,8 @@ def main():
                 traffic = json.load(open(tpath)).get("headline_kernel_bytes_per_launch")
             except Exception:
                 traffic = None
-        algo_name = {1: "time-domain", 2: "overlap-save-1024", 3: "time-domain-matrix-core"}[fir_algo]
+        algo_name = {1: "time-domain", 2: "overlap-save-1024", 3: "time-domain-matrix-core", 4: "overlap-save-2048",
+                     5: "overlap-save-4096"}[fir_algo]
         line = {
             "metric": "Msamples/s/GPU (float32 FIR 257-tap, 4096 ch) + achieved HBM GB/s vs peak",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -219,7 +221,8 @@ def main():
                        "algorithm": algo_name, "per_gpu_Msamples_s": value / world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": {1: "k_fir_td_f32", 2: ols_kernel_name(channels, n), 3: "k_fir_mfma_bf16x3"}[fir_algo],
+                         "kernel": {1: "k_fir_td_f32", 2: ols_kernel_name(channels, n), 3: "k_fir_mfma_bf16x3",
+                                    4: "k_fir_ols2048_f32", 5: "k_fir_ols4096_f32"}[fir_algo],
                          "kernel_ms_avg": kern_ms, "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * channels * n,
                          "memcpy_d2d_GBs": memcpy_gbs,
                          "frac_of_memcpy_d2d": (achieved / memcpy_gbs) if memcpy_gbs else None},
