@@ -189,12 +189,35 @@ def main():
         if world == 1 and not args.no_cpu:
             cpu = cpu_baseline(taps, pyoracle)
 
+    # long filters on the same batch (weak scaling like the headline): 513 taps on the 2048-point overlap-save, 2049 taps
+    # on the 4096-point one -- under 'also', never part of `value`
+    if not args.no_also and fir_algo == 2:
+        for long_taps in (513, 2049):
+            lt = filters.fir_design("lpf", long_taps, 0.1, 0.0, filters.KAISER)
+            lf = filters.FirFilterMC(channels, n, lt, stream=stream)
+            lf.filter(x, y)
+            torch.cuda.synchronize()
+            barrier()
+            tm = L.llz_hip_timer_new()
+            L.llz_hip_timer_start(tm, sptr)
+            for _ in range(3):
+                lf.filter(x, y)
+            L.llz_hip_timer_stop(tm, sptr)
+            lms = shard.max_over_ranks(L.llz_hip_timer_ms(tm) / 3, device=comm_dev)
+            L.llz_hip_timer_free(tm)
+            also[f"fir_{long_taps}taps_{channels}ch_per_gpu"] = {
+                "Msamples_s": channels * n * world / lms / 1e3, "GBs_per_gpu": BYTES_PER_SAMPLE * channels * n / lms / 1e6,
+                "hbm_frac_per_gpu": BYTES_PER_SAMPLE * channels * n / lms / 1e6 / HBM_PEAK_GBS, "ms": lms,
+                "channels_per_gpu": channels, "scaling": "weak",
+                "algorithm": {4: "overlap-save-2048", 5: "overlap-save-4096"}.get(lf.algo, str(lf.algo))}
+            lf.close()
+
     # release the FIR batch before the other configs allocate theirs
     fir.close()
     del x, y
     torch.cuda.empty_cache()
     if not args.no_also:
-        also = sharded_configs(torch, filters, capi, shard, dev, comm_dev, stream, rank, world, barrier)
+        also.update(sharded_configs(torch, filters, capi, shard, dev, comm_dev, stream, rank, world, barrier))
     if args.extra and world == 1:
         also.update(extra_paths(torch, filters, capi, dev, stream))
 
