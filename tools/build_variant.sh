@@ -8,6 +8,7 @@ name=$1; kern=$2; flags=$3
 make -s
 extra=""
 [ "$kern" = fir_td ] && extra="-fno-slp-vectorize"
+[ "$kern" = fft ] && extra="-mllvm -pragma-unroll-threshold=262144"      # as csrc/Makefile (HIPFLAGS_fft)
 /opt/rocm/bin/hipcc -O3 -fPIC --offload-arch=gfx950 -std=c++17 -Wno-unused-function $extra $flags -c kernels/$kern.hip -o build/var_$name.o
 objs=$(ls build/host_*.o build/hip_*.o | grep -v "hip_$kern.o")
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../libllz_var_$name.so $objs build/var_$name.o -lm
