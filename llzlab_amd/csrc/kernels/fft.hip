@@ -1129,9 +1129,9 @@ k_fir_ols2048_f32(const float *__restrict__ in, float *__restrict__ out, const f
     constexpr bool interior = INTERIOR;
     const float *p0 = row + (o0 - keep) + lg, *p1 = p0 + V;        // (formed, not dereferenced, when not interior)
     // The even bins (s = a + b) and the odd bins (d = (a - b) W) only meet again at the very end, so each half goes through
-    // transform, product and inverse transform on its own, and the window is READ TWICE (the second time from cache): with
-    // both halves formed from one read, 128 registers of s and d sit under the first transform's working set (302 VGPRs,
-    // one wave per SIMD).
+    // transform, product and inverse transform on its own: s waits in 64 registers while d is worked on (with two waves per
+    // SIMD forced, what does not fit in 256 registers is spilled once and read once; reading the window a second time
+    // instead of keeping s measured 10 % slower).
     auto window = [&](int j, cf &a, cf &b) {                       // positions m = lg + E j and m + H of both blocks
         const int m = lg + E * j;
         if (interior) {
@@ -1142,7 +1142,7 @@ k_fir_ols2048_f32(const float *__restrict__ in, float *__restrict__ out, const f
             b = cf{sample(o0 - keep + m + H), sample(o1 - keep + m + H)};
         }
     };
-    cf si[E], di[E];
+    cf si[E], di[E], s[E];
     {
         cf d[E];
 #pragma unroll
@@ -1151,6 +1151,7 @@ k_fir_ols2048_f32(const float *__restrict__ in, float *__restrict__ out, const f
             window(j, a, b);
             const float2 w = tw1[j * E + lg];
             d[j] = cmul<false>(csub(a, b), cf{w.x, w.y});
+            s[j] = cadd(a, b);
             if ((j & 7) == 7) asm volatile("" ::: "memory");        // (loads are not to be hoisted wholesale: registers)
         }
         fft32<false>(d); transpose_twiddle<false>(d, buf, s_tw, lg); fft32<false>(d);   // d[q] = Z[2 kq + 1], kq = lg + E brev5(q)
@@ -1164,16 +1165,7 @@ k_fir_ols2048_f32(const float *__restrict__ in, float *__restrict__ out, const f
         for (int j = 0; j < E; j++) di[j] = d[brevE<E>(j)];        // bin order -> natural order: renaming
         fft32<true>(di); transpose_twiddle<true>(di, buf, s_tw, lg); fft32<true>(di);
     }
-    asm volatile("" ::: "memory");                                  // the second read of the window stays behind the first half
     {
-        cf s[E];
-#pragma unroll
-        for (int j = 0; j < E; j++) {
-            cf a, b;
-            window(j, a, b);
-            s[j] = cadd(a, b);
-            if ((j & 7) == 7) asm volatile("" ::: "memory");
-        }
         fft32<false>(s); transpose_twiddle<false>(s, buf, s_tw, lg); fft32<false>(s);   // s[q] = Z[2 kq]
 #pragma unroll
         for (int q = 0; q < E; q++) {
