@@ -1339,8 +1339,10 @@ k_acf_sq_f32(const float *__restrict__ x, float *__restrict__ r, int frames, int
 // half by each walk), so the only LDS traffic left is the transpose inside the group.
 //   forward: in = x [count][N], out = X [count][N/2];   inverse: in = X [count][N/2], out = x [count][N]
 // tc/ts: cos and sin of -2 pi (k + 1/8) / N, k < N/4 (llz_mdct.c:459-462).  Both directions use the FORWARD transform.
+// (N = 8192 forward needs 300 VGPRs: two waves per SIMD are forced there, the little that does not fit is spilled --
+//  0.94 -> 0.51 ms; the inverse at 344 loses with the same treatment, 0.53 -> 0.57 ms, and keeps one wave)
 template <int E, bool TWO, bool INVERSE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((E == 32 && TWO && !INVERSE) ? 2 : 1)))
 k_mdct_reg_f32(const float *__restrict__ in, float *__restrict__ out, int count, const float *__restrict__ tc,
                const float *__restrict__ ts, const float2 *__restrict__ tw2d, const float2 *__restrict__ tw1,
                float sqrt_cof)
