@@ -190,7 +190,7 @@ def main():
             cpu = cpu_baseline(taps, pyoracle)
 
     # long filters on the same batch (weak scaling like the headline): 513 taps on the 2048-point overlap-save, 2049 taps
-    # on the 4096-point one -- under 'also', never part of `value`
+    # on the 4096-point one (the library's own choice) -- under 'also', never part of `value`
     if not args.no_also and fir_algo == 2:
         for long_taps in (513, 2049):
             lt = filters.fir_design("lpf", long_taps, 0.1, 0.0, filters.KAISER)

@@ -279,7 +279,9 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
          * matrix-core form of the time domain (23.7 ms at 257 taps against 31.9 ms on the VALU) */
         if (flt_len <= 32) algo = LLZ_FIR_ALGO_TIME;
         else if (flt_len <= LLZS_OLS_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE;
-        else if (flt_len <= LLZS_OLS2_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_2048;
+        /* 2048- against 4096-point overlap-save (4096 ch x 2^20): 12.1 against ~12.4 ms at 513 taps, 16.9 against 14.8 at
+         * 1025; both go as 1 / (valid outputs per block), which puts the crossover at ~550 taps */
+        else if (flt_len <= 550) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_2048;
         else if (flt_len <= LLZS_OLS4_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_4096;
         else algo = llzs_fir_mfma_f32_fits(flt_len, 1) ? LLZ_FIR_ALGO_TIME_MFMA : LLZ_FIR_ALGO_TIME;
     }

@@ -711,8 +711,10 @@ __device__ __forceinline__ void square_core(cf (&v)[E], float *buf, const float2
 }
 
 // tw2d: [E][E] float2, entry [k1][l] = exp(-2 pi j k1 l / N); one transform per group of E lanes, 256 / E per workgroup
+// E = 64 needs ~300 VGPRs: at least two waves per SIMD are asked for (256 registers, a few spilled), which beats one
+// wave with everything in registers: N = 4096 0.248 -> 0.197 ms
 template <int E, bool INV>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(E == 64 ? 2 : 1)))
 k_fft_square_f32(float *__restrict__ data, int count, const float2 *__restrict__ tw2d)
 {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -1204,8 +1206,9 @@ k_fir_ols2048_f32(const float *__restrict__ in, float *__restrict__ out, const f
 // The same with 4096-point transforms (64 x 64, a whole wave per job) for filters of 1026..3073 taps: no radix-2 step, so
 // the packed pair of blocks goes through one transform, the spectrum product and one inverse transform.
 // hperm: [q][lane] = H[lane + 64 brev6(q)] / 4096.
+// (interior instantiation: two waves per SIMD asked for, as for k_fft_square_f32<64>: 1537 taps 29.6 -> 17.4 ms)
 template <bool INTERIOR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INTERIOR ? 2 : 1)))
 k_fir_ols4096_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
                   const float2 *__restrict__ hperm, const float2 *__restrict__ tw2d, int n, long in_pitch,
                   long out_pitch, int flt_len, int jobs_per_channel, long total_jobs, int first_job, int head_jobs)

@@ -149,8 +149,8 @@ def test_fir_mc_host_pointers_and_errors(dev, oracle):
     assert filters.FirFilterMC(2, 64, np.ones(257)).algo == filters.FIR_ALGO_OVERLAP_SAVE
     assert filters.FirFilterMC(2, 64, np.ones(63)).algo == filters.FIR_ALGO_OVERLAP_SAVE      # AUTO: 33..257 taps
     assert filters.FirFilterMC(2, 64, np.ones(32)).algo == filters.FIR_ALGO_TIME
-    assert filters.FirFilterMC(2, 64, np.ones(300)).algo == filters.FIR_ALGO_OVERLAP_SAVE_2048   # 258..1025
-    assert filters.FirFilterMC(2, 64, np.ones(2000)).algo == filters.FIR_ALGO_OVERLAP_SAVE_4096  # 1026..3073
+    assert filters.FirFilterMC(2, 64, np.ones(300)).algo == filters.FIR_ALGO_OVERLAP_SAVE_2048   # 258..550
+    assert filters.FirFilterMC(2, 64, np.ones(2000)).algo == filters.FIR_ALGO_OVERLAP_SAVE_4096  # 551..3073
     assert filters.FirFilterMC(2, 64, np.ones(300), algo=filters.FIR_ALGO_TIME_MFMA).algo == filters.FIR_ALGO_TIME_MFMA
 
 
@@ -903,8 +903,8 @@ def test_fir_ols2048_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
     full = oracle.fir_batch_f32(np.concatenate([x, np.zeros((channels, taps_n - 1), np.float32)], axis=1),
                                 taps.astype(np.float32).astype(np.float64))
     assert np.sqrt(np.mean((tail.cpu().numpy() - full[:, 2 * n:]) ** 2)) <= TOL
-    if taps_n > 257:
-        g = filters.FirFilterMC(channels, n, taps)                 # AUTO
+    if 257 < taps_n <= 550:
+        g = filters.FirFilterMC(channels, n, taps)                 # AUTO: 258..550 taps
         assert g.algo == filters.FIR_ALGO_OVERLAP_SAVE_2048
         g.close()
 
@@ -932,8 +932,8 @@ def test_fir_ols4096_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
     full = oracle.fir_batch_f32(np.concatenate([x, np.zeros((channels, taps_n - 1), np.float32)], axis=1),
                                 taps.astype(np.float32).astype(np.float64))
     assert np.sqrt(np.mean((tail.cpu().numpy() - full[:, 2 * n:]) ** 2)) <= TOL
-    if taps_n > 1025:
-        g = filters.FirFilterMC(channels, n, taps)                 # AUTO
+    if taps_n > 550:
+        g = filters.FirFilterMC(channels, n, taps)                 # AUTO: 551..3073 taps
         assert g.algo == filters.FIR_ALGO_OVERLAP_SAVE_4096
         g.close()
 
