@@ -161,7 +161,8 @@ if "pcm" in which:
         del il, pl
 
 if "stft" in which:
-    for hint, F, ch, frames in ((0, 256, 1024, 256), (1, 512, 1024, 128), (0, 64, 4096, 256), (0, 256, 8, 32768)):
+    for hint, F, ch, frames in ((0, 256, 1024, 256), (1, 512, 1024, 128), (0, 64, 4096, 256), (0, 512, 1024, 128),
+                                (0, 256, 8, 32768)):
         n = F * frames
         x = torch.rand(ch, n, dtype=torch.float32, device=dev) * 2 - 1
         q = filters.StftMC(ch, hint, F, filters.BLACKMAN, stream=stream)
