@@ -29,40 +29,71 @@ FLT_LEN = 257
 SEED = 0x11C0FFEE
 
 
+def host_cores():
+    """(online cores by sysconf, cores this process may use): threads for the all-cores leg = the smaller of the two, cut
+    further by a cgroup CPU quota when the box sets one"""
+    online = os.sysconf("SC_NPROCESSORS_ONLN")
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else online
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            usable = min(usable, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return online, max(1, min(online, usable))
+
+
 def cpu_baseline(taps64, oracle_mod):
-    """Reference CPU path (oracle/_ref when built, else the oracle port) on a bounded sample of the same
-    workload, one llz_fir_filter state machine per channel, frame 4096, all host threads."""
-    threads = max(1, min(16, os.cpu_count() or 1))
-    ch_per_thread, n = 8, 1 << 20
+    """Reference CPU path (oracle/_ref when built, else the oracle port) on a bounded sample of the same workload: one
+    llz_fir_filter state machine per channel, frame 4096 -- once on ONE core and once with the channels partitioned
+    over all cores the box gives this process."""
+    online, threads = host_cores()
+    ch_per_thread, n = 24, 1 << 20                     # ~3-4 s of work per thread at ~7 Msamples/s/core
     kind = "reference" if oracle_mod.have_ref() else "port"
     orc = oracle_mod.Oracle()
-    x = orc.synth_f32(threads * ch_per_thread, n, SEED).astype(np.float64)
     backend = oracle_mod.Ref() if kind == "reference" else orc
     frame = 4096
+    x = orc.synth_f32(ch_per_thread, n, SEED).astype(np.float64)     # every thread filters the same 24 rows
 
-    def work(t):
+    def work(_t):
         for c in range(ch_per_thread):
             # design inside the reference (same call the real caller makes), then stream frames
-            backend.fir_stream(0, frame, FLT_LEN, 0.1, 0.0, 2, x[t * ch_per_thread + c], flush=False)
+            backend.fir_stream(0, frame, FLT_LEN, 0.1, 0.0, 2, x[c], flush=False)
 
-    ths = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
-    t0 = time.perf_counter()
-    for th in ths:
-        th.start()
-    for th in ths:
-        th.join()
-    dt = time.perf_counter() - t0
-    total = threads * ch_per_thread * n
-    return {"value": total / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": kind,
-            "sample": f"{threads * ch_per_thread} ch x {n} samples, {FLT_LEN}-tap llz_fir_filter, frame {frame}, "
-                      f"{threads} threads ({dt:.1f} s)"}
+    def leg(nthreads):
+        ths = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        dt = time.perf_counter() - t0
+        return nthreads * ch_per_thread * n / dt / 1e6, dt
+
+    one, dt1 = leg(1)
+    allc, dta = leg(threads)
+    return {"value": allc, "unit": "Msamples/s", "cores": threads, "kind": kind,
+            "sample": f"{threads} threads x {ch_per_thread} ch x {n} samples, {FLT_LEN}-tap llz_fir_filter, frame {frame} "
+                      f"({dta:.1f} s); sysconf(_SC_NPROCESSORS_ONLN) = {online}",
+            "single_core": {"value": one, "unit": "Msamples/s/core", "cores": 1,
+                            "sample": f"1 thread x {ch_per_thread} ch x {n} samples ({dt1:.1f} s)"}}
 
 
 def ols_kernel_name(channels, n):
     """which overlap-save kernel the launcher takes (llzs_fir_ols_f32 in csrc/kernels/fir_ols.hip): the chain form when a
     half-wave walks several 16-job segments, the walk form on batches that fit one round"""
     jobs = (n + 1535) // 1536
-    return "k_fir_ols_chain_f32" if ((jobs + 15) // 16) * channels >= 4 * 4096 else "k_fir_ols_walk_f32"
+    return "k_fir_ols_chain_f32<IO_WIDE>" if ((jobs + 15) // 16) * channels >= 4 * 4096 else "k_fir_ols_walk_f32<IO_WIDE>"
+
+
+def kernel_source_sha():
+    """sha256 over the headline kernel's sources: profiles/pmc_traffic.json records the one it was measured on, and
+    `roofline.traffic` is reported only while they still match"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("fir_ols.hip", "fft32.hpp"):
+        h.update(open(os.path.join(ROOT, "llzlab_amd", "csrc", "kernels", f), "rb").read())
+    return h.hexdigest()
 
 
 def main():
@@ -75,7 +106,7 @@ def main():
     ap.add_argument("--algo", type=int, default=0, help="0 auto (overlap-save), 1 time domain, 2 overlap-save, 3 time domain on the matrix cores, 4 / 5 overlap-save with\n"
                          "2048- / 4096-point transforms")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--extra", action="store_true", help="also time the 63-tap time-domain FIR on one GPU (under 'also')")
+    ap.add_argument("--extra", action="store_true", help="(kept for old command lines: the extra configs now run by default)")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the channel-sharded resample / IIR configs (BASELINE configs 4 and 5) reported under 'also'")
     ap.add_argument("--dist-backend", default="nccl",
@@ -168,24 +199,35 @@ def main():
     samples_per_step = channels * n * world
     value = samples_per_step / (wall / args.steps) / 1e6                  # Msamples/s, whole job
 
-    # parity spot check against the oracle (outside the timed region): first + last 2 channels, first 16 Ki samples
+    # parity against the oracle (outside the timed region), SURVEY.md 8(d): first 4 + last 4 channels over their FULL
+    # length (every segment hand-over of the chain kernel, the ragged last segment) and all channels x first 16 Ki samples
     parity = None
     also = {}
     cpu = None
     if rank == 0:
         from oracle import pyoracle
         orc = pyoracle.Oracle()
-        sel = [0, 1, channels - 2, channels - 1]
-        m = min(n, 1 << 14)
         keep = FLT_LEN - 1
-        # the handle streams: every step after the first starts from the previous step's last 256 samples, so
-        # the oracle is fed [tail of x | head of x] and its first 256 outputs are dropped
-        xs = torch.cat([x[sel, n - keep:], x[sel, :m]], dim=1).cpu().numpy()
-        ref = orc.fir_batch_f32(xs, taps.astype(np.float32).astype(np.float64))[:, keep:]
-        got = y[sel, :m].cpu().numpy().astype(np.float64)
-        err = float(np.sqrt(np.mean((got - ref) ** 2)))
-        parity = {"rms_abs": err, "rms_rel": err / float(np.sqrt(np.mean(ref ** 2))), "tolerance": 1e-5,
-                  "checked": f"{len(sel)} ch x {m} samples vs CPU oracle (streaming state included)"}
+        h64 = taps.astype(np.float32).astype(np.float64)
+
+        def rms_pair(got, ref):
+            err = float(np.sqrt(np.mean((got.astype(np.float64) - ref) ** 2)))
+            return err, err / float(np.sqrt(np.mean(ref ** 2)))
+
+        # the handle streams: every step after the first starts from the previous step's last 256 samples, so the
+        # oracle is fed [tail of x | x] and its first 256 outputs are dropped
+        sel = sorted(set(list(range(min(4, channels))) + list(range(max(0, channels - 4), channels))))
+        xs = torch.cat([x[sel, n - keep:], x[sel]], dim=1).cpu().numpy()
+        full_abs, full_rel = rms_pair(y[sel].cpu().numpy(), orc.fir_batch_f32_mt(xs, h64)[:, keep:])
+        m = min(n, 1 << 14)
+        xs = torch.cat([x[:, n - keep:], x[:, :m]], dim=1).cpu().numpy()
+        head_abs, head_rel = rms_pair(y[:, :m].cpu().numpy(), orc.fir_batch_f32_mt(xs, h64)[:, keep:])
+        del xs
+        parity = {"rms_abs": max(full_abs, head_abs), "rms_rel": max(full_rel, head_rel), "tolerance": 1e-5,
+                  "full_length": {"channels": sel, "samples": n, "rms_abs": full_abs, "rms_rel": full_rel},
+                  "all_channels_head": {"channels": channels, "samples": m, "rms_abs": head_abs, "rms_rel": head_rel},
+                  "checked": f"{len(sel)} ch x {n} samples + {channels} ch x {m} samples vs CPU oracle "
+                             "(streaming state included)"}
         if world == 1 and not args.no_cpu:
             cpu = cpu_baseline(taps, pyoracle)
 
@@ -218,7 +260,7 @@ def main():
     torch.cuda.empty_cache()
     if not args.no_also:
         also.update(sharded_configs(torch, filters, capi, shard, dev, comm_dev, stream, rank, world, barrier))
-    if args.extra and world == 1:
+    if not args.no_also and world == 1:
         also.update(extra_paths(torch, filters, capi, dev, stream))
 
     if rank == 0:
@@ -228,7 +270,10 @@ def main():
         # the committed PMC figure is per launch of the DEFAULT workload: report it only for that workload
         if os.path.exists(tpath) and channels == CHANNELS and n == N_SAMPLES and fir_algo == 2:
             try:
-                traffic = json.load(open(tpath)).get("headline_kernel_bytes_per_launch")
+                rec = json.load(open(tpath))
+                # measured on exactly these kernel sources?  (a stale figure is not reported)
+                if rec.get("kernel_source_sha256") == kernel_source_sha():
+                    traffic = rec.get("headline_kernel_bytes_per_launch")
             except Exception:
                 traffic = None
         algo_name = {1: "time-domain", 2: "overlap-save-1024", 3: "time-domain-matrix-core", 4: "overlap-save-2048",
@@ -329,22 +374,26 @@ def sharded_configs(torch, filters, capi, shard, dev, comm_dev, stream, rank, wo
     x = torch.empty(ch, n, dtype=torch.float32, device=dev)
     y = torch.empty_like(x)
     filters.synth_f32(x, SEED, chan0=lo, stream=stream)
-    coef = np.tile(np.array([0.2066, 0.4131, 0.2066, 1.0, -0.3695, 0.1958]), (8, 1)) if rank == 0 else np.zeros((8, 6))
-    coef = shard.broadcast_table(coef, device=comm_dev)
-    q = filters.IirCascadeMC(ch, coef, stream=stream)
-    ms = timed(lambda: q.filter(x, y), 20, warm=10)      # a 2 ms kernel: clocks need tens of ms to settle after idling
-    out["iir8_1024ch_sharded"] = {
-        "Msamples_s": total_ch * n / ms / 1e3, "GBs_per_gpu": 8 * ch * n / ms / 1e6,
-        "hbm_frac_per_gpu": 8 * ch * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "channels_per_gpu": ch,
-        "scaling": "strong",
-        # the binding roof of this kernel is the vector pipe, not HBM: 7 FMA per sample and section, in
-        # float32 when every section's rounding-noise gain allows it (this coefficient set: poles at radius 0.44), else
-        # in double
-        "arithmetic": "f32" if q.precision == 32 else "f64",
-        "valu_TFLOPs_per_gpu": 2 * 7 * 8 * ch * n / ms / 1e9,
-        "valu_peak_TFLOPs": 157.3 if q.precision == 32 else 78.6,
-        "valu_frac_per_gpu": 2 * 7 * 8 * ch * n / ms / 1e9 / (157.3 if q.precision == 32 else 78.6)}
-    q.close()
+    # two coefficient sets: 8 copies of the in-tree low-pass section (pole radius 0.44, float32
+    # arithmetic passes the noise-gain check) and 8 high-Q sections at pole radius 0.99 (double arithmetic)
+    for key, row in (("iir8_1024ch_sharded", [0.2066, 0.4131, 0.2066, 1.0, -0.3695, 0.1958]),
+                     ("iir8_r099_1024ch_sharded", [0.01, 0.0, -0.01, 1.0, -2 * 0.99 * np.cos(0.3), 0.99 ** 2])):
+        coef = np.tile(np.array(row), (8, 1)) if rank == 0 else np.zeros((8, 6))
+        coef = shard.broadcast_table(coef, device=comm_dev)
+        q = filters.IirCascadeMC(ch, coef, stream=stream)
+        ms = timed(lambda: q.filter(x, y), 20, warm=10)      # a 2 ms kernel: clocks need tens of ms to settle after idling
+        fma = q.fma_per_sample_section if hasattr(q, "fma_per_sample_section") else 7
+        out[key] = {
+            "Msamples_s": total_ch * n / ms / 1e3, "GBs_per_gpu": 8 * ch * n / ms / 1e6,
+            "hbm_frac_per_gpu": 8 * ch * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "channels_per_gpu": ch,
+            "scaling": "strong",
+            # the binding roof of this kernel is the vector pipe, not HBM: float32 when every section's
+            # rounding-noise gain allows it, else double
+            "arithmetic": "f32" if q.precision == 32 else "f64",
+            "valu_TFLOPs_per_gpu": 2 * fma * 8 * ch * n / ms / 1e9,
+            "valu_peak_TFLOPs": 157.3 if q.precision == 32 else 78.6,
+            "valu_frac_per_gpu": 2 * fma * 8 * ch * n / ms / 1e9 / (157.3 if q.precision == 32 else 78.6)}
+        q.close()
     del x, y
     torch.cuda.empty_cache()
     return out
@@ -368,7 +417,7 @@ def extra_paths(torch, filters, capi, dev, stream):
         L.llz_hip_timer_free(t)
         return ms
 
-    # config 2: 64 ch x 63 taps x 1 Mi, time domain
+    # config 2: 64 ch x 63 taps x 1 Mi on its stated algorithm (time domain) and on the library's own choice
     ch, n = 64, 1 << 20
     x = torch.empty(ch, n, dtype=torch.float32, device=dev)
     y = torch.empty_like(x)
@@ -377,7 +426,8 @@ def extra_paths(torch, filters, capi, dev, stream):
     for name, algo in (("fir63_64ch_time_domain", filters.FIR_ALGO_TIME), ("fir63_64ch_overlap_save", filters.FIR_ALGO_OVERLAP_SAVE)):
         f = filters.FirFilterMC(ch, n, taps63, algo=algo, stream=stream)
         ms = timeit(lambda: f.filter(x, y), 10)
-        out[name] = {"Msamples_s": ch * n / ms / 1e3, "GBs": 8 * ch * n / ms / 1e6, "ms": ms}
+        out[name] = {"Msamples_s": ch * n / ms / 1e3, "GBs": 8 * ch * n / ms / 1e6,
+                     "hbm_frac": 8 * ch * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms}
         f.close()
     return out
 

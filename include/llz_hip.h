@@ -25,6 +25,12 @@ int   llz_hip_set_device(int device);
 int   llz_hip_get_device(void);
 int   llz_hip_synchronize(void *stream);       /* hipStreamSynchronize (NULL = default stream) */
 
+/* Measurement / test override of one of the library's own choices (kernel form, grid shape): name as listed by
+ * llz_hip_tune_name(i), value < 0 clears it.  Returns LLZ_OK, or LLZ_ERR_ARG for an unknown name.  The
+ * library never reads environment variables; without calls to this function every choice follows from the problem. */
+int         llz_hip_tune(const char *name, int value);
+const char *llz_hip_tune_name(int index);      /* NULL past the last name */
+
 void *llz_hip_malloc(size_t bytes);            /* device memory, NULL on failure */
 void  llz_hip_free(void *dev_ptr);
 int   llz_hip_upload(void *dev_dst, const void *host_src, size_t bytes);

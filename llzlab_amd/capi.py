@@ -79,6 +79,8 @@ def lib():
     sig("llz_hip_set_device", i, i)
     sig("llz_hip_get_device", i)
     sig("llz_hip_synchronize", i, vp)
+    sig("llz_hip_tune", i, C.c_char_p, i)
+    sig("llz_hip_tune_name", C.c_char_p, i)
     sig("llz_hip_malloc", vp, C.c_size_t)
     sig("llz_hip_free", None, vp)
     sig("llz_hip_upload", i, vp, vp, C.c_size_t)
@@ -224,7 +226,36 @@ def lib():
     sig("llz_pcm_deinterleave_i16_f32", i, vp, vp, i, lng, C.c_float, vp)
     sig("llz_pcm_interleave_f32_i16", i, vp, vp, i, lng, C.c_float, vp)
     _lib = L
+    # measurement harness only: LLZ_TUNE="name=value,..." is applied HERE (Python), through the public override call;
+    # the C library itself never reads the environment
+    for item in filter(None, os.environ.get("LLZ_TUNE", "").split(",")):
+        name, _, val = item.partition("=")
+        if L.llz_hip_tune(name.strip().encode(), int(val)) != 0:
+            raise LlzError("LLZ_TUNE: unknown override " + name)
     return L
+
+
+def tune(name, value):
+    """Override (value >= 0) or clear (value < 0) one of the library's own kernel-form choices: tests and A/B runs only."""
+    if lib().llz_hip_tune(name.encode(), int(value)) != 0:
+        raise LlzError("unknown override " + name)
+
+
+class tuned:
+    """with capi.tuned(ols_chain=1): ...  -- overrides set on entry and cleared on exit."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            tune(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            tune(k, -1)
+        return False
 
 
 def last_error():

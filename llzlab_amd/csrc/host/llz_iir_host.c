@@ -109,7 +109,8 @@ typedef struct {
     double *d_pd, *d_pl; /* state-transition powers for the pipelined kernel: [S][6][4] and [S][64][12] */
     float *d_coef32, *d_pd32, *d_pl32;   /* float copies for the wave-autonomous float32 kernel: [S][5], [S][16], [S][64][12] */
     float *d_ph32;       /* [S][24]: (h1[k], h2[k]) k < 8 = zero-input outputs of the unit start states, b0 b1 b2 a1 a2, pad */
-    double *d_state;     /* [channels][stages][x1,x2,y1,y2] */
+    double *d_state;     /* [channels][stages][x1,x2,y1,y2]: the current state */
+    double *d_state_alt; /* where a time-segmented launch writes the frame's end state (then the two swap) */
     int warm_chunks;     /* 1024-sample chunks after which any state error has decayed below 1e-13 (0: unknown / too long) */
     int float32_ok;      /* every section's rounding-noise gain is small enough for float32 arithmetic */
     void *stream;
@@ -119,7 +120,7 @@ typedef struct {
 static void iirm_destroy(iirm_t *f)
 {
     if (!f) return;
-    llzs_free(f->d_coef); llzs_free(f->d_state); llzs_free(f->d_pd); llzs_free(f->d_pl);
+    llzs_free(f->d_coef); llzs_free(f->d_state); llzs_free(f->d_state_alt); llzs_free(f->d_pd); llzs_free(f->d_pl);
     llzs_free(f->d_coef32); llzs_free(f->d_pd32); llzs_free(f->d_pl32); llzs_free(f->d_ph32);
     llz_stage_release(&f->st_in); llz_stage_release(&f->st_out);
     f->tag = 0;
@@ -284,11 +285,12 @@ unsigned long llz_iir_cascade_mc_init(int channels, int stages, const double *co
         }
         f->d_coef = (double *)llzs_malloc(sizeof(double) * 5 * (size_t)stages);
         f->d_state = (double *)llzs_malloc(st_bytes);
-        if (!f->d_coef || !f->d_state) rc = LLZ_ERR_NOMEM;
+        f->d_state_alt = (double *)llzs_malloc(st_bytes);
+        if (!f->d_coef || !f->d_state || !f->d_state_alt) rc = LLZ_ERR_NOMEM;
     }
     if (rc == LLZ_OK) rc = llzs_h2d(f->d_coef, c5, sizeof(double) * 5 * (size_t)stages, NULL);
     if (rc == LLZ_OK) rc = llzs_memset(f->d_state, 0, st_bytes, NULL);
-    if (rc == LLZ_OK) f->float32_ok = iirm_float32_ok(c5, stages) && !getenv("LLZ_IIR_F64");   /* env: A/B runs */
+    if (rc == LLZ_OK) f->float32_ok = iirm_float32_ok(c5, stages) && llzs_tune(LLZS_TUNE_IIR_F64) != 1;
     if (rc == LLZ_OK) rc = iirm_build_powers(f, c5, 16);
     if (rc == LLZ_OK) f->warm_chunks = iirm_memory_chunks(c5, stages);
     if (rc == LLZ_OK) rc = llzs_sync(NULL);
@@ -349,22 +351,26 @@ int llz_iir_cascade_mc(unsigned long handle, const float *x, float *y, int frame
     const int n_fast = aligned ? frame_len - frame_len % chunk : 0;
     /* short-memory cascades of up to 8 sections: a wave per (channel, time segment), all sections in registers (float32,
      * packed: 3.65 -> 2.3 ms on config 4; double: 4.76 -> 3.75 ms on the 0.99-radius set) */
-    const char *kern = getenv("LLZ_IIR_KERNEL");
     /* (needs enough (channel, segment) items to fill most of the chip, segments at least 8 x the warm-up long; measured
      * crossover against the stage pipeline, tools/iir_xover.sh: 1024 items pipeline, 2048 items wave form) */
     const long seg_items = f->warm_chunks > 0 ? (long)f->channels * (n_fast / LLZS_IIR_PIPE_CHUNK / (8 * f->warm_chunks)) : 0;
-    const char *mi = getenv("LLZ_IIR_WAVE_MIN_ITEMS");                /* crossover experiments */
-    const int wave_form = f->stages <= 8 && seg_items >= (mi ? atol(mi) : 2048) && !(kern && strcmp(kern, "pipe") == 0) &&
+    const int min_items = llzs_tune(LLZS_TUNE_IIR_WAVE_MIN_ITEMS) >= 0 ? llzs_tune(LLZS_TUNE_IIR_WAVE_MIN_ITEMS) : 2048;
+    const int wave_form = f->stages <= 8 && seg_items >= min_items && llzs_tune(LLZS_TUNE_IIR_PIPE) != 1 &&
                           (!f->float32_ok || f->d_pl32);
     if (rc == LLZ_OK && n_fast > 0 && wave_form && f->float32_ok)
-        rc = llzs_iir_cascade_wave_f32(d_in, d_out, f->d_coef32, f->d_pd32, f->d_pl32, f->d_ph32, f->d_state, f->channels, n_fast,
+        rc = llzs_iir_cascade_wave_f32(d_in, d_out, f->d_coef32, f->d_pd32, f->d_pl32, f->d_ph32, f->d_state, f->d_state_alt, f->channels, n_fast,
                                        frame_len, frame_len, f->stages, f->warm_chunks, f->stream);
     else if (rc == LLZ_OK && n_fast > 0 && wave_form)
-        rc = llzs_iir_cascade_wave_f64(d_in, d_out, f->d_coef, f->d_pd, f->d_pl, f->d_state, f->channels, n_fast,
+        rc = llzs_iir_cascade_wave_f64(d_in, d_out, f->d_coef, f->d_pd, f->d_pl, f->d_state, f->d_state_alt, f->channels, n_fast,
                                        frame_len, frame_len, f->stages, f->warm_chunks, f->stream);
     else if (rc == LLZ_OK && n_fast > 0)
-        rc = llzs_iir_cascade_pipe_f32(d_in, d_out, f->d_coef, f->d_pd, f->d_pl, f->d_state, f->channels, n_fast,
+        rc = llzs_iir_cascade_pipe_f32(d_in, d_out, f->d_coef, f->d_pd, f->d_pl, f->d_state, f->d_state_alt, f->channels, n_fast,
                                        frame_len, frame_len, f->stages, f->warm_chunks, f->float32_ok, f->stream);
+    if (rc == LLZ_OK && n_fast > 0) {                 /* the launch read d_state and wrote d_state_alt */
+        double *t = f->d_state;
+        f->d_state = f->d_state_alt;
+        f->d_state_alt = t;
+    }
     if (rc == LLZ_OK && n_fast < frame_len)
         rc = llzs_iir_cascade_f32(d_in + n_fast, d_out + n_fast, f->d_coef, f->d_state, f->channels,
                                   frame_len - n_fast, frame_len, frame_len, f->stages, f->stream);

@@ -288,8 +288,7 @@ static int rsm_upload_matrix(rsm_t *r)
     for (size_t i = 0; i < count; i++) m32[i] = (float)r->taps.mat[i];
     int rc = llzs_h2d(r->d_mat, m32, sizeof(float) * count, NULL);
     if (rc == LLZ_OK && r->L == 1) {
-        const char *path = getenv("LLZ_RS_DEC_PATH");       /* "valu" selects the LDS polyphase kernel (A/B runs) */
-        r->use_mfma = llzs_fir_mfma_f32_fits(r->Q, r->M) && !(path && strcmp(path, "valu") == 0);
+        r->use_mfma = llzs_fir_mfma_f32_fits(r->Q, r->M) && llzs_tune(LLZS_TUNE_RS_DEC_VALU) != 1;
         /* phase taps for the decimator fast path: gp[m][j] = g[0][j*M + m], rows zero padded to tp */
         const int per_phase = (r->Q + r->M - 1) / r->M;
         r->tp = (per_phase + 15) & ~15;

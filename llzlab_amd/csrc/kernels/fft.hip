@@ -1544,7 +1544,7 @@ int launch_fft(typename A::data_t *data, int count, int size, const typename A::
 
 extern "C" int llzs_fft_f32(float *data, int count, int size, const float *cs, int inverse, void *stream)
 {
-    if ((size == 64 || size == 256 || size == 4096) && data && cs && count >= 1 && !getenv("LLZ_FFT_GENERIC")) {
+    if ((size == 64 || size == 256 || size == 4096) && data && cs && count >= 1 && llzs_tune(LLZS_TUNE_FFT_GENERIC) < 1) {
         // the [E][E] twiddle table is derived once per device and size from the caller's table (kept for the process)
         static float2 *tables[16][3];
         int dev = 0;
@@ -1575,7 +1575,7 @@ extern "C" int llzs_fft_f32(float *data, int count, int size, const float *cs, i
         LLZ_LAUNCH_CHECK("k_fft_square_f32");
         return LLZ_OK;
     }
-    if ((size == 128 || size == 512 || size == 2048) && data && cs && count >= 1 && !getenv("LLZ_FFT_GENERIC")) {
+    if ((size == 128 || size == 512 || size == 2048) && data && cs && count >= 1 && llzs_tune(LLZS_TUNE_FFT_GENERIC) < 1) {
         static float2 *tables2[16][3][2];                           // [device][size][tw2d, tw1]
         int dev = 0;
         LLZ_HIP_CHECK(hipGetDevice(&dev));
@@ -1607,7 +1607,7 @@ extern "C" int llzs_fft_f32(float *data, int count, int size, const float *cs, i
         LLZ_LAUNCH_CHECK("k_fft_2xsquare_f32");
         return LLZ_OK;
     }
-    if (size == 1024 && data && cs && count >= 1 && !getenv("LLZ_FFT_GENERIC")) {
+    if (size == 1024 && data && cs && count >= 1 && llzs_tune(LLZS_TUNE_FFT_GENERIC) < 1) {
         const unsigned blocks = (unsigned)((count + 7) / 8);
         if (inverse)
             hipLaunchKernelGGL(k_fft1024_f32<true>, dim3(blocks), dim3(256), 0, as_stream(stream),
@@ -1684,7 +1684,7 @@ extern "C" int llzs_fft_f64(double *data, int size, const double *cs, int invers
 
 extern "C" int llzs_fft_fixed(int *data, int count, int size, const short *cs, int inverse, void *stream)
 {
-    if (data && cs && count >= 1 && !getenv("LLZ_FFT_GENERIC")) {
+    if (data && cs && count >= 1 && llzs_tune(LLZS_TUNE_FFT_GENERIC) < 1) {
 #define LLZ_Q15_REG(EE, TT)                                                                                          \
     do {                                                                                                             \
         const unsigned blocks = (unsigned)((count + (256 / EE) - 1) / (256 / EE));                                   \
@@ -1721,7 +1721,7 @@ extern "C" int llzs_acf_fused_f32(const float *x, float *r, int frames, int n, i
         llzs_set_error("acf_fused_f32: bad arguments (n=%d p=%d size=%d)", n, p, size);
         return LLZ_ERR_ARG;
     }
-    if ((size == 128 || size == 512) && !getenv("LLZ_FFT_GENERIC")) {   // the same on square_core (E = 8, 16)
+    if ((size == 128 || size == 512) && llzs_tune(LLZS_TUNE_FFT_GENERIC) < 1) {   // the same on square_core (E = 8, 16)
         static float2 *tabs[16][2];
         int dev = 0;
         LLZ_HIP_CHECK(hipGetDevice(&dev));
@@ -1741,13 +1741,13 @@ extern "C" int llzs_acf_fused_f32(const float *x, float *r, int frames, int n, i
         LLZ_LAUNCH_CHECK("k_acf_sq_f32");
         return LLZ_OK;
     }
-    if (size == 1024 && !getenv("LLZ_FFT_GENERIC")) {
+    if (size == 1024 && llzs_tune(LLZS_TUNE_FFT_GENERIC) < 1) {
         hipLaunchKernelGGL(k_acf1024_f32, dim3((unsigned)((frames + 7) / 8)), dim3(256), 0, as_stream(stream), x, r, frames,
                            n, p, cs);
         LLZ_LAUNCH_CHECK("k_acf1024_f32");
         return LLZ_OK;
     }
-    if (size == 2048 && !getenv("LLZ_FFT_GENERIC")) {              // two real 2048-point transforms = two complex 1024-point ones
+    if (size == 2048 && llzs_tune(LLZS_TUNE_FFT_GENERIC) < 1) {              // two real 2048-point transforms = two complex 1024-point ones
         hipLaunchKernelGGL(k_acf2048_f32, dim3((unsigned)((frames + 7) / 8)), dim3(256), 0, as_stream(stream), x, r,
                            frames, n, p, cs);
         LLZ_LAUNCH_CHECK("k_acf2048_f32");
@@ -1926,7 +1926,7 @@ extern "C" int llzs_stft_analysis_f32(const float *x, const float *hist, float *
     const int rc = stft_check(channels, frames, F, size, &log2n, "stft_analysis_f32");
     if (rc != LLZ_OK) return rc;
     const long total_tr = (long)channels * frames;
-    if ((size == 256 || size == 512 || size == 2048) && !getenv("LLZ_FFT_GENERIC")) {
+    if ((size == 256 || size == 512 || size == 2048) && llzs_tune(LLZS_TUNE_FFT_GENERIC) < 1) {
         const float2 *tw2d = nullptr, *tw1 = nullptr;
         const int trc = stft_reg_tables(size, cs, stream, &tw2d, &tw1);
         if (trc != LLZ_OK) return trc;
@@ -1944,7 +1944,7 @@ extern "C" int llzs_stft_analysis_f32(const float *x, const float *hist, float *
         LLZ_LAUNCH_CHECK("k_stft_analysis_reg_f32");
         return LLZ_OK;
     }
-    if (size == 1024 && !getenv("LLZ_FFT_GENERIC")) {
+    if (size == 1024 && llzs_tune(LLZS_TUNE_FFT_GENERIC) < 1) {
         hipLaunchKernelGGL(k_stft_analysis1024_f32, dim3((unsigned)((total_tr + 7) / 8)), dim3(256), 0, as_stream(stream),
                            x, hist, re, im, w, frames, F, cs, x_pitch, total_tr);
         LLZ_LAUNCH_CHECK("k_stft_analysis1024_f32");
@@ -1980,7 +1980,7 @@ extern "C" int llzs_stft_synthesis_f32(const float *re, const float *im, float *
     int run_len = (int)(want < 8 * R ? 8 * R : want);
     if (run_len < tpw) run_len = tpw;
     if (run_len > frames) run_len = frames;
-    if ((size == 256 || size == 512 || size == 2048) && !getenv("LLZ_FFT_GENERIC")) {
+    if ((size == 256 || size == 512 || size == 2048) && llzs_tune(LLZS_TUNE_FFT_GENERIC) < 1) {
         const float2 *tw2d = nullptr, *tw1 = nullptr;
         const int trc = stft_reg_tables(size, cs, stream, &tw2d, &tw1);
         if (trc != LLZ_OK) return trc;
@@ -2001,7 +2001,7 @@ extern "C" int llzs_stft_synthesis_f32(const float *re, const float *im, float *
         LLZ_LAUNCH_CHECK("k_stft_synthesis_reg_f32");
         return LLZ_OK;
     }
-    if (size == 1024 && !getenv("LLZ_FFT_GENERIC")) {
+    if (size == 1024 && llzs_tune(LLZS_TUNE_FFT_GENERIC) < 1) {
         if (run_len < 8 * R) run_len = 8 * R;
         if (run_len > frames) run_len = frames;
         const int runs1k = (frames + run_len - 1) / run_len;

@@ -139,27 +139,36 @@ __device__ __forceinline__ int xaddr(int row, int col) { return row * OLS_PITCH 
 // then reads its row. reg index r of the source is stored at row brev5(r) (undoing the FFT's output order).
 #define OLS_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+// wcol: the column this lane's registers go to (its index in the twiddle W^(row * wcol) as well); rrow: the row it reads
+// back.  The half-wave's lanes must cover 0..31 once in each (any lane order: the overlap-save kernel's wide I/O form
+// owns permuted columns).
 template <bool INV>
-__device__ __forceinline__ void transpose_twiddle(cf (&v)[32], float *buf, const float2 *__restrict__ tw, int l5)
+__device__ __forceinline__ void transpose_twiddle(cf (&v)[32], float *buf, const float2 *__restrict__ tw, int wcol, int rrow)
 {
-    // inter-pass twiddle W_1024^(+-brev5(r)*l5) applied on the way out, then two single-plane transposes
+    // inter-pass twiddle W_1024^(+-brev5(r)*wcol) applied on the way out, then two single-plane transposes
 #pragma unroll
     for (int r = 0; r < 32; r++) {
-        const float2 w = tw[brev5(r) * 32 + l5];
+        const float2 w = tw[brev5(r) * 32 + wcol];
         v[r] = cmul<INV>(v[r], cf{w.x, w.y});
     }
 #pragma unroll
-    for (int r = 0; r < 32; r++) buf[xaddr(brev5(r), l5)] = v[r].x;
+    for (int r = 0; r < 32; r++) buf[xaddr(brev5(r), wcol)] = v[r].x;
     OLS_WAVE_SYNC();
 #pragma unroll
-    for (int cidx = 0; cidx < 32; cidx++) v[cidx].x = buf[xaddr(l5, cidx)];
+    for (int cidx = 0; cidx < 32; cidx++) v[cidx].x = buf[xaddr(rrow, cidx)];
     OLS_WAVE_SYNC();
 #pragma unroll
-    for (int r = 0; r < 32; r++) buf[xaddr(brev5(r), l5)] = v[r].y;
+    for (int r = 0; r < 32; r++) buf[xaddr(brev5(r), wcol)] = v[r].y;
     OLS_WAVE_SYNC();
 #pragma unroll
-    for (int cidx = 0; cidx < 32; cidx++) v[cidx].y = buf[xaddr(l5, cidx)];
+    for (int cidx = 0; cidx < 32; cidx++) v[cidx].y = buf[xaddr(rrow, cidx)];
     OLS_WAVE_SYNC();
+}
+
+template <bool INV>
+__device__ __forceinline__ void transpose_twiddle(cf (&v)[32], float *buf, const float2 *__restrict__ tw, int l5)
+{
+    transpose_twiddle<INV>(v, buf, tw, l5, l5);
 }
 
 } // namespace

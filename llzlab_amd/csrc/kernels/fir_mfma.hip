@@ -452,10 +452,7 @@ int mfb_pick_nacc(int T, int M)
 {
     mfb_shape sh;
     size_t bytes;
-    if (const char *e = getenv("LLZ_MFMA_NACC")) {                   // A/B runs
-        const int v = atoi(e);
-        if ((v == 1 || v == 2) && mfb_make_shape(T, M, v, 1, &sh, &bytes)) return v;
-    }
+    if (const int v = llzs_tune(LLZS_TUNE_MFMA_NACC); (v == 1 || v == 2) && mfb_make_shape(T, M, v, 1, &sh, &bytes)) return v;
     if (mfb_make_shape(T, M, 2, 1, &sh, &bytes) && bytes <= 78 * 1024) return 2;
     if (mfb_make_shape(T, M, 1, 1, &sh, &bytes)) return 1;
     return 0;
@@ -477,7 +474,7 @@ int mfb_launch(const float *in, float *out, const float *hist, const float *taps
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     int per_cu = (int)((160 * 1024) / lds_bytes);
     if (per_cu > 4) per_cu = 4;
-    if (const char *e = getenv("LLZ_MFMA_WG_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
+    if (const int v = llzs_tune(LLZS_TUNE_MFMA_WG_PER_CU); v >= 1 && v <= 8) per_cu = v;
     long grid = (long)cus * per_cu;
     if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL((k_fir_mfma_bf16x3<NACC, NV>), dim3((unsigned)grid), dim3(MF_THREADS), lds_bytes, as_stream(stream),

@@ -1,4 +1,4 @@
-// fir_ols.hip -- K4: overlap-save long FIR (up to 257 taps) with a 1024-point complex FFT that never leaves the CU.
+// fir_ols.hip -- K4: overlap-save FIR (up to 257 taps) with a 1024-point complex FFT that never leaves the CU.
 //
 // New functionality relative to the reference (llz_fir.c is time-domain only); its end-to-end
 // oracle is the time-domain llz_fir_filter (llz_fir.c:547-584), its FFT stage follows the sign/scale
@@ -6,29 +6,37 @@
 // folded into the filter spectrum on the host).
 //
 // Why: 257 taps in the time domain is 514 flop per 8 B of HBM traffic -> VALU-bound at ~30 % of the HBM roofline.
-// Overlap-save costs ~55 flop per sample and is HBM-bound.
+// Overlap-save costs ~46 vector lane-operations per sample and is HBM-bound.
 //
 // Mapping to CDNA4 (wave64):
-//   * job = one channel x 1536 new samples. Two consecutive 1024-sample blocks (each: 256 overlap + 768 new)
-//     are packed as real and imaginary part of ONE complex 1024-point transform -- the filter is real, so
+//   * job = one channel x 1536 new samples.  Two consecutive 1024-sample blocks (each: 256 overlap + 768 new) are
+//     the real and imaginary part of ONE complex 1024-point transform -- the filter is real, so
 //     IFFT(FFT(xa + j xb) H) = ya + j yb and nothing has to be untangled.
-//   * a half-wave (32 lanes) owns a job: 1024 = 32 x 32, every lane keeps 32 complex values in registers.
-//     A transform is two passes of 32-point in-register FFTs (constant twiddles fold into the code) with one
-//     32x32 transpose through LDS between them (row pitch 33 floats: conflict-free ds_write_b32/ds_read_b32).
-//     Forward leaves bins digit-reversed in the register index, which is free (register renaming), so
-//     FFT -> multiply by H -> IFFT needs no permutation pass at all.
-//   * per workgroup (4 waves): LDS = 8 KB inter-pass twiddles W_1024^(a*b) + 8 KB filter spectrum + 4 x 8.25 KB
-//     transpose buffers = 49 KB -> 3 workgroups (12 waves) per CU.
-//   * waves are independent (no workgroup barrier after the table load) and walk the job list with a grid
-//     stride; neighbouring jobs of a channel sit in neighbouring waves so the 256-sample halo re-read is an L2 hit.
-// HBM traffic: 4 B read + 4 B written per sample (+1/6 halo re-read served by L2).
+//   * a half-wave (32 lanes) owns a job: 1024 = 32 x 32, every lane keeps 32 complex values in registers.  A
+//     transform is two passes of 32-point in-register FFTs (fft32.hpp) with one 32 x 32 transpose through LDS
+//     between them (row pitch 33 floats).  Forward leaves bins digit-reversed in the register index, which is
+//     free (register renaming), so FFT -> multiply by H -> IFFT needs no permutation pass at all.
+//   * a half-wave walks a SEGMENT of up to 16 consecutive jobs of one channel and carries the 256-sample overlap in
+//     registers from job to job, so every input sample is requested from memory exactly once; the next job's samples
+//     are requested (into registers) before the current job is transformed.  Two kernels share that job step:
+//       k_fir_ols_walk_f32   one segment after the other (batches that fit one round of the grid)
+//       k_fir_ols_chain_f32  the prefetch is carried ACROSS segments: the last job of a segment requests the first job
+//                            and the halo of the half-wave's next segment (large batches: the headline)
+//   * HBM access shape (template parameter IO):
+//       IO_WIDE   8 bytes per lane, every wave instruction moves 512 CONTIGUOUS bytes of one job: lane (q = lane % 16,
+//                 i = lane / 16) takes columns 2q, 2q+1 of row 4m+i of the wave's lower-half job and, in a second
+//                 instruction, of its upper-half job.  A 4 x 4 transpose between the lane's quarter and four
+//                 registers (two v_permlane16_swap + two v_permlane32_swap, gfx950) then hands every sample to the
+//                 lane that transforms it: +96 vector instructions per job pair (~4 %) for accesses four times as
+//                 long as the first form's.
+//       IO_DWORD  one dword per lane, a half-wave instruction moves 128 contiguous bytes of its own job (the first
+//                 form; rows that are not 8-byte aligned, and the ragged first / last jobs of any row, use it)
+//   * per workgroup (4 waves): LDS = 8 KB inter-pass twiddles W_1024^(a*b) + 8 KB filter spectrum + 8 x 4.1 KB
+//     transpose buffers = 49 KB; two workgroups per CU (the prefetch registers allow two waves per SIMD).
+// HBM traffic: 4 B read + 4 B written per sample, nothing re-read (PMC: profiles/pmc_traffic.json).
 #include <stdlib.h>
 #include "common.hpp"
 #include "fft32.hpp"
-
-#ifndef LLZ_DIAG
-#define LLZ_DIAG 0     /* 1 / 2: timing-only builds for ablation (EXTRA_HIPFLAGS=-DLLZ_DIAG=n), never shipped */
-#endif
 
 namespace {
 
@@ -36,272 +44,141 @@ constexpr int OLS_N = 1024;
 constexpr int OLS_OVERLAP = 256;
 constexpr int OLS_VALID = OLS_N - OLS_OVERLAP;     // 768
 constexpr int OLS_JOB = 2 * OLS_VALID;             // 1536 new samples per complex transform
-#ifndef LLZ_OLS_WAVES
-#define LLZ_OLS_WAVES 4
-#endif
-constexpr int OLS_WAVES = LLZ_OLS_WAVES;
+constexpr int OLS_WAVES = 4;
 constexpr int OLS_THREADS = 64 * OLS_WAVES;
-// everything a half-wave needs to know about its job
-struct ols_job {
-    const float *row;      // input row of the job's channel
-    float *orow;           // output row
-    const float *hrow;     // history row (flt_len-1 samples) or nullptr
-    int s;                 // first new sample
-    bool live;             // false: the idle upper half of an odd last pair
+constexpr int OLS_SEG = 16;                        // jobs per segment at most (16 x 1536 samples of one channel)
+
+constexpr int IO_DWORD = 1, IO_WIDE = 2;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// where a lane sits: which of the wave's two jobs it transforms, which column of the 32 x 32 decomposition it owns, and
+// (wide form) which 8-byte column pair q and row-in-group i it moves between HBM and registers
+struct ols_lane {
+    int half, col, q, i;
 };
 
-__device__ __forceinline__ ols_job ols_locate(long pair, int half, const float *in, float *out, const float *hist,
-                                              long in_pitch, long out_pitch, int keep, int jobs_per_channel,
-                                              long total_jobs)
+template <int IO>
+__device__ __forceinline__ ols_lane ols_lane_of(int lane)
 {
-    ols_job jb;
-    const long job = pair * 2 + half;
-    jb.live = job < total_jobs;
-    const int c = jb.live ? (int)(job / jobs_per_channel) : 0;
-    const int j = jb.live ? (int)(job - (long)c * jobs_per_channel) : 0;
-    jb.s = j * OLS_JOB;
-    jb.row = in + (size_t)c * in_pitch;
-    jb.orow = out + (size_t)c * out_pitch;
-    jb.hrow = hist ? hist + (size_t)c * keep : nullptr;
-    return jb;
+    ols_lane g;
+    g.half = lane >> 5;
+    g.q = lane & 15;
+    g.i = lane >> 4;
+    // wide form: after the quarter transpose lane (q, i) holds column 2q + (i & 1) of job i >> 1
+    g.col = IO == IO_WIDE ? 2 * (lane & 15) + ((lane >> 4) & 1) : (lane & 31);
+    return g;
 }
 
-// block A = samples [s-256, s+768) -> real parts, block B = [s+512, s+1536) -> imaginary parts;
-// register n1 of lane l5 holds sample 32*n1 + l5 of each block
-__device__ __forceinline__ void ols_load(cf (&v)[32], const ols_job &jb, int l5, int n, int keep)
+// one segment of one half-wave: `count` consecutive jobs of channel c starting at job j0
+struct ols_seg {
+    bool live;
+    int c, j0, count;
+};
+
+struct ols_geom {
+    int n, keep, jobs_per_channel, segs_per_channel, seg_len;
+    long total_segs, in_pitch, out_pitch;
+};
+
+__device__ __forceinline__ ols_seg ols_locate(long seg, const ols_geom &G)
 {
-    const int a0 = jb.s - OLS_OVERLAP + l5;
-    const int b0 = jb.s + OLS_VALID - OLS_OVERLAP + l5;
-    // the whole wave takes the unguarded path only when both of its jobs are interior
-    const bool safe = jb.live && (jb.s >= OLS_OVERLAP) && (jb.s + OLS_JOB <= n);
-    if (__all(safe)) {
-#pragma unroll
-        for (int n1 = 0; n1 < 32; n1++) {
-            v[n1].x = jb.row[a0 + 32 * n1];
-            v[n1].y = jb.row[b0 + 32 * n1];
-        }
-    } else {
-        // edge jobs (first / last of a channel). Step 1, branch-free: every address clamped into the row, samples
-        // outside [0, n) zeroed afterwards.
-#pragma unroll
-        for (int n1 = 0; n1 < 32; n1++) {
-            const int ia = a0 + 32 * n1, ib = b0 + 32 * n1;
-            const float xa = jb.row[min(max(ia, 0), n - 1)], xb = jb.row[min(max(ib, 0), n - 1)];
-            v[n1].x = (jb.live && ia >= 0 && ia < n) ? xa : 0.f;
-            v[n1].y = (jb.live && ib >= 0 && ib < n) ? xb : 0.f;
-        }
-        // Step 2: only the first job of a channel reaches back before the stream start, and only with block A's
-        // first 256 samples (registers 0..7): those come from the history row.
-        if (jb.live && jb.hrow != nullptr && jb.s < OLS_OVERLAP) {
-#pragma unroll
-            for (int n1 = 0; n1 < 8; n1++) {
-                const int ia = a0 + 32 * n1;
-                if (ia < 0 && ia >= -keep) v[n1].x = jb.hrow[keep + ia];
-            }
-        }
-    }
+    ols_seg g;
+    g.live = seg < G.total_segs;
+    g.c = g.live ? (int)(seg / G.segs_per_channel) : 0;
+    g.j0 = g.live ? (int)(seg - (long)g.c * G.segs_per_channel) * G.seg_len : 0;
+    g.count = g.live ? min(G.seg_len, G.jobs_per_channel - g.j0) : 0;
+    return g;
 }
 
-// FFT -> multiply by the filter spectrum -> IFFT, all in registers + one LDS transpose each way
-__device__ __forceinline__ void ols_filter(cf (&v)[32], cf (&u)[32], float *buf, const float2 *s_tw,
-                                           const float2 *s_h, int l5)
-{
-    // ---- forward: pass 1 over n1 (in registers), twiddle + transpose, pass 2 over n2
-    fft32<false>(v);
-    transpose_twiddle<false>(v, buf, s_tw, l5);
-    fft32<false>(v);                                        // v[r] = X[l5 + 32*brev5(r)]
-    // ---- filter in the frequency domain (spectrum already carries the 1/1024)
-#pragma unroll
-    for (int r = 0; r < 32; r++) {
-        const float2 h = s_h[l5 + 32 * brev5(r)];
-        u[brev5(r)] = cmul<false>(v[r], cf{h.x, h.y});     // back to natural k2 order: renaming only
-    }
-    // ---- inverse: pass over k2, conj twiddle + transpose, pass over k1
-    fft32<true>(u);
-    transpose_twiddle<true>(u, buf, s_tw, l5);
-    fft32<true>(u);                                         // u[r] = y[32*brev5(r) + l5]
-}
-
-#ifndef LLZ_OLS_NT
-#define LLZ_OLS_NT 1      /* streaming (non-temporal) output stores: measured +1 % */
-#endif
-#if LLZ_OLS_NT
-#define OLS_ST(p, v) __builtin_nontemporal_store((v), (p))
-#else
-#define OLS_ST(p, v) (*(p) = (v))
-#endif
-
-// keep the 768 valid samples of each block: n1 = brev5(r) >= 8
-__device__ __forceinline__ void ols_store(const cf (&u)[32], const ols_job &jb, int l5, int n)
-{
-    if (!jb.live) return;
-    const int oa = jb.s + l5 - OLS_OVERLAP;                 // + 32*n1
-    const int ob = jb.s + OLS_VALID + l5 - OLS_OVERLAP;
-    if (jb.s + OLS_JOB <= n) {
-#pragma unroll
-        for (int r = 0; r < 32; r++) {
-            const int n1 = brev5(r);
-            if (n1 >= 8) {
-                OLS_ST(&jb.orow[oa + 32 * n1], u[r].x);
-                OLS_ST(&jb.orow[ob + 32 * n1], u[r].y);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 32; r++) {
-            const int n1 = brev5(r);
-            if (n1 >= 8) {
-                if (oa + 32 * n1 < n) jb.orow[oa + 32 * n1] = u[r].x;
-                if (ob + 32 * n1 < n) jb.orow[ob + 32 * n1] = u[r].y;
-            }
-        }
-    }
-}
-
-// PREFETCH: the next pair's 64 input dwords per lane are requested before the current pair is transformed, so
-// HBM latency hides under ~2200 VALU instructions instead of under other waves only (costs 64 VGPRs: 2 waves/SIMD)
-template <bool PREFETCH>
-__global__ void __launch_bounds__(OLS_THREADS)
-k_fir_ols_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
-              const float2 *__restrict__ hfreq, const float2 *__restrict__ twid, int channels, int n,
-              long in_pitch, long out_pitch, int flt_len, int jobs_per_channel, long total_jobs)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2 *s_tw = reinterpret_cast<float2 *>(smem);           // [32][32]  W_1024^(a*b)
-    float2 *s_h = s_tw + 1024;                                  // [1024]    FFT(taps)/1024, natural bins
-    float *s_x = reinterpret_cast<float *>(s_h + 1024);         // per half-wave transpose buffers
-
-    for (int i = threadIdx.x; i < 1024; i += OLS_THREADS) {
-        s_tw[i] = twid[i];
-        s_h[i] = hfreq[i];
-    }
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int half = lane >> 5;
-    const int l5 = lane & 31;
-    float *buf = s_x + (wave * 2 + half) * OLS_XBUF;
-
-    const long waves_total = (long)gridDim.x * OLS_WAVES;
-    const long pairs = (total_jobs + 1) >> 1;
-    const int keep = flt_len - 1;
-    long pair = (long)blockIdx.x * OLS_WAVES + wave;
-    if (pair >= pairs) return;
-
-    if (PREFETCH) {
-        ols_job cur = ols_locate(pair, half, in, out, hist, in_pitch, out_pitch, keep, jobs_per_channel, total_jobs);
-        cf nxt[32];
-        ols_load(nxt, cur, l5, n, keep);
-        while (true) {
-            cf v[32], u[32];
-#pragma unroll
-            for (int r = 0; r < 32; r++) v[r] = nxt[r];
-            const long np = pair + waves_total;
-            const bool more = np < pairs;
-            ols_job nj = cur;
-            if (more) {
-                nj = ols_locate(np, half, in, out, hist, in_pitch, out_pitch, keep, jobs_per_channel, total_jobs);
-                ols_load(nxt, nj, l5, n, keep);
-            }
-#if LLZ_DIAG == 1    /* memory only: loads feed the stores directly (wrong results; timing build) */
-#pragma unroll
-            for (int r = 0; r < 32; r++) u[r] = v[brev5(r)];
-#else
-            ols_filter(v, u, buf, s_tw, s_h, l5);
-#endif
-            ols_store(u, cur, l5, n);
-            if (!more) break;
-            cur = nj;
-            pair = np;
-        }
-    } else {
-        cf v[32], u[32];
-#if LLZ_DIAG == 2
-#pragma unroll
-        for (int r = 0; r < 32; r++) u[r] = cf{0.f, 0.f};
-#endif
-        for (; pair < pairs; pair += waves_total) {
-            const ols_job jb = ols_locate(pair, half, in, out, hist, in_pitch, out_pitch, keep, jobs_per_channel,
-                                          total_jobs);
-#if LLZ_DIAG == 2    /* compute only: one load per wave, stores suppressed unless a value is NaN (timing build) */
-            if (pair == (long)blockIdx.x * OLS_WAVES + wave) ols_load(v, jb, l5, n, keep);
-            else {
-#pragma unroll
-                for (int r = 0; r < 32; r++) { v[r].x = u[r].x; v[r].y = u[r].y; }
-            }
-            ols_filter(v, u, buf, s_tw, s_h, l5);
-            if (u[0].x != u[0].x) ols_store(u, jb, l5, n);
-#elif LLZ_DIAG == 1
-            ols_load(v, jb, l5, n, keep);
-#pragma unroll
-            for (int r = 0; r < 32; r++) u[r] = v[brev5(r)];
-            ols_store(u, jb, l5, n);
-#else
-            ols_load(v, jb, l5, n, keep);
-            ols_filter(v, u, buf, s_tw, s_h, l5);
-            ols_store(u, jb, l5, n);
-#endif
-        }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// "walk" form: a half-wave owns a SEGMENT of consecutive jobs of one channel and carries the 256-sample overlap in
-// registers from job to job, so every input sample is requested from memory exactly once:
-//   * block A's first 256 samples (registers 0..7, real part) are the previous job's last 256 (kept in 8 VGPRs),
-//   * block B's first 256 samples (registers 0..7, imaginary part) are block A's last 256 (registers 24..31),
-// which leaves 48 instead of 64 loads per lane and job and removes the halo re-read from L2/HBM altogether.
-// Segments are dealt round-robin to half-waves; both halves of a wave run the same number of jobs (a segment that
-// is short at the end of a channel idles its tail).
-#ifndef LLZ_OLS_SEG
-#define LLZ_OLS_SEG 16
-#endif
-constexpr int OLS_SEG = LLZ_OLS_SEG;                        // jobs per segment (16 x 1536 samples of one channel)
-
-struct ols_raw {                                            // the 1536 new samples of one job, 48 per lane
+// the 1536 new samples of a job pair as they arrive: 48 registers per lane.  direct = false: wide layout (a[4m + c]:
+// c = 0, 1 columns 2q, 2q+1 of row 4m+i of the lower job's block A, c = 2, 3 the same of the upper job; b: block B),
+// to be transposed; direct = true: a[r] / b[r] = row r of this lane's own job and column already
+struct ols_raw {
     float a[24], b[24];
 };
 
-#ifndef LLZ_OLS_NTLOAD
-#define LLZ_OLS_NTLOAD 1   /* streaming (non-temporal) input loads: measured +0.8 % (6.69 -> 6.635 ms) */
-#endif
-#if LLZ_OLS_NTLOAD
-#define OLS_LD(p) __builtin_nontemporal_load(p)
-#else
-#define OLS_LD(p) (*(p))
-#endif
-__device__ __forceinline__ void walk_load(ols_raw &raw, const float *row, int s, int l5, int n, bool live)
+// 4 x 4 transpose between the lane's quarter (lane bits 4, 5) and four registers:
+// new (quarter i, register c) = old (quarter c, register i)
+__device__ __forceinline__ void quarter_transpose(float &r0, float &r1, float &r2, float &r3)
 {
-    // sample index of a[i]: s + 32*i + l5 ; of b[i]: s + 768 + 32*i + l5
-    const bool safe = live && (s + OLS_JOB <= n);
-    if (__all(safe)) {
+    auto sw16 = [](float &x, float &y) {
+        const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+        x = __uint_as_float(p[0]);
+        y = __uint_as_float(p[1]);
+    };
+    auto sw32 = [](float &x, float &y) {
+        const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+        x = __uint_as_float(p[0]);
+        y = __uint_as_float(p[1]);
+    };
+    sw16(r0, r1); sw16(r2, r3);            // lane bit 4 <-> register bit 0
+    sw32(r0, r2); sw32(r1, r3);            // lane bit 5 <-> register bit 1
+}
+
+// request the 1536 new samples of the wave's two jobs (job h: row[h] + s[h], h = 0 lower / 1 upper half-wave).
+// Returns `direct` (wave-uniform): whether the registers already are in the transform layout.
+template <int IO>
+__device__ __forceinline__ bool ols_load(ols_raw &raw, const float *const (&row)[2], const int (&s)[2],
+                                         const bool (&live)[2], const ols_lane &g, int n)
+{
+    const bool whole = live[0] && live[1] && s[0] + OLS_JOB <= n && s[1] + OLS_JOB <= n;   // wave-uniform
+    if (IO == IO_WIDE && whole) {
+        const float *p0 = row[0] + s[0] + 32 * g.i + 2 * g.q;
+        const float *p1 = row[1] + s[1] + 32 * g.i + 2 * g.q;
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+            const f32x2 xa = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(p0 + 128 * m));
+            const f32x2 ya = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(p1 + 128 * m));
+            const f32x2 xb = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(p0 + OLS_VALID + 128 * m));
+            const f32x2 yb = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(p1 + OLS_VALID + 128 * m));
+            raw.a[4 * m] = xa.x; raw.a[4 * m + 1] = xa.y; raw.a[4 * m + 2] = ya.x; raw.a[4 * m + 3] = ya.y;
+            raw.b[4 * m] = xb.x; raw.b[4 * m + 1] = xb.y; raw.b[4 * m + 2] = yb.x; raw.b[4 * m + 3] = yb.y;
+        }
+        return false;
+    }
+    // this lane's own job and column, one dword per lane
+    const float *r = g.half ? row[1] : row[0];
+    const int so = g.half ? s[1] : s[0];
+    const bool lv = g.half ? live[1] : live[0];
+    if (whole) {
 #pragma unroll
         for (int i = 0; i < 24; i++) {
-            raw.a[i] = OLS_LD(&row[s + 32 * i + l5]);
-            raw.b[i] = OLS_LD(&row[s + OLS_VALID + 32 * i + l5]);
+            raw.a[i] = __builtin_nontemporal_load(&r[so + 32 * i + g.col]);
+            raw.b[i] = __builtin_nontemporal_load(&r[so + OLS_VALID + 32 * i + g.col]);
         }
     } else {
-        // (also taken by the prefetch past the end of a segment: those loads are issued and discarded on purpose --
-        // skipping them with a wave-uniform branch measured 8 % SLOWER, 7.4 vs 6.8 ms; they cost 1/16 extra reads)
+        // ragged last job of a row, or an idle half: addresses clamped into the row, samples outside [0, n) are zero
 #pragma unroll
         for (int i = 0; i < 24; i++) {
-            const int ia = s + 32 * i + l5, ib = ia + OLS_VALID;
-            const float xa = row[min(ia, n - 1)], xb = row[min(ib, n - 1)];
-            raw.a[i] = (live && ia < n) ? xa : 0.f;
-            raw.b[i] = (live && ib < n) ? xb : 0.f;
+            const int ia = so + 32 * i + g.col, ib = ia + OLS_VALID;
+            const float xa = r[min(ia, n - 1)], xb = r[min(ib, n - 1)];
+            raw.a[i] = (lv && ia < n) ? xa : 0.f;
+            raw.b[i] = (lv && ib < n) ? xb : 0.f;
+        }
+    }
+    return true;
+}
+
+__device__ __forceinline__ void ols_raw_to_rows(ols_raw &raw, bool direct)
+{
+    if (!direct) {
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+            quarter_transpose(raw.a[4 * m], raw.a[4 * m + 1], raw.a[4 * m + 2], raw.a[4 * m + 3]);
+            quarter_transpose(raw.b[4 * m], raw.b[4 * m + 1], raw.b[4 * m + 2], raw.b[4 * m + 3]);
         }
     }
 }
 
-// the 256 samples in front of a segment: from the row (s > 0) or from the history / zeros (s == 0)
-__device__ __forceinline__ void walk_load_halo(float (&halo)[8], const float *row, const float *hrow, int s, int l5,
-                                               int keep, bool live)
+// the 256 samples in front of a segment, rows 0..7 of this lane's column: from the row (s > 0) or from the history
+// (the previous call's last flt_len-1 samples) / zeros (s == 0)
+__device__ __forceinline__ void ols_load_halo(float (&halo)[8], const float *row, const float *hrow, int s, int col,
+                                              int keep, bool live)
 {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const int idx = s - OLS_OVERLAP + 32 * i + l5;
+        const int idx = s - OLS_OVERLAP + 32 * i + col;
         float v = 0.f;
         if (live) {
             if (idx >= 0) v = row[idx];
@@ -311,172 +188,233 @@ __device__ __forceinline__ void walk_load_halo(float (&halo)[8], const float *ro
     }
 }
 
-template <bool PREFETCH>
-__global__ void __launch_bounds__(OLS_THREADS)
-k_fir_ols_walk_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
-                   const float2 *__restrict__ hfreq, const float2 *__restrict__ twid, int channels, int n,
-                   long in_pitch, long out_pitch, int flt_len, int jobs_per_channel, int segs_per_channel,
-                   long total_segs, int seg_len)
+// FFT -> multiply by the filter spectrum -> IFFT, all in registers + one LDS transpose each way.  `col` is the lane's
+// column n2 of the input / output decomposition n = 32 n1 + n2; between the transposes lane l5 owns bin row k1 = l5.
+__device__ __forceinline__ void ols_filter(cf (&v)[32], cf (&u)[32], float *buf, const float2 *s_tw,
+                                           const float2 *s_h, int l5, int col)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2 *s_tw = reinterpret_cast<float2 *>(smem);
-    float2 *s_h = s_tw + 1024;
-    float *s_x = reinterpret_cast<float *>(s_h + 1024);
-    for (int i = threadIdx.x; i < 1024; i += OLS_THREADS) {
-        s_tw[i] = twid[i];
-        s_h[i] = hfreq[i];
+    // ---- forward: pass 1 over n1 (in registers), twiddle W^(k1 n2) + transpose, pass 2 over n2
+    fft32<false>(v);
+    transpose_twiddle<false>(v, buf, s_tw, col, l5);
+    fft32<false>(v);                                        // v[r] = X[l5 + 32*brev5(r)]
+    // ---- filter in the frequency domain (spectrum already carries the 1/1024)
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+        const float2 h = s_h[l5 + 32 * brev5(r)];
+        u[brev5(r)] = cmul<false>(v[r], cf{h.x, h.y});     // back to natural k2 order: renaming only
     }
-    __syncthreads();
+    // ---- inverse: pass over k2, conj twiddle + transpose, pass over k1
+    fft32<true>(u);
+    transpose_twiddle<true>(u, buf, s_tw, l5, col);
+    fft32<true>(u);                                         // u[r] = y[32*brev5(r) + col]
+}
 
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int half = lane >> 5;
-    const int l5 = lane & 31;
-    float *buf = s_x + (wave * 2 + half) * OLS_XBUF;
-    const int keep = flt_len - 1;
-    const long halves_total = (long)gridDim.x * OLS_WAVES * 2;
-    const long first = ((long)blockIdx.x * OLS_WAVES + wave) * 2;          // this wave's first segment pair
-
-    for (long sp = first; sp < total_segs; sp += halves_total) {
-        const long seg = sp + half;
-        const bool seg_live = seg < total_segs;
-        const int c = seg_live ? (int)(seg / segs_per_channel) : 0;
-        const int j0 = seg_live ? (int)(seg - (long)c * segs_per_channel) * seg_len : 0;
-        const int jcount = seg_live ? min(seg_len, jobs_per_channel - j0) : 0;
-        const float *row = in + (size_t)c * in_pitch;
-        float *orow = out + (size_t)c * out_pitch;
-        const float *hrow = hist ? hist + (size_t)c * keep : nullptr;
-
-        float halo[8];
-        walk_load_halo(halo, row, hrow, j0 * OLS_JOB, l5, keep, seg_live);
-        ols_raw raw;
-        if (PREFETCH) walk_load(raw, row, j0 * OLS_JOB, l5, n, jcount > 0);
-
-#pragma unroll 1
-        for (int jj = 0; jj < seg_len; jj++) {
-            const int s = (j0 + jj) * OLS_JOB;
-            const bool live = jj < jcount;
-            if (!__any(live)) break;
-            if (!PREFETCH) walk_load(raw, row, s, l5, n, live);
-            cf v[32], u[32];
+// keep the 768 valid samples of each block: rows n1 = brev5(r) >= 8
+template <int IO>
+__device__ __forceinline__ void ols_store(const cf (&u)[32], float *const (&orow)[2], const int (&s)[2],
+                                          const bool (&live)[2], const ols_lane &g, int n)
+{
+    const bool whole = live[0] && live[1] && s[0] + OLS_JOB <= n && s[1] + OLS_JOB <= n;   // wave-uniform
+    if (IO == IO_WIDE && whole) {
+        float *p0 = orow[0] + s[0] - OLS_OVERLAP + 32 * g.i + 2 * g.q;
+        float *p1 = orow[1] + s[1] - OLS_OVERLAP + 32 * g.i + 2 * g.q;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                v[i].x = halo[i];                         // block A [0,256)   = carried overlap
-                v[i].y = raw.a[16 + i];                   // block B [0,256)   = block A [768,1024)
-                halo[i] = raw.b[16 + i];                  // next overlap      = block B [768,1024)
+        for (int m = 2; m < 8; m++) {
+            float a0 = u[brev5(4 * m)].x, a1 = u[brev5(4 * m + 1)].x, a2 = u[brev5(4 * m + 2)].x, a3 = u[brev5(4 * m + 3)].x;
+            float b0 = u[brev5(4 * m)].y, b1 = u[brev5(4 * m + 1)].y, b2 = u[brev5(4 * m + 2)].y, b3 = u[brev5(4 * m + 3)].y;
+            quarter_transpose(a0, a1, a2, a3);
+            quarter_transpose(b0, b1, b2, b3);
+            f32x2 t;
+            t.x = a0; t.y = a1; __builtin_nontemporal_store(t, reinterpret_cast<f32x2 *>(p0 + 128 * m));
+            t.x = a2; t.y = a3; __builtin_nontemporal_store(t, reinterpret_cast<f32x2 *>(p1 + 128 * m));
+            t.x = b0; t.y = b1; __builtin_nontemporal_store(t, reinterpret_cast<f32x2 *>(p0 + OLS_VALID + 128 * m));
+            t.x = b2; t.y = b3; __builtin_nontemporal_store(t, reinterpret_cast<f32x2 *>(p1 + OLS_VALID + 128 * m));
+        }
+        return;
+    }
+    const bool lv = g.half ? live[1] : live[0];
+    if (!lv) return;
+    float *o = g.half ? orow[1] : orow[0];
+    const int so = g.half ? s[1] : s[0];
+    const int oa = so + g.col - OLS_OVERLAP;                // + 32*n1
+    const int ob = oa + OLS_VALID;
+    if (whole) {
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            const int n1 = brev5(r);
+            if (n1 >= 8) {
+                __builtin_nontemporal_store(u[r].x, &o[oa + 32 * n1]);
+                __builtin_nontemporal_store(u[r].y, &o[ob + 32 * n1]);
             }
+        }
+    } else {
 #pragma unroll
-            for (int i = 0; i < 24; i++) {
-                v[8 + i].x = raw.a[i];
-                v[8 + i].y = raw.b[i];
+        for (int r = 0; r < 32; r++) {
+            const int n1 = brev5(r);
+            if (n1 >= 8) {
+                if (oa + 32 * n1 < n) o[oa + 32 * n1] = u[r].x;
+                if (ob + 32 * n1 < n) o[ob + 32 * n1] = u[r].y;
             }
-            if (PREFETCH) walk_load(raw, row, s + OLS_JOB, l5, n, (jj + 1) < jcount);
-#if LLZ_DIAG == 1    /* memory only: the loaded samples go straight to the stores (wrong results; timing build) */
-#pragma unroll
-            for (int r = 0; r < 32; r++) u[r] = v[brev5(r)];
-#elif LLZ_DIAG == 2  /* compute only: transform the first job's data over and over, no further loads */
-            ols_filter(v, u, buf, s_tw, s_h, l5);
-#else
-            ols_filter(v, u, buf, s_tw, s_h, l5);
-#endif
-            ols_job jb;
-            jb.row = row; jb.orow = orow; jb.hrow = hrow; jb.s = s; jb.live = live;
-            ols_store(u, jb, l5, n);
         }
     }
 }
 
-
-// Chain form: the walk form with the prefetch carried ACROSS segments.  In the walk form the prefetch issued during a
-// segment's last job runs past the segment's end and is discarded (1/16 of the input fetched twice), and every segment
-// starts with an exposed load of its halo and first job.  Here the last job of a segment prefetches the first job and
-// the halo of the half-wave's NEXT segment instead, so every load is used and no segment start waits on memory.
-__global__ void __launch_bounds__(OLS_THREADS)
-k_fir_ols_chain_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
-                    const float2 *__restrict__ hfreq, const float2 *__restrict__ twid, int channels, int n,
-                    long in_pitch, long out_pitch, int flt_len, int jobs_per_channel, int segs_per_channel,
-                    long total_segs, int seg_len)
+// blocks A and B of a job from the carried overlap and the job's new samples; the new overlap is block B's last 256
+__device__ __forceinline__ void ols_assemble(cf (&v)[32], float (&halo)[8], const ols_raw &raw)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2 *s_tw = reinterpret_cast<float2 *>(smem);
-    float2 *s_h = s_tw + 1024;
-    float *s_x = reinterpret_cast<float *>(s_h + 1024);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        v[i].x = halo[i];                         // block A [0,256)   = carried overlap
+        v[i].y = raw.a[16 + i];                   // block B [0,256)   = block A [768,1024)
+        halo[i] = raw.b[16 + i];                  // next overlap      = block B [768,1024)
+    }
+#pragma unroll
+    for (int i = 0; i < 24; i++) {
+        v[8 + i].x = raw.a[i];
+        v[8 + i].y = raw.b[i];
+    }
+}
+
+struct ols_smem {
+    float2 *tw, *h;
+    float *buf;
+};
+
+__device__ __forceinline__ ols_smem ols_tables(char *smem, const float2 *__restrict__ hfreq, const float2 *__restrict__ twid)
+{
+    ols_smem m;
+    m.tw = reinterpret_cast<float2 *>(smem);                 // [32][32]  W_1024^(a*b)
+    m.h = m.tw + 1024;                                        // [1024]    FFT(taps)/1024, natural bins
     for (int i = threadIdx.x; i < 1024; i += OLS_THREADS) {
-        s_tw[i] = twid[i];
-        s_h[i] = hfreq[i];
+        m.tw[i] = twid[i];
+        m.h[i] = hfreq[i];
     }
     __syncthreads();
+    const int wave = threadIdx.x >> 6, half = (threadIdx.x >> 5) & 1;
+    m.buf = reinterpret_cast<float *>(m.h + 1024) + (wave * 2 + half) * OLS_XBUF;     // per half-wave transpose buffer
+    return m;
+}
 
+// Walk form: a half-wave runs one segment after the other (grid stride); inside a segment the next job is requested one job
+// ahead.  The request issued during a segment's last job runs past the segment's end and is discarded on purpose (skipping
+// it with a wave-uniform branch measured 8 % slower); the chain form below turns it into the next segment's first job.
+template <int IO>
+__global__ void __launch_bounds__(OLS_THREADS, 2)
+k_fir_ols_walk_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
+                   const float2 *__restrict__ hfreq, const float2 *__restrict__ twid, ols_geom G)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ols_smem S = ols_tables(smem, hfreq, twid);
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l5 = lane & 31;
-    float *buf = s_x + (wave * 2 + half) * OLS_XBUF;
-    const int keep = flt_len - 1;
+    const ols_lane g = ols_lane_of<IO>(lane);
+    const long halves_total = (long)gridDim.x * OLS_WAVES * 2;
+    const long first = ((long)blockIdx.x * OLS_WAVES + wave) * 2;          // this wave's first segment pair
+
+    for (long sp = first; sp < G.total_segs; sp += halves_total) {
+        const ols_seg sg[2] = {ols_locate(sp, G), ols_locate(sp + 1, G)};
+        const float *const row[2] = {in + (size_t)sg[0].c * G.in_pitch, in + (size_t)sg[1].c * G.in_pitch};
+        float *const orow[2] = {out + (size_t)sg[0].c * G.out_pitch, out + (size_t)sg[1].c * G.out_pitch};
+        const ols_seg own = g.half ? sg[1] : sg[0];
+        const float *orow_in = g.half ? row[1] : row[0];
+
+        float halo[8];
+        ols_load_halo(halo, orow_in, hist ? hist + (size_t)own.c * G.keep : nullptr, own.j0 * OLS_JOB, g.col, G.keep,
+                      own.live);
+        ols_raw raw;
+        bool direct;
+        {
+            const int s0[2] = {sg[0].j0 * OLS_JOB, sg[1].j0 * OLS_JOB};
+            const bool lv[2] = {sg[0].count > 0, sg[1].count > 0};
+            direct = ols_load<IO>(raw, row, s0, lv, g, G.n);
+        }
+        const int jmax = max(sg[0].count, sg[1].count);
+#pragma unroll 1
+        for (int jj = 0; jj < jmax; jj++) {
+            const int s[2] = {(sg[0].j0 + jj) * OLS_JOB, (sg[1].j0 + jj) * OLS_JOB};
+            const bool live[2] = {jj < sg[0].count, jj < sg[1].count};
+            cf v[32], u[32];
+            ols_raw_to_rows(raw, direct);
+            ols_assemble(v, halo, raw);
+            {
+                const int sn[2] = {s[0] + OLS_JOB, s[1] + OLS_JOB};
+                const bool ln[2] = {jj + 1 < sg[0].count, jj + 1 < sg[1].count};
+                direct = ols_load<IO>(raw, row, sn, ln, g, G.n);
+            }
+            ols_filter(v, u, S.buf, S.tw, S.h, l5, g.col);
+            ols_store<IO>(u, orow, s, live, g, G.n);
+        }
+    }
+}
+
+// Chain form: the walk form with the prefetch carried ACROSS segments.  The last job of a segment requests the first job and
+// the halo of the half-wave's NEXT segment, so every load is used and no segment start waits on memory.  Both halves of
+// a wave step through their segments together (a segment that is short at the end of a channel idles its tail).
+template <int IO>
+__global__ void __launch_bounds__(OLS_THREADS, 2)
+k_fir_ols_chain_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
+                    const float2 *__restrict__ hfreq, const float2 *__restrict__ twid, ols_geom G)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ols_smem S = ols_tables(smem, hfreq, twid);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l5 = lane & 31;
+    const ols_lane g = ols_lane_of<IO>(lane);
     const long halves_total = (long)gridDim.x * OLS_WAVES * 2;
     const long first = ((long)blockIdx.x * OLS_WAVES + wave) * 2;
 
-    struct seginfo {
-        bool live;
-        int c, j0, jcount;
-    };
-    auto locate = [&](long seg) {
-        seginfo g;
-        g.live = seg < total_segs;
-        g.c = g.live ? (int)(seg / segs_per_channel) : 0;
-        g.j0 = g.live ? (int)(seg - (long)g.c * segs_per_channel) * seg_len : 0;
-        g.jcount = g.live ? min(seg_len, jobs_per_channel - g.j0) : 0;
-        return g;
-    };
-
-    seginfo cur = locate(first + half);
+    ols_seg cur[2] = {ols_locate(first, G), ols_locate(first + 1, G)};
     float halo[8];
     ols_raw raw;
+    bool direct;
     {
-        const float *row = in + (size_t)cur.c * in_pitch;
-        walk_load_halo(halo, row, hist ? hist + (size_t)cur.c * keep : nullptr, cur.j0 * OLS_JOB, l5, keep, cur.live);
-        walk_load(raw, row, cur.j0 * OLS_JOB, l5, n, cur.jcount > 0);
+        const float *const row[2] = {in + (size_t)cur[0].c * G.in_pitch, in + (size_t)cur[1].c * G.in_pitch};
+        const ols_seg own = g.half ? cur[1] : cur[0];
+        ols_load_halo(halo, g.half ? row[1] : row[0], hist ? hist + (size_t)own.c * G.keep : nullptr, own.j0 * OLS_JOB,
+                      g.col, G.keep, own.live);
+        const int s0[2] = {cur[0].j0 * OLS_JOB, cur[1].j0 * OLS_JOB};
+        const bool lv[2] = {cur[0].count > 0, cur[1].count > 0};
+        direct = ols_load<IO>(raw, row, s0, lv, g, G.n);
     }
-    for (long sp = first; sp < total_segs; sp += halves_total) {
-        const seginfo nxt = locate(sp + halves_total + half);
-        const float *row = in + (size_t)cur.c * in_pitch;
-        float *orow = out + (size_t)cur.c * out_pitch;
-        const float *hrow = hist ? hist + (size_t)cur.c * keep : nullptr;
-        const float *nrow = in + (size_t)nxt.c * in_pitch;
-        const float *nhrow = hist ? hist + (size_t)nxt.c * keep : nullptr;
+    for (long sp = first; sp < G.total_segs; sp += halves_total) {
+        const ols_seg nxt[2] = {ols_locate(sp + halves_total, G), ols_locate(sp + halves_total + 1, G)};
+        const float *const row[2] = {in + (size_t)cur[0].c * G.in_pitch, in + (size_t)cur[1].c * G.in_pitch};
+        float *const orow[2] = {out + (size_t)cur[0].c * G.out_pitch, out + (size_t)cur[1].c * G.out_pitch};
+        const float *const nrow[2] = {in + (size_t)nxt[0].c * G.in_pitch, in + (size_t)nxt[1].c * G.in_pitch};
+        const ols_seg nown = g.half ? nxt[1] : nxt[0];
         float halo_n[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) halo_n[i] = 0.f;
 
+        const int jmax = max(cur[0].count, cur[1].count);
 #pragma unroll 1
-        for (int jj = 0; jj < seg_len; jj++) {
-            const int s = (cur.j0 + jj) * OLS_JOB;
-            const bool live = jj < cur.jcount;
-            if (!__any(live)) break;
+        for (int jj = 0; jj < jmax; jj++) {
+            const int s[2] = {(cur[0].j0 + jj) * OLS_JOB, (cur[1].j0 + jj) * OLS_JOB};
+            const bool live[2] = {jj < cur[0].count, jj < cur[1].count};
             cf v[32], u[32];
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                v[i].x = halo[i];
-                v[i].y = raw.a[16 + i];
-                halo[i] = raw.b[16 + i];
+            ols_raw_to_rows(raw, direct);
+            ols_assemble(v, halo, raw);
+            // next job of this segment pair, or (after the pair's last job) the first jobs and halos of the next pair.  A
+            // half whose own segment has ended while its partner's has not requests nothing.
+            const bool in_pair = jj + 1 < jmax;                                  // wave-uniform
+            {
+                const float *const lrow[2] = {in_pair ? row[0] : nrow[0], in_pair ? row[1] : nrow[1]};
+                const int sn[2] = {in_pair ? s[0] + OLS_JOB : nxt[0].j0 * OLS_JOB,
+                                   in_pair ? s[1] + OLS_JOB : nxt[1].j0 * OLS_JOB};
+                const bool ln[2] = {in_pair ? jj + 1 < cur[0].count : nxt[0].count > 0,
+                                    in_pair ? jj + 1 < cur[1].count : nxt[1].count > 0};
+                direct = ols_load<IO>(raw, lrow, sn, ln, g, G.n);
             }
-#pragma unroll
-            for (int i = 0; i < 24; i++) {
-                v[8 + i].x = raw.a[i];
-                v[8 + i].y = raw.b[i];
-            }
-            // next job of this segment, or (from the segment's last job on) the first job and halo of the next segment
-            const bool in_seg = (jj + 1) < cur.jcount;
-            walk_load(raw, in_seg ? row : nrow, in_seg ? s + OLS_JOB : nxt.j0 * OLS_JOB, l5, n,
-                      in_seg ? true : nxt.jcount > 0);
-            if (__any(!in_seg))
-                walk_load_halo(halo_n, nrow, nhrow, nxt.j0 * OLS_JOB, l5, keep, !in_seg && nxt.live);
-            ols_filter(v, u, buf, s_tw, s_h, l5);
-            ols_job jb;
-            jb.row = row; jb.orow = orow; jb.hrow = hrow; jb.s = s; jb.live = live;
-            ols_store(u, jb, l5, n);
+            if (!in_pair)
+                ols_load_halo(halo_n, g.half ? nrow[1] : nrow[0], hist ? hist + (size_t)nown.c * G.keep : nullptr,
+                              nown.j0 * OLS_JOB, g.col, G.keep, nown.live);
+            ols_filter(v, u, S.buf, S.tw, S.h, l5, g.col);
+            ols_store<IO>(u, orow, s, live, g, G.n);
         }
-        cur = nxt;
+        cur[0] = nxt[0];
+        cur[1] = nxt[1];
 #pragma unroll
         for (int i = 0; i < 8; i++) halo[i] = halo_n[i];
     }
@@ -496,73 +434,54 @@ extern "C" int llzs_fir_ols_f32(const float *in, float *out, const float *hist, 
         llzs_set_error("fir_ols_f32: flt_len %d outside 1..%d", flt_len, LLZS_OLS_MAX_TAPS);
         return LLZ_ERR_RANGE;
     }
-    const int jobs_per_channel = (n + OLS_JOB - 1) / OLS_JOB;
-    const long total_jobs = (long)jobs_per_channel * channels;
-    const long pairs = (total_jobs + 1) / 2;
+    ols_geom G;
+    G.n = n;
+    G.keep = flt_len - 1;
+    G.in_pitch = in_pitch;
+    G.out_pitch = out_pitch;
+    G.jobs_per_channel = (n + OLS_JOB - 1) / OLS_JOB;
     const size_t lds_bytes = 2 * 1024 * sizeof(float2) + (size_t)OLS_WAVES * 2 * OLS_XBUF * sizeof(float);
-    long blocks = (pairs + OLS_WAVES - 1) / OLS_WAVES;
-    // tuning knobs (measurement only): LLZ_OLS_VARIANT bit 0 = register prefetch, bit 1 = walk form, bit 2 / bit 3 = force /
-    // forbid the chain form;
-    // LLZ_OLS_WG_PER_CU = resident workgroups per CU the grid is sized for
-    static int variant = -1, wg_per_cu = -1;
-    if (variant < 0) {
-        const char *e = getenv("LLZ_OLS_VARIANT");
-        variant = e ? atoi(e) : 3;              /* default: walk form + register prefetch (fastest measured) */
-        e = getenv("LLZ_OLS_WG_PER_CU");
-        wg_per_cu = e ? atoi(e) : 0;
-    }
-    const bool prefetch = (variant & 1) != 0;
-    const int per_cu = wg_per_cu > 0 ? wg_per_cu : (prefetch ? 2 : 3);
-    const long max_blocks = 256L * per_cu;       // one resident set of workgroups, grid stride over the work list
-    const float2 *hf = reinterpret_cast<const float2 *>(hfreq), *tw = reinterpret_cast<const float2 *>(twid);
-    if (variant >= 2) {
-        // chain form (prefetch carried across segments) when a half-wave walks several segments; on a batch that fits one
-        // round the walk form is faster (64 ch x 63 taps: 0.14 vs 0.16 ms).  LLZ_OLS_VARIANT bit 2 forces it, bit 3 forbids
-        const bool large = (long)((jobs_per_channel + OLS_SEG - 1) / OLS_SEG) * channels >= 4 * max_blocks * OLS_WAVES * 2;
-        const bool chain = prefetch && ((variant & 4) != 0 || (large && (variant & 8) == 0));
-        // jobs per segment: a half-wave walks seg_len consecutive jobs of one channel (the overlap stays in registers), at
-        // most OLS_SEG.  Small batches (BASELINE config 2: 64 channels) would leave half-wave slots idle or quantise badly
-        // into rounds with the full length, so take the length that minimises rounds x (length + halo reload)
-        const long slots = max_blocks * OLS_WAVES * 2;
-        int seg_len = OLS_SEG;
-        if ((long)((jobs_per_channel + OLS_SEG - 1) / OLS_SEG) * channels < 4 * slots) {
-            // (large batches keep the full length: on 4096 channels a shorter segment measured 2.6 % slower, the start of
-            // a segment costs about one job: halo reload and an empty prefetch pipeline)
-            double best = 1e300;
-            for (int sl = OLS_SEG; sl >= 1; sl--) {
-                const long segs = (long)((jobs_per_channel + sl - 1) / sl) * channels;
-                const double cost = (double)((segs + slots - 1) / slots) * (sl + 1.0);
-                if (cost < best * 0.999) { best = cost; seg_len = sl; }
-            }
+    // one resident set of workgroups (two per CU: 49 KB of LDS and ~240 registers per lane), grid stride over the segments
+    const int tuned_per_cu = llzs_tune(LLZS_TUNE_OLS_WG_PER_CU);
+    const long max_blocks = 256L * (tuned_per_cu > 0 ? tuned_per_cu : 2);
+    const long slots = max_blocks * OLS_WAVES * 2;
+    // jobs per segment: a half-wave walks seg_len consecutive jobs of one channel (the overlap stays in registers), at most
+    // OLS_SEG.  Small batches (BASELINE config 2: 64 channels) would leave half-wave slots idle or quantise badly into
+    // rounds with the full length, so they take the length that minimises rounds x (length + one job of start-up).  Large
+    // batches keep the full length: on 4096 channels a shorter segment measured 2.6 % slower.
+    const bool large = (long)((G.jobs_per_channel + OLS_SEG - 1) / OLS_SEG) * channels >= 4 * slots;
+    int seg_len = OLS_SEG;
+    if (!large) {
+        double best = 1e300;
+        for (int sl = OLS_SEG; sl >= 1; sl--) {
+            const long segs = (long)((G.jobs_per_channel + sl - 1) / sl) * channels;
+            const double cost = (double)((segs + slots - 1) / slots) * (sl + 1.0);
+            if (cost < best * 0.999) { best = cost; seg_len = sl; }
         }
-        const int segs_per_channel = (jobs_per_channel + seg_len - 1) / seg_len;
-        const long total_segs = (long)segs_per_channel * channels;
-        blocks = (total_segs + 2 * OLS_WAVES - 1) / (2 * OLS_WAVES);
-        if (blocks > max_blocks) blocks = max_blocks;
-        if (chain)
-            hipLaunchKernelGGL(k_fir_ols_chain_f32, dim3((unsigned)blocks), dim3(OLS_THREADS), lds_bytes,
-                               as_stream(stream), in, out, hist, hf, tw, channels, n, in_pitch, out_pitch, flt_len,
-                               jobs_per_channel, segs_per_channel, total_segs, seg_len);
-        else if (prefetch)
-            hipLaunchKernelGGL(k_fir_ols_walk_f32<true>, dim3((unsigned)blocks), dim3(OLS_THREADS), lds_bytes,
-                               as_stream(stream), in, out, hist, hf, tw, channels, n, in_pitch, out_pitch, flt_len,
-                               jobs_per_channel, segs_per_channel, total_segs, seg_len);
-        else
-            hipLaunchKernelGGL(k_fir_ols_walk_f32<false>, dim3((unsigned)blocks), dim3(OLS_THREADS), lds_bytes,
-                               as_stream(stream), in, out, hist, hf, tw, channels, n, in_pitch, out_pitch, flt_len,
-                               jobs_per_channel, segs_per_channel, total_segs, seg_len);
-        LLZ_LAUNCH_CHECK("k_fir_ols_walk_f32");
-        return LLZ_OK;
     }
+    G.seg_len = seg_len;
+    G.segs_per_channel = (G.jobs_per_channel + seg_len - 1) / seg_len;
+    G.total_segs = (long)G.segs_per_channel * channels;
+    long blocks = (G.total_segs + 2 * OLS_WAVES - 1) / (2 * OLS_WAVES);
     if (blocks > max_blocks) blocks = max_blocks;
-    if (prefetch)
-        hipLaunchKernelGGL(k_fir_ols_f32<true>, dim3((unsigned)blocks), dim3(OLS_THREADS), lds_bytes,
-                           as_stream(stream), in, out, hist, hf, tw, channels, n, in_pitch, out_pitch, flt_len,
-                           jobs_per_channel, total_jobs);
+    // chain form when a half-wave walks several segments; on a batch that fits one round the walk form is faster (64 ch x
+    // 63 taps: 0.14 vs 0.16 ms)
+    const int tuned_chain = llzs_tune(LLZS_TUNE_OLS_CHAIN);
+    const bool chain = tuned_chain >= 0 ? tuned_chain == 1 : large;
+    // 8-byte accesses need 8-byte aligned rows
+    const bool even = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 7) == 0 &&
+                      ((in_pitch | out_pitch) & 1) == 0;
+    const bool wide = even && llzs_tune(LLZS_TUNE_OLS_IO) != IO_DWORD;
+    const float2 *hf = reinterpret_cast<const float2 *>(hfreq), *tw = reinterpret_cast<const float2 *>(twid);
+    const dim3 grid((unsigned)blocks), block(OLS_THREADS);
+    if (chain && wide)
+        hipLaunchKernelGGL(k_fir_ols_chain_f32<IO_WIDE>, grid, block, lds_bytes, as_stream(stream), in, out, hist, hf, tw, G);
+    else if (chain)
+        hipLaunchKernelGGL(k_fir_ols_chain_f32<IO_DWORD>, grid, block, lds_bytes, as_stream(stream), in, out, hist, hf, tw, G);
+    else if (wide)
+        hipLaunchKernelGGL(k_fir_ols_walk_f32<IO_WIDE>, grid, block, lds_bytes, as_stream(stream), in, out, hist, hf, tw, G);
     else
-        hipLaunchKernelGGL(k_fir_ols_f32<false>, dim3((unsigned)blocks), dim3(OLS_THREADS), lds_bytes,
-                           as_stream(stream), in, out, hist, hf, tw, channels, n, in_pitch, out_pitch, flt_len,
-                           jobs_per_channel, total_jobs);
+        hipLaunchKernelGGL(k_fir_ols_walk_f32<IO_DWORD>, grid, block, lds_bytes, as_stream(stream), in, out, hist, hf, tw, G);
     LLZ_LAUNCH_CHECK("k_fir_ols_f32");
     return LLZ_OK;
 }

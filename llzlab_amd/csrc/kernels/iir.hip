@@ -9,6 +9,7 @@
 //                        chained M=N=2 handles). One lane per channel walks time; float32 I/O is staged through
 //                        LDS in 64x64 tiles so HBM sees 256-byte rows although lanes own channels. State and
 //                        arithmetic are double (the recurrence amplifies rounding by ~1/(1-r)^2 for pole radius r).
+#include <mutex>
 #include "common.hpp"
 #include <type_traits>
 #include <stdlib.h>
@@ -198,8 +199,8 @@ template <typename R, int RR>
 __global__ void __launch_bounds__(1024)
 k_iir_cascade_pipe(const float *__restrict__ in, float *__restrict__ out, const double *__restrict__ coef,
                        const double *__restrict__ pd /* [S][6][4] */, const double *__restrict__ pl /* [S][64][12] */,
-                       double *__restrict__ state, int nchunks_total, long in_pitch, long out_pitch, int stages,
-                       int segs, int seg_chunks, int warm)
+                       const double *__restrict__ state_in, double *__restrict__ state, int nchunks_total, long in_pitch,
+                       long out_pitch, int stages, int segs, int seg_chunks, int warm)
 {
     extern __shared__ __attribute__((aligned(16))) char slots_raw[];
     R *slots = reinterpret_cast<R *>(slots_raw);        // [stages-1][(64 * RR)]: one per section boundary
@@ -225,9 +226,12 @@ k_iir_cascade_pipe(const float *__restrict__ in, float *__restrict__ out, const 
     const R L00 = (R)plane_tab[0], L01 = (R)plane_tab[1], L10 = (R)plane_tab[2], L11 = (R)plane_tab[3];
     const R M1a = (R)plane_tab[4], M1b = (R)plane_tab[5], M1c = (R)plane_tab[6], M1d = (R)plane_tab[7];
     const R M2a = (R)plane_tab[8], M2b = (R)plane_tab[9], M2c = (R)plane_tab[10], M2d = (R)plane_tab[11];
+    // the frame's start state is read from state_in, its end state written to another buffer (state): segment 0 and the
+    // last segment of a channel are different workgroups of one launch, and nothing orders them
+    const double *st_in = state_in + ((size_t)c * stages + s) * 4;
     double *st = state + ((size_t)c * stages + s) * 4;
     R su1 = 0, su2 = 0, sy1 = 0, sy2 = 0;                   // x(n-1), x(n-2), y(n-1), y(n-2)
-    if (seg == 0) { su1 = (R)st[0]; su2 = (R)st[1]; sy1 = (R)st[2]; sy2 = (R)st[3]; }
+    if (seg == 0) { su1 = (R)st_in[0]; su2 = (R)st_in[1]; sy1 = (R)st_in[2]; sy2 = (R)st_in[3]; }
 
     const float *row = in + (size_t)c * in_pitch + (size_t)chunk0 * (64 * RR) + lane * RR;
     float *orow = out + (size_t)c * out_pitch + (size_t)chunk0 * (64 * RR) + lane * RR;
@@ -357,8 +361,8 @@ template <typename R, int S>
 __global__ void __launch_bounds__(256)
 k_iir_cascade_wave(const float *__restrict__ in, float *__restrict__ out, const R *__restrict__ coef32,
                    const R *__restrict__ pd32 /* [S][pd_stride], P^(2^d) d < 4 first */, const R *__restrict__ pl32 /* [S][64][12] */,
-                   double *__restrict__ state, int nchunks_total, long in_pitch, long out_pitch, int stages,
-                   int segs, int seg_chunks, int warm, long items, int pd_stride)
+                   const double *__restrict__ state_in, double *__restrict__ state, int nchunks_total, long in_pitch,
+                   long out_pitch, int stages, int segs, int seg_chunks, int warm, long items, int pd_stride)
 {
     __shared__ __attribute__((aligned(16))) R s_pl[S * 64 * 12];
     for (int e = threadIdx.x; e < stages * 768; e += 256) s_pl[e] = pl32[e];
@@ -376,7 +380,7 @@ k_iir_cascade_wave(const float *__restrict__ in, float *__restrict__ out, const 
     for (int s = 0; s < S; s++) {
         su1[s] = su2[s] = sy1[s] = sy2[s] = 0;
         if (s < stages && seg == 0) {
-            const double *st = state + ((size_t)c * stages + s) * 4;
+            const double *st = state_in + ((size_t)c * stages + s) * 4;
             su1[s] = (R)st[0]; su2[s] = (R)st[1]; sy1[s] = (R)st[2]; sy2[s] = (R)st[3];
         }
     }
@@ -560,8 +564,8 @@ __global__ void __launch_bounds__(256)
 k_iir_cascade_wave_pk(const float *__restrict__ in, float *__restrict__ out,
                       const float *__restrict__ pd32 /* [S][16], P^(2^d) d < 4, row major 2x2 each */,
                       const float *__restrict__ pl32 /* [S][64][12] */, const float *__restrict__ ph32 /* [S][24] */,
-                      double *__restrict__ state, int nchunks_total, long in_pitch, long out_pitch,
-                      int segs, int seg_chunks, int warm, long items)
+                      const double *__restrict__ state_in, double *__restrict__ state, int nchunks_total, long in_pitch,
+                      long out_pitch, int segs, int seg_chunks, int warm, long items)
 {
     __shared__ __attribute__((aligned(16))) float s_pl[S * 64 * 12];
     __shared__ __attribute__((aligned(16))) float s_pd[S * 16];
@@ -585,7 +589,7 @@ k_iir_cascade_wave_pk(const float *__restrict__ in, float *__restrict__ out,
     for (int s = 0; s < S; s++) {
         su1[s] = su2[s] = sy1[s] = sy2[s] = 0;
         if (seg == 0) {
-            const double *st = state + ((size_t)c * S + s) * 4;
+            const double *st = state_in + ((size_t)c * S + s) * 4;
             su1[s] = (float)st[0]; su2[s] = (float)st[1]; sy1[s] = (float)st[2]; sy2[s] = (float)st[3];
         }
     }
@@ -723,8 +727,9 @@ template <int S>
 __global__ void __launch_bounds__(256)
 k_iir_cascade_wave_pf64(const float *__restrict__ in, float *__restrict__ out,
                         const double *__restrict__ coef /* [S][5] */, const double *__restrict__ pd /* [S][24] */,
-                        const double *__restrict__ pl /* [S][64][12] */, double *__restrict__ state, int nchunks_total,
-                        long in_pitch, long out_pitch, int segs, int seg_chunks, int warm, long items)
+                        const double *__restrict__ pl /* [S][64][12] */, const double *__restrict__ state_in,
+                        double *__restrict__ state, int nchunks_total, long in_pitch, long out_pitch, int segs,
+                        int seg_chunks, int warm, long items)
 {
     __shared__ __attribute__((aligned(16))) double s_pl[S * 64 * 12];
     __shared__ __attribute__((aligned(16))) double s_pd[S * 16];
@@ -744,7 +749,7 @@ k_iir_cascade_wave_pf64(const float *__restrict__ in, float *__restrict__ out,
     for (int s = 0; s < S; s++) {
         su1[s] = su2[s] = sy1[s] = sy2[s] = 0;
         if (seg == 0) {
-            const double *st = state + ((size_t)c * S + s) * 4;
+            const double *st = state_in + ((size_t)c * S + s) * 4;
             su1[s] = st[0]; su2[s] = st[1]; sy1[s] = st[2]; sy2[s] = st[3];
         }
     }
@@ -858,13 +863,14 @@ extern "C" int llzs_iir_cascade_f32(const float *in, float *out, const double *c
 // pd: [stages][6][4] = P^(2^d) row major, P = A^16; pl: [stages][64][12] = P^lane, P^(lane%16+1), P^(lane%32+1).  n must be a multiple of 1024 and
 // the rows 16-byte aligned (pitches % 4 == 0); the caller runs the remainder through llzs_iir_cascade_f32.
 extern "C" int llzs_iir_cascade_pipe_f32(const float *in, float *out, const double *coef, const double *pd,
-                                         const double *pl, double *state, int channels, int n, long in_pitch,
-                                         long out_pitch, int stages, int warm_chunks, int float32, void *stream)
+                                         const double *pl, const double *state_in, double *state, int channels, int n,
+                                         long in_pitch, long out_pitch, int stages, int warm_chunks, int float32,
+                                         void *stream)
 {
     // 16 samples per lane in both precisions: 32 in float32 measured slower (4.27 vs 3.62 ms: 128 VGPRs with spills under
     // the 1024-thread bound, and twice as long dependent recurrences per lane)
     const int RR = 16, chunk = 64 * RR;
-    if (!in || !out || !coef || !pd || !pl || !state || channels <= 0 || n <= 0 || (n % chunk) ||
+    if (!in || !out || !coef || !pd || !pl || !state || !state_in || state == state_in || channels <= 0 || n <= 0 || (n % chunk) ||
         stages < 1 || stages > 16 || in_pitch < n || out_pitch < n || (in_pitch & 3) || (out_pitch & 3) ||
         (reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) {
         llzs_set_error("iir_cascade_pipe_f32: bad arguments (n=%d must be a multiple of %d, rows 16-byte aligned)", n,
@@ -890,16 +896,16 @@ extern "C" int llzs_iir_cascade_pipe_f32(const float *in, float *out, const doub
         if (segs > 16) segs = 16;
         while (segs > 1 && nchunks / segs < 8 * warm) segs--;
     }
-    if (const char *e = getenv("LLZ_IIR_SEGS")) { const int v = atoi(e); if (v >= 1 && v <= 64 && (v == 1 || warm_chunks > 0)) segs = v; }
+    if (const int v = llzs_tune(LLZS_TUNE_IIR_SEGS); v >= 1 && v <= 64 && (v == 1 || warm_chunks > 0)) segs = v;
     const int seg_chunks = (nchunks + segs - 1) / segs;
     segs = (nchunks + seg_chunks - 1) / seg_chunks;
     if (float32)
         hipLaunchKernelGGL((k_iir_cascade_pipe<float, 16>), dim3((unsigned)((long)channels * segs)), dim3(64 * stages), lds,
-                           as_stream(stream), in, out, coef, pd, pl, state, nchunks, in_pitch, out_pitch, stages, segs,
+                           as_stream(stream), in, out, coef, pd, pl, state_in, state, nchunks, in_pitch, out_pitch, stages, segs,
                            seg_chunks, warm);
     else
         hipLaunchKernelGGL((k_iir_cascade_pipe<double, 16>), dim3((unsigned)((long)channels * segs)), dim3(64 * stages), lds,
-                           as_stream(stream), in, out, coef, pd, pl, state, nchunks, in_pitch, out_pitch, stages, segs,
+                           as_stream(stream), in, out, coef, pd, pl, state_in, state, nchunks, in_pitch, out_pitch, stages, segs,
                            seg_chunks, warm);
     LLZ_LAUNCH_CHECK("k_iir_cascade_pipe");
     return LLZ_OK;
@@ -908,10 +914,10 @@ extern "C" int llzs_iir_cascade_pipe_f32(const float *in, float *out, const doub
 // wave-autonomous form (see k_iir_cascade_wave).  n a multiple of 1024, rows 16-byte aligned, warm_chunks > 0.
 template <typename R>
 static int launch_iir_wave(const float *in, float *out, const R *coef, const R *pd, const R *pl, const float *ph32,
-                           double *state, int channels, int n, long in_pitch, long out_pitch, int stages, int warm_chunks,
-                           int pd_stride, void *stream)
+                           const double *state_in, double *state, int channels, int n, long in_pitch, long out_pitch,
+                           int stages, int warm_chunks, int pd_stride, void *stream)
 {
-    if (!in || !out || !coef || !pd || !pl || !state || channels <= 0 || n <= 0 || (n % 1024) || stages < 1 ||
+    if (!in || !out || !coef || !pd || !pl || !state || !state_in || state == state_in || channels <= 0 || n <= 0 || (n % 1024) || stages < 1 ||
         stages > 8 /* 16 sections in registers spill */ || warm_chunks < 1 || in_pitch < n || out_pitch < n || (in_pitch & 3) || (out_pitch & 3) ||
         (reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) {
         llzs_set_error("iir_cascade_wave: bad arguments");
@@ -923,7 +929,7 @@ static int launch_iir_wave(const float *in, float *out, const R *coef, const R *
     // of warm-up and table load, ~1.4 chunks, stays small and the hardware balances the rounds), otherwise exactly one
     // round; segments at least 8 x the warm-up.
     // the one-section-ahead kernels (packed float32 / double); LLZ_IIR_UNPACKED=1 keeps the first wave kernels for A/B
-    static const bool first_version = getenv("LLZ_IIR_UNPACKED") != nullptr;
+    const bool first_version = llzs_tune(LLZS_TUNE_IIR_UNPACKED) == 1;
     const bool ahead = !first_version && (std::is_same<R, double>::value || ph32 != nullptr);
     const void *kfn = nullptr;
     if (ahead) {
@@ -947,7 +953,9 @@ static int launch_iir_wave(const float *in, float *out, const R *coef, const R *
     // (queried once per kernel and process: same answer on every device of a node)
     static struct { const void *fn; long slots; } seen[24];
     static int nseen = 0;
+    static std::mutex seen_lock;
     long slots = 0;
+    std::lock_guard<std::mutex> guard(seen_lock);
     for (int i = 0; i < nseen; i++)
         if (seen[i].fn == kfn) slots = seen[i].slots;
     if (!slots) {
@@ -963,7 +971,7 @@ static int launch_iir_wave(const float *in, float *out, const R *coef, const R *
             cus = 256;
         }
         slots = 4L * blocks_per_cu * cus;
-        if (nseen < 24) { seen[nseen].slots = slots; seen[nseen].fn = kfn; nseen++; }   // benign if two threads race
+        if (nseen < 24) { seen[nseen].slots = slots; seen[nseen].fn = kfn; nseen++; }
     }
     int segs = 1;
     for (int rounds = 3; rounds >= 1; rounds--) {
@@ -973,7 +981,7 @@ static int launch_iir_wave(const float *in, float *out, const R *coef, const R *
         if (rounds == 1 || nchunks / segs >= 64) break;
     }
     while (segs > 1 && nchunks / segs < 8 * warm_chunks) segs--;
-    if (const char *e = getenv("LLZ_IIR_SEGS")) { const int v = atoi(e); if (v >= 1 && v <= 64) segs = v; }
+    if (const int v = llzs_tune(LLZS_TUNE_IIR_SEGS); v >= 1 && v <= 64) segs = v;
     const int seg_chunks = (nchunks + segs - 1) / segs;
     segs = (nchunks + seg_chunks - 1) / seg_chunks;
     const long items = (long)channels * segs;
@@ -981,7 +989,7 @@ static int launch_iir_wave(const float *in, float *out, const R *coef, const R *
     if (ahead) {
         if constexpr (std::is_same<R, float>::value) {
 #define LLZ_AHEAD_LAUNCH(S)                                                                                          \
-    hipLaunchKernelGGL((k_iir_cascade_wave_pk<S>), grid, dim3(256), 0, as_stream(stream), in, out, pd, pl, ph32, state, \
+    hipLaunchKernelGGL((k_iir_cascade_wave_pk<S>), grid, dim3(256), 0, as_stream(stream), in, out, pd, pl, ph32, state_in, state, \
                        nchunks, in_pitch, out_pitch, segs, seg_chunks, warm_chunks, items)
             switch (stages) {
             case 1: LLZ_AHEAD_LAUNCH(1); break; case 2: LLZ_AHEAD_LAUNCH(2); break; case 3: LLZ_AHEAD_LAUNCH(3); break;
@@ -992,7 +1000,7 @@ static int launch_iir_wave(const float *in, float *out, const R *coef, const R *
         } else {
 #define LLZ_AHEAD_LAUNCH(S)                                                                                          \
     hipLaunchKernelGGL((k_iir_cascade_wave_pf64<S>), grid, dim3(256), 0, as_stream(stream), in, out, coef, pd, pl,      \
-                       state, nchunks, in_pitch, out_pitch, segs, seg_chunks, warm_chunks, items)
+                       state_in, state, nchunks, in_pitch, out_pitch, segs, seg_chunks, warm_chunks, items)
             switch (stages) {
             case 1: LLZ_AHEAD_LAUNCH(1); break; case 2: LLZ_AHEAD_LAUNCH(2); break; case 3: LLZ_AHEAD_LAUNCH(3); break;
             case 4: LLZ_AHEAD_LAUNCH(4); break; case 5: LLZ_AHEAD_LAUNCH(5); break; case 6: LLZ_AHEAD_LAUNCH(6); break;
@@ -1005,7 +1013,7 @@ static int launch_iir_wave(const float *in, float *out, const R *coef, const R *
     }
 #define LLZ_WAVE_LAUNCH(S)                                                                                           \
     hipLaunchKernelGGL((k_iir_cascade_wave<R, S>), grid, dim3(256), 0, as_stream(stream), in, out, coef, pd, pl,        \
-                       state, nchunks, in_pitch, out_pitch, stages, segs, seg_chunks, warm_chunks, items, pd_stride)
+                       state_in, state, nchunks, in_pitch, out_pitch, stages, segs, seg_chunks, warm_chunks, items, pd_stride)
     if (stages <= 2) LLZ_WAVE_LAUNCH(2);
     else if (stages <= 4) LLZ_WAVE_LAUNCH(4);
     else LLZ_WAVE_LAUNCH(8);
@@ -1016,18 +1024,18 @@ static int launch_iir_wave(const float *in, float *out, const R *coef, const R *
 
 extern "C" int llzs_iir_cascade_wave_f32(const float *in, float *out, const float *coef32, const float *pd32,
                                          const float *pl32, const float *ph32 /* NULL: unpacked kernel */,
-                                         double *state, int channels, int n, long in_pitch, long out_pitch, int stages,
-                                         int warm_chunks, void *stream)
+                                         const double *state_in, double *state, int channels, int n, long in_pitch,
+                                         long out_pitch, int stages, int warm_chunks, void *stream)
 {
-    return launch_iir_wave<float>(in, out, coef32, pd32, pl32, ph32, state, channels, n, in_pitch, out_pitch, stages,
+    return launch_iir_wave<float>(in, out, coef32, pd32, pl32, ph32, state_in, state, channels, n, in_pitch, out_pitch, stages,
                                   warm_chunks, 16, stream);
 }
 
 // the same in double, from the pipelined kernel's own tables (pd: [S][6][4])
 extern "C" int llzs_iir_cascade_wave_f64(const float *in, float *out, const double *coef, const double *pd,
-                                         const double *pl, double *state, int channels, int n, long in_pitch,
-                                         long out_pitch, int stages, int warm_chunks, void *stream)
+                                         const double *pl, const double *state_in, double *state, int channels, int n,
+                                         long in_pitch, long out_pitch, int stages, int warm_chunks, void *stream)
 {
-    return launch_iir_wave<double>(in, out, coef, pd, pl, nullptr, state, channels, n, in_pitch, out_pitch, stages, warm_chunks,
+    return launch_iir_wave<double>(in, out, coef, pd, pl, nullptr, state_in, state, channels, n, in_pitch, out_pitch, stages, warm_chunks,
                                    24, stream);
 }

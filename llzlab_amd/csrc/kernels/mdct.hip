@@ -153,7 +153,7 @@ extern "C" int llzs_mdct4_f32(const float *in, float *out, int count, int N, con
         llzs_set_error("mdct4_f32: bad arguments (N=%d must be a power of two in 32..8192, count=%d)", N, count);
         return LLZ_ERR_ARG;
     }
-    if (!getenv("LLZ_FFT_GENERIC")) {                              // the six sizes with a register-transform kernel
+    if (llzs_tune(LLZS_TUNE_FFT_GENERIC) < 1) {                              // the six sizes with a register-transform kernel
         const int rc = llzs_mdct4_reg_f32(in, out, count, N, tc, ts, cs, inverse, stream);
         if (rc != LLZ_ERR_RANGE) return rc;
     }

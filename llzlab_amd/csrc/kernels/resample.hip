@@ -530,7 +530,7 @@ extern "C" int llzs_resample_f32(const float *in, float *out, const float *hist,
                                  float gain, long long i0, long long in0, void *stream)
 {
     if (in && out && g && channels > 0 && channels <= 65535 && n_in > 0 && n_out > 0 && L >= 1 && M >= 1 && Q >= 1 &&
-        in_pitch >= n_in && out_pitch >= n_out && !getenv("LLZ_RS_GENERIC_OLD") && !getenv("LLZ_RS_NO_WINDOW")) {
+        in_pitch >= n_in && out_pitch >= n_out && llzs_tune(LLZS_TUNE_RS_GENERIC) < 1) {
         // small L, M: the register-window kernel (R periods per lane; M R = 8 .. 24 samples per lane and tile)
 #define LLZ_RSW_TRY(LL, MM, RR)                                                                                      \
     if (L == LL && M == MM) {                                                                                        \
@@ -561,7 +561,7 @@ extern "C" int llzs_resample_f32(const float *in, float *out, const float *hist,
         if (((qpad >> 2) & 1) == 0) qpad += 4;                       // qpad/4 odd: conflict-free 16-byte row reads
         const int span_max = (int)(((long)(RS_THREADS * RSL_R - 1) * M + L - 1) / L) + 1 + Q;
         const size_t lds = ((size_t)L * qpad + 8 + span_max) * sizeof(float);
-        if (lds <= 64 * 1024 && !getenv("LLZ_RS_GENERIC_OLD")) {
+        if (lds <= 64 * 1024 && llzs_tune(LLZS_TUNE_RS_GENERIC) < 2) {
             // tiles per workgroup: enough to amortise the tap matrix (its size in tile-spans, x4), while the grid keeps
             // at least ~8 workgroups per CU
             const long tiles = (n_out + RS_THREADS * RSL_R - 1) / (RS_THREADS * RSL_R);
@@ -569,7 +569,7 @@ extern "C" int llzs_resample_f32(const float *in, float *out, const float *hist,
             const long cap = tiles * channels / 2048;
             if (tpb > cap) tpb = cap;
             if (tpb < 1) tpb = 1;
-            if (const char *e = getenv("LLZ_RS_TILES")) { const int v = atoi(e); if (v >= 1) tpb = v; }
+            if (const int v = llzs_tune(LLZS_TUNE_RS_TILES); v >= 1) tpb = v;
             dim3 grid((unsigned)((tiles + tpb - 1) / tpb), (unsigned)channels);
             hipLaunchKernelGGL(k_resample_f32_lds, grid, dim3(RS_THREADS), lds, as_stream(stream), in, out, hist, g, n_in,
                                n_out, in_pitch, out_pitch, L, M, Q, gain, i0, in0, qpad, (int)tpb);

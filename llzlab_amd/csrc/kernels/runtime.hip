@@ -17,6 +17,37 @@ extern "C" void llzs_set_error(const char *fmt, ...)
 
 extern "C" const char *llz_hip_last_error(void) { return g_err; }
 
+// ---- tuning overrides: explicit API, never the environment ---------------------------------------------------------
+#include <atomic>
+#include <string.h>
+static std::atomic<int> g_tune[LLZS_TUNE_COUNT];
+static const char *const g_tune_names[LLZS_TUNE_COUNT] = {
+    "ols_chain", "ols_wg_per_cu", "ols_io", "rs_generic", "rs_tiles", "rs_dec_valu", "rs_i16_path", "mfma_nacc",
+    "mfma_wg_per_cu", "fft_generic", "iir_segs", "iir_unpacked", "iir_f64", "iir_pipe", "iir_wave_min_items", "fir_part"};
+namespace {
+struct tune_init {
+    tune_init() { for (auto &t : g_tune) t.store(-1, std::memory_order_relaxed); }
+} g_tune_init;
+}
+
+extern "C" int llzs_tune(int id)
+{
+    return (id >= 0 && id < LLZS_TUNE_COUNT) ? g_tune[id].load(std::memory_order_relaxed) : -1;
+}
+
+extern "C" const char *llz_hip_tune_name(int index)
+{
+    return (index >= 0 && index < LLZS_TUNE_COUNT) ? g_tune_names[index] : nullptr;
+}
+
+extern "C" int llz_hip_tune(const char *name, int value)
+{
+    for (int i = 0; name && i < LLZS_TUNE_COUNT; i++)
+        if (strcmp(name, g_tune_names[i]) == 0) { g_tune[i].store(value < 0 ? -1 : value); return LLZ_OK; }
+    llzs_set_error("llz_hip_tune: unknown name '%s'", name ? name : "(null)");
+    return LLZ_ERR_ARG;
+}
+
 extern "C" int llz_hip_device_count(void)
 {
     int n = 0;

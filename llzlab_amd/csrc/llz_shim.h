@@ -25,6 +25,31 @@ int   llzs_memset(void *dev_dst, int value, size_t bytes, void *stream);
 int   llzs_sync(void *stream);
 int   llzs_is_device_ptr(const void *p);
 
+/* ---- tuning overrides (measurement and tests only) ----
+ * The library never reads the environment.  Every algorithm / launch-shape choice is made from the problem's shape; a
+ * choice can be overridden for A/B measurements and for tests that force a rarely taken form through the public
+ * llz_hip_tune(name, value) (include/llz_hip.h).  value < 0 = unset (the library's own choice). */
+enum {
+    LLZS_TUNE_OLS_CHAIN = 0,        /* 1 force / 0 forbid the chain form of the 1024-point overlap-save kernel */
+    LLZS_TUNE_OLS_WG_PER_CU,        /* resident workgroups per CU the overlap-save grid is sized for */
+    LLZS_TUNE_OLS_IO,               /* 1: one dword per lane (first form) / 4: 16 bytes per lane */
+    LLZS_TUNE_RS_GENERIC,           /* 1: general L/M resampler without the register-window kernel; 2: first LDS kernel */
+    LLZS_TUNE_RS_TILES,             /* tiles per workgroup of the general L/M resampler */
+    LLZS_TUNE_RS_DEC_VALU,          /* 1: L = 1 float32 decimator on the vector pipe (LDS polyphase kernel) */
+    LLZS_TUNE_RS_I16_PATH,          /* 1: int16 resampler always on the all-double kernel (no screened fast pass) */
+    LLZS_TUNE_MFMA_NACC,            /* accumulator tiles per wave of the matrix-core FIR (1 / 2) */
+    LLZS_TUNE_MFMA_WG_PER_CU,
+    LLZS_TUNE_FFT_GENERIC,          /* 1: staged LDS passes instead of the register transforms */
+    LLZS_TUNE_IIR_SEGS,             /* time segments per channel */
+    LLZS_TUNE_IIR_UNPACKED,         /* 1: first wave-autonomous kernels (no packed arithmetic, no fetch-ahead) */
+    LLZS_TUNE_IIR_F64,              /* 1: double arithmetic whatever the noise-gain check says */
+    LLZS_TUNE_IIR_PIPE,             /* 1: stage pipeline even where the wave form would be taken */
+    LLZS_TUNE_IIR_WAVE_MIN_ITEMS,   /* crossover (channel, segment) item count of the wave form */
+    LLZS_TUNE_FIR_PART,             /* 1 force / 0 forbid the partitioned overlap-save for long filters */
+    LLZS_TUNE_COUNT
+};
+int llzs_tune(int id);                                   /* current override or -1 */
+
 /* ---- FIR ---- */
 #define LLZS_FIR_TAP_PAD 8      /* time-domain kernels read taps in groups of 8: pad the table with zeros */
 #define LLZS_OLS_NFFT   1024
@@ -77,7 +102,8 @@ int llzs_iir_cascade_f32(const float *in, float *out, const double *coef, double
  * P^(2^d) of P = A^16 with A = [[-a1,-a2],[1,0]], pl = [stages][64][12] = P^lane, P^(lane%16+1), P^(lane%32+1); same coef / state layout as above. */
 #define LLZS_IIR_PIPE_CHUNK 1024     /* 64 lanes x 16 samples */
 int llzs_iir_cascade_pipe_f32(const float *in, float *out, const double *coef, const double *pd, const double *pl,
-                              double *state, int channels, int n, long in_pitch, long out_pitch, int stages,
+                              const double *state_in, double *state_out /* a different buffer: segments of one launch
+                                                                         * are not ordered */, int channels, int n, long in_pitch, long out_pitch, int stages,
                               int warm_chunks /* 0: never split a channel along time */,
                               int float32 /* 1: float32 arithmetic (every section passed the host's noise-gain check) */,
                               void *stream);
@@ -89,11 +115,11 @@ int llzs_iir_cascade_wave_f32(const float *in, float *out, const float *coef32, 
                               const float *ph32 /* [S][24]: (h1[k], h2[k]) k < 8, the outputs at k of the unit start
                                                    * states, then b0 b1 b2 a1 a2 and 3 pad; NULL = the
                                                    * unpacked kernel */,
-                              double *state, int channels, int n, long in_pitch, long out_pitch, int stages,
+                              const double *state_in, double *state_out, int channels, int n, long in_pitch, long out_pitch, int stages,
                               int warm_chunks, void *stream);
 /* the same in double from the pipelined kernel's tables; at most 8 sections */
 int llzs_iir_cascade_wave_f64(const float *in, float *out, const double *coef, const double *pd, const double *pl,
-                              double *state, int channels, int n, long in_pitch, long out_pitch, int stages,
+                              const double *state_in, double *state_out, int channels, int n, long in_pitch, long out_pitch, int stages,
                               int warm_chunks, void *stream);
 int llzs_iir_df1_f64(const double *in, double *out, const double *a, const double *b, double *xs, double *ys,
                      int M, int N, int n, void *stream);

@@ -410,6 +410,17 @@ class Oracle:
         self.lib.orc_fir_batch_f32(x.ctypes.data, _ptr(out), Cn, n, _ptr(h), len(h))
         return out
 
+    def fir_batch_f32_mt(self, x, h, threads=None):
+        """fir_batch_f32 with the channels spread over host threads (ctypes releases the GIL; channels are independent)"""
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        threads = max(1, min(threads or (os.cpu_count() or 1), x.shape[0]))
+        parts = np.array_split(np.arange(x.shape[0]), threads)
+        with ThreadPoolExecutor(threads) as ex:
+            outs = list(ex.map(lambda idx: self.fir_batch_f32(x[idx[0]:idx[-1] + 1], h), [q for q in parts if len(q)]))
+        return np.concatenate(outs, axis=0)
+
     def iir_cascade_batch_f32(self, x, coef):
         x = np.ascontiguousarray(x, dtype=np.float32)
         coef = _f64(coef).reshape(-1, 6)

@@ -939,90 +939,117 @@ def test_fir_ols4096_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
 
 
 # ------------------------------------------------------------------------------------------------ overlap-save, chain form
-_CHAIN_SCRIPT = r'''
-import os, sys
-import numpy as np
-import torch
-sys.path.insert(0, os.environ["LLZ_REPO"])
-from llzlab_amd import filters
-from oracle import pyoracle as po
-po.build()
-oracle = po.Oracle()
-dev = torch.device("cuda:0")
-for channels, n, taps_n in ((3, 1536 * 40 + 100, 257), (5, 1536 * 33, 63), (2, 1000, 129), (9, 1536 * 17 + 1, 200)):
-    taps = oracle.fir_design(po.LPF, taps_n, 0.2, 0.0, po.KAISER)
-    x = oracle.synth_f32(channels, 2 * n, seed=taps_n)
-    ref = oracle.fir_batch_f32(x, taps.astype(np.float32).astype(np.float64))
-    f = filters.FirFilterMC(channels, n, taps, algo=filters.FIR_ALGO_OVERLAP_SAVE)
-    outs = []
-    for o in (0, n):                                    # two frames: the history carried between calls
-        xd = torch.from_numpy(np.ascontiguousarray(x[:, o:o + n])).to(dev)
-        yd = torch.empty_like(xd)
-        f.filter(xd, yd)
-        outs.append(yd.cpu().numpy())
-    got = np.concatenate(outs, axis=1).astype(np.float64)
-    err = float(np.sqrt(np.mean((got - ref) ** 2)))
-    rel = err / float(np.sqrt(np.mean(ref ** 2)))
-    assert err <= 1e-5 and rel <= 1e-5, (channels, n, taps_n, err, rel)
-    f.close()
-print("CHAIN_OK")
-'''
-
-
-def test_fir_ols_chain_form_forced(dev):
+@pytest.mark.parametrize("io", [-1, 1], ids=["wide", "dword"])
+@pytest.mark.parametrize("chain", [1, 0], ids=["chain", "walk"])
+def test_fir_ols_forms_forced(dev, oracle, chain, io):
     """the launcher takes the chain form (prefetch carried across segments) only on batches far larger than a test can
-    afford to check sample by sample; LLZ_OLS_VARIANT=7 forces it on small ones in a child process (the knob is read once
-    per process), including ragged lengths, segments shorter than 16 jobs and streaming across calls"""
-    import subprocess
-    env = dict(os.environ, LLZ_OLS_VARIANT="7", LLZ_REPO=ROOT)
-    r = subprocess.run([sys.executable, "-c", _CHAIN_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "CHAIN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    afford to check sample by sample, and the one-dword-per-lane access form only for rows that are not 8-byte aligned:
+    llz_hip_tune forces each combination on small batches, including ragged lengths, segments shorter than 16 jobs, odd
+    row pitches (which must fall back to the dword form by themselves) and streaming across calls"""
+    with capi.tuned(ols_chain=chain, ols_io=io):
+        for channels, n, taps_n in ((3, 1536 * 40 + 100, 257), (5, 1536 * 33, 63), (2, 1000, 129), (9, 1536 * 17 + 1, 200),
+                                    (4, 1536 * 5 + 7, 257)):
+            taps = oracle.fir_design(po.LPF, taps_n, 0.2, 0.0, po.KAISER)
+            x = oracle.synth_f32(channels, 2 * n, seed=taps_n)
+            ref = oracle.fir_batch_f32(x, taps.astype(np.float32).astype(np.float64))
+            f = filters.FirFilterMC(channels, n, taps, algo=filters.FIR_ALGO_OVERLAP_SAVE)
+            outs = []
+            for o in (0, n):                                    # two frames: the history carried between calls
+                xd = torch.from_numpy(np.ascontiguousarray(x[:, o:o + n])).to(dev)
+                yd = torch.empty_like(xd)
+                f.filter(xd, yd)
+                outs.append(yd.cpu().numpy())
+            f.close()
+            rms_check(np.concatenate(outs, axis=1), ref, f"fir ols chain={chain} io={io} {channels}x{n}x{taps_n}")
 
 
-_IIR_FIRST_SCRIPT = r'''
-import os, sys
-import numpy as np
-import torch
-sys.path.insert(0, os.environ["LLZ_REPO"])
-from llzlab_amd import filters
-from oracle import pyoracle as po
-po.build()
-oracle = po.Oracle()
-dev = torch.device("cuda:0")
-for stages, radius, prec in ((8, 0.44, 32), (3, 0.7, 32), (8, 0.99, 64), (5, 0.97, 64)):
+def test_fir_ols_headline_shape_full_length(dev, oracle):
+    """BASELINE config 3 at its full size through the DEFAULT launcher (chain form, wide accesses): 4096 channels x 2^20
+    samples x 257 taps.  Eight channels are checked over their FULL length against the oracle (first, last and six spread
+    so that they fall into different rounds of the persistent grid; every one crosses all 42 segment boundaries and ends
+    in the ragged 11-job last segment), plus every channel over its first 16 Ki samples (SURVEY.md 8(d) parity measure)."""
+    channels, n, taps_n = 4096, 1 << 20, 257
+    taps = oracle.fir_design(po.LPF, taps_n, 0.1, 0.0, po.KAISER)
+    x = torch.empty(channels, n, dtype=torch.float32, device=dev)
+    filters.synth_f32(x, seed=0x11C0FFEE)
+    y = torch.empty_like(x)
+    f = filters.FirFilterMC(channels, n, taps)
+    assert f.algo == filters.FIR_ALGO_OVERLAP_SAVE
+    f.filter(x, y)
+    torch.cuda.synchronize()
+    h = taps.astype(np.float32).astype(np.float64)
+    sel = [0, 1, 95, 1337, 2048, 3071, 4094, 4095]
+    ref = oracle.fir_batch_f32_mt(x[sel].cpu().numpy(), h)
+    rms_check(y[sel].cpu().numpy(), ref, "fir ols headline, 8 channels x 2^20")
+    m = 1 << 14
+    ref = oracle.fir_batch_f32_mt(x[:, :m].cpu().numpy(), h)
+    rms_check(y[:, :m].cpu().numpy(), ref, "fir ols headline, all channels x 16 Ki")
+    # second call: streaming state (the previous call's last 256 samples) through the same launch shape
+    f.filter(x, y)
+    torch.cuda.synchronize()
+    xs = torch.cat([x[sel, n - (taps_n - 1):], x[sel, :m]], dim=1).cpu().numpy()
+    ref = oracle.fir_batch_f32(xs, h)[:, taps_n - 1:]
+    rms_check(y[sel, :m].cpu().numpy(), ref, "fir ols headline, second call")
+    f.close()
+
+
+def test_iir_wave_first_version_kernels(dev, oracle):
+    """llz_hip_tune("iir_unpacked", 1) keeps the first wave-autonomous kernels (no one-section-ahead fetch, no packed
+    arithmetic) for A/B runs; they stay checked here"""
+    with capi.tuned(iir_unpacked=1):
+        for stages, radius, prec in ((8, 0.44, 32), (3, 0.7, 32), (8, 0.99, 64), (5, 0.97, 64)):
+            rows = []
+            for k in range(stages):
+                r, th = radius - 0.01 * k, 0.3 + 0.2 * k
+                a1, a2 = -2 * r * np.cos(th), r * r
+                rows.append([(1 + a1 + a2) / 4, (1 + a1 + a2) / 2, (1 + a1 + a2) / 4, 1.0, a1, a2])
+            coef = np.array(rows)
+            channels, n = 2048, 1024 * (256 if prec == 64 else 24) + 52
+            f = filters.IirCascadeMC(channels, coef)
+            assert f.precision == prec, (stages, radius, f.precision)
+            sel = [0, 1000, 2047]
+            xs, ys = [], []
+            for call in range(2):
+                x = torch.empty(channels, n, dtype=torch.float32, device=dev)
+                filters.synth_f32(x, seed=90 + call)
+                y = torch.empty_like(x)
+                f.filter(x, y)
+                xs.append(x[sel].cpu().numpy()); ys.append(y[sel].cpu().numpy())
+            f.close()
+            ref = oracle.iir_cascade_batch_f32(np.concatenate(xs, axis=1), coef)
+            got = np.concatenate(ys, axis=1).astype(np.float64)
+            err, scale = float(np.sqrt(np.mean((got - ref) ** 2))), float(np.sqrt(np.mean(ref ** 2)))
+            assert err <= 1e-5 * max(1.0, scale) and err / scale <= 1e-5, (stages, radius, err, scale)
+
+
+@pytest.mark.parametrize("segs", [2, 5, 16])
+@pytest.mark.parametrize("form", ["pipe", "wave32", "wave64"])
+def test_iir_time_segments_stream_across_calls(dev, oracle, form, segs):
+    """several time segments per channel in ONE launch, streamed over two calls: segment 0 reads the frame's start state
+    while the last segment of the same launch writes the frame's end state -- different workgroups that nothing orders, so
+    the two states live in different buffers (the handle swaps them after the launch)"""
+    radius = 0.99 if form == "wave64" else 0.5
     rows = []
-    for k in range(stages):
-        r, th = radius - 0.01 * k, 0.3 + 0.2 * k
+    for k in range(4):
+        r, th = radius - 0.02 * k, 0.4 + 0.3 * k
         a1, a2 = -2 * r * np.cos(th), r * r
         rows.append([(1 + a1 + a2) / 4, (1 + a1 + a2) / 2, (1 + a1 + a2) / 4, 1.0, a1, a2])
     coef = np.array(rows)
-    channels, n = 2048, 1024 * (256 if prec == 64 else 24) + 52
-    f = filters.IirCascadeMC(channels, coef)
-    assert f.precision == prec, (stages, radius, f.precision)
-    sel = [0, 1000, 2047]
-    xs, ys = [], []
-    for call in range(2):
-        x = torch.empty(channels, n, dtype=torch.float32, device=dev)
-        filters.synth_f32(x, seed=90 + call)
-        y = torch.empty_like(x)
-        f.filter(x, y)
-        xs.append(x[sel].cpu().numpy()); ys.append(y[sel].cpu().numpy())
-    f.close()
+    channels, n = 24, 1024 * (2048 if form == "wave64" else 256)
+    with capi.tuned(iir_segs=segs, iir_pipe=1 if form == "pipe" else -1, iir_wave_min_items=0):
+        f = filters.IirCascadeMC(channels, coef)
+        xs, ys = [], []
+        for call in range(2):
+            x = torch.empty(channels, n, dtype=torch.float32, device=dev)
+            filters.synth_f32(x, seed=60 + call)
+            y = torch.empty_like(x)
+            f.filter(x, y)
+            xs.append(x.cpu().numpy()); ys.append(y.cpu().numpy())
+        f.close()
     ref = oracle.iir_cascade_batch_f32(np.concatenate(xs, axis=1), coef)
     got = np.concatenate(ys, axis=1).astype(np.float64)
     err, scale = float(np.sqrt(np.mean((got - ref) ** 2))), float(np.sqrt(np.mean(ref ** 2)))
-    assert err <= 1e-5 * max(1.0, scale) and err / scale <= 1e-5, (stages, radius, err, scale)
-print("IIR_FIRST_OK")
-'''
-
-
-def test_iir_wave_first_version_kernels(dev):
-    """LLZ_IIR_UNPACKED=1 keeps the first wave-autonomous kernels (no one-section-ahead fetch, no packed arithmetic) for A/B
-    runs; they stay checked here in a child process (the knob is read once per process)"""
-    import subprocess
-    env = dict(os.environ, LLZ_IIR_UNPACKED="1", LLZ_REPO=ROOT)
-    r = subprocess.run([sys.executable, "-c", _IIR_FIRST_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "IIR_FIRST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert err <= 1e-5 * max(1.0, scale) and err / scale <= 1e-5, (form, segs, err, scale)
 
 
 # ------------------------------------------------------------------------------------------------ limits and degenerate calls
