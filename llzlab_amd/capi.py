@@ -222,6 +222,25 @@ def lib():
     sig("llz_mdct_fixed_uninit", None, ul)
     sig("llz_mdct_fixed", None, ul, ip, ip)
     sig("llz_imdct_fixed", None, ul, ip, ip)
+    # llz_shard.h
+    pp = C.POINTER(C.c_void_p)
+    sig("llz_shard_range", i, i, i, i, ip, ip)
+    sig("llz_fir_filter_mc_sharded_init", ul, i, i, vp, i, i, ip, i)
+    sig("llz_fir_filter_mc_sharded", i, ul, pp, pp, i)
+    sig("llz_fir_filter_mc_sharded_flush", i, ul, pp)
+    sig("llz_iir_cascade_mc_sharded_init", ul, i, i, vp, ip, i)
+    sig("llz_iir_cascade_mc_sharded", i, ul, pp, pp, i)
+    sig("llz_resample_mc_sharded_init", ul, i, i, i, d, i, i, ip, i)
+    sig("llz_resample_mc_sharded", lng, ul, pp, lng, pp)
+    sig("llz_sharded_uninit", None, ul)
+    sig("llz_sharded_count", i, ul)
+    sig("llz_sharded_shard", i, ul, i, ip, ip, ip)
+    sig("llz_sharded_stream", vp, ul, i)
+    sig("llz_sharded_sub", ul, ul, i)
+    sig("llz_sharded_synchronize", i, ul)
+    sig("llz_sharded_timer_start", i, ul)
+    sig("llz_sharded_timer_stop", i, ul)
+    sig("llz_sharded_timer_ms", d, ul, dp)
     # llz_pcm.h
     sig("llz_pcm_deinterleave_i16_f32", i, vp, vp, i, lng, C.c_float, vp)
     sig("llz_pcm_interleave_f32_i16", i, vp, vp, i, lng, C.c_float, vp)

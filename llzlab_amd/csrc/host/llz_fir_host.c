@@ -144,6 +144,7 @@ int llz_fir_filter_flush(unsigned long handle, double *buf_out)
 
 typedef struct {
     int tag;
+    int device;                 /* the device the handle's buffers live on: every call binds it */
     int channels, frame_len, flt_len, algo;
     float *d_taps;              /* flt_len floats zero-padded to a multiple of 16 */
     float *d_hfreq, *d_twid;    /* overlap-save tables (NULL for the time-domain algorithm) */
@@ -200,8 +201,8 @@ static int firm_build_ols_tables(firm_t *f, const float *taps)
         f->d_hfreq = (float *)llzs_malloc(sizeof(float) * 2 * (size_t)N);
         f->d_twid = (float *)llzs_malloc(sizeof(float) * 2 * 1024);
         rc = (f->d_hfreq && f->d_twid) ? LLZ_OK : LLZ_ERR_NOMEM;
-        if (rc == LLZ_OK) rc = llzs_h2d(f->d_hfreq, hf, sizeof(float) * 2 * (size_t)N, NULL);
-        if (rc == LLZ_OK) rc = llzs_h2d(f->d_twid, tw, sizeof(float) * 2 * 1024, NULL);
+        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_hfreq, hf, sizeof(float) * 2 * (size_t)N);
+        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_twid, tw, sizeof(float) * 2 * 1024);
     }
     free(hf); free(tw); free(cs);
     return rc;
@@ -260,8 +261,8 @@ static int firm_build_ols_big_tables(firm_t *f, const float *taps, int N)
         f->d_hperm2 = (float *)llzs_malloc(sizeof(float) * 2 * (size_t)N);
         f->d_cs2 = (float *)llzs_malloc(sizeof(float) * 2 * (size_t)N);
         rc = (f->d_hperm2 && f->d_cs2) ? LLZ_OK : LLZ_ERR_NOMEM;
-        if (rc == LLZ_OK) rc = llzs_h2d(f->d_hperm2, hp, sizeof(float) * 2 * (size_t)N, NULL);
-        if (rc == LLZ_OK) rc = llzs_h2d(f->d_cs2, csf, sizeof(float) * 2 * (size_t)N, NULL);
+        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_hperm2, hp, sizeof(float) * 2 * (size_t)N);
+        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_cs2, csf, sizeof(float) * 2 * (size_t)N);
     }
     free(hp); free(csf); free(cs); free(hf);
     return rc;
@@ -309,6 +310,7 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
     firm_t *f = (firm_t *)calloc(1, sizeof(*f));
     if (!f) return LLZ_BAD_HANDLE;
     f->tag = LLZ_TAG_FIRM;
+    f->device = llzs_device_get();
     f->channels = channels; f->frame_len = frame_len; f->flt_len = flt_len; f->algo = algo;
 
     const int tpad = (flt_len + 15) & ~15;
@@ -323,7 +325,7 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
         f->d_zero = (float *)llzs_malloc(hist_bytes);
         if (!f->d_taps || !f->d_hist[0] || !f->d_hist[1] || !f->d_zero) rc = LLZ_ERR_NOMEM;
     }
-    if (rc == LLZ_OK) rc = llzs_h2d(f->d_taps, padded, sizeof(float) * (size_t)tpad, NULL);
+    if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_taps, padded, sizeof(float) * (size_t)tpad);
     if (rc == LLZ_OK) rc = llzs_memset(f->d_hist[0], 0, hist_bytes, NULL);
     if (rc == LLZ_OK) rc = llzs_memset(f->d_hist[1], 0, hist_bytes, NULL);
     if (rc == LLZ_OK) rc = llzs_memset(f->d_zero, 0, hist_bytes, NULL);
@@ -393,8 +395,10 @@ void llz_fir_filter_mc_uninit(unsigned long handle)
 {
     if (LLZ_HANDLE_OK(handle, firm_t, LLZ_TAG_FIRM)) {
         firm_t *f = (firm_t *)handle;
+        const int prev = llzs_device_enter(f->device);
         llzs_sync(f->stream);
         firm_destroy(f);
+        llzs_device_leave(prev);
     }
 }
 
@@ -443,6 +447,9 @@ static int firm_launch(firm_t *f, const float *d_in, float *d_out, int n, long p
     return rc;
 }
 
+static int firm_process(firm_t *f, const float *in, float *out, int frame_len);
+static int firm_flush(firm_t *f, float *out);
+
 int llz_fir_filter_mc(unsigned long handle, const float *in, float *out, int frame_len)
 {
     if (!LLZ_HANDLE_OK(handle, firm_t, LLZ_TAG_FIRM) || !in || !out) {
@@ -450,6 +457,14 @@ int llz_fir_filter_mc(unsigned long handle, const float *in, float *out, int fra
         return LLZ_ERR_ARG;
     }
     firm_t *f = (firm_t *)handle;
+    const int prev = llzs_device_enter(f->device);       /* the handle's device, whatever the caller has current */
+    const int rc = firm_process(f, in, out, frame_len);
+    llzs_device_leave(prev);
+    return rc;
+}
+
+static int firm_process(firm_t *f, const float *in, float *out, int frame_len)
+{
     if (frame_len != f->frame_len) {
         llzs_set_error("llz_fir_filter_mc: frame_len %d != init frame_len %d", frame_len, f->frame_len);
         return LLZ_ERR_ARG;
@@ -484,6 +499,14 @@ int llz_fir_filter_mc_flush(unsigned long handle, float *out)
         return LLZ_ERR_ARG;
     }
     firm_t *f = (firm_t *)handle;
+    const int prev = llzs_device_enter(f->device);
+    const int rc = firm_flush(f, out);
+    llzs_device_leave(prev);
+    return rc;
+}
+
+static int firm_flush(firm_t *f, float *out)
+{
     const int keep = f->flt_len - 1;
     if (keep == 0) return 0;
     const size_t bytes = sizeof(float) * (size_t)f->channels * (size_t)keep;

@@ -114,6 +114,7 @@ typedef struct {
     int warm_chunks;     /* 1024-sample chunks after which any state error has decayed below 1e-13 (0: unknown / too long) */
     int float32_ok;      /* every section's rounding-noise gain is small enough for float32 arithmetic */
     void *stream;
+    int device;          /* the device the handle's buffers live on: every call binds it */
     llz_stage_t st_in, st_out;
 } iirm_t;
 
@@ -163,8 +164,8 @@ static int iirm_build_powers(iirm_t *f, const double *c5, int lane_run)
         f->d_pd = (double *)llzs_malloc(sizeof(double) * (size_t)S * 24);
         f->d_pl = (double *)llzs_malloc(sizeof(double) * (size_t)S * 768);
         rc = (f->d_pd && f->d_pl) ? LLZ_OK : LLZ_ERR_NOMEM;
-        if (rc == LLZ_OK) rc = llzs_h2d(f->d_pd, pd, sizeof(double) * (size_t)S * 24, NULL);
-        if (rc == LLZ_OK) rc = llzs_h2d(f->d_pl, pl, sizeof(double) * (size_t)S * 768, NULL);
+        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_pd, pd, sizeof(double) * (size_t)S * 24);
+        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_pl, pl, sizeof(double) * (size_t)S * 768);
         if (rc == LLZ_OK && f->float32_ok) {                           /* float copies for k_iir_cascade_wave_f32 */
             float *t = (float *)malloc(sizeof(float) * (size_t)S * (5 + 16 + 768 + 24));
             if (!t) rc = LLZ_ERR_NOMEM;
@@ -190,10 +191,10 @@ static int iirm_build_powers(iirm_t *f, const double *c5, int lane_run)
                 f->d_pl32 = (float *)llzs_malloc(sizeof(float) * 768 * (size_t)S);
                 f->d_ph32 = (float *)llzs_malloc(sizeof(float) * 24 * (size_t)S);
                 if (!f->d_coef32 || !f->d_pd32 || !f->d_pl32 || !f->d_ph32) rc = LLZ_ERR_NOMEM;
-                if (rc == LLZ_OK) rc = llzs_h2d(f->d_coef32, c32, sizeof(float) * 5 * (size_t)S, NULL);
-                if (rc == LLZ_OK) rc = llzs_h2d(f->d_pd32, pd32, sizeof(float) * 16 * (size_t)S, NULL);
-                if (rc == LLZ_OK) rc = llzs_h2d(f->d_pl32, pl32, sizeof(float) * 768 * (size_t)S, NULL);
-                if (rc == LLZ_OK) rc = llzs_h2d(f->d_ph32, ph32, sizeof(float) * 24 * (size_t)S, NULL);
+                if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_coef32, c32, sizeof(float) * 5 * (size_t)S);
+                if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_pd32, pd32, sizeof(float) * 16 * (size_t)S);
+                if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_pl32, pl32, sizeof(float) * 768 * (size_t)S);
+                if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_ph32, ph32, sizeof(float) * 24 * (size_t)S);
             }
             free(t);
         }
@@ -274,6 +275,7 @@ unsigned long llz_iir_cascade_mc_init(int channels, int stages, const double *co
     iirm_t *f = (iirm_t *)calloc(1, sizeof(*f));
     if (!f) return LLZ_BAD_HANDLE;
     f->tag = LLZ_TAG_IIRM;
+    f->device = llzs_device_get();
     f->channels = channels; f->stages = stages;
     double *c5 = (double *)malloc(sizeof(double) * 5 * (size_t)stages);
     const size_t st_bytes = sizeof(double) * 4 * (size_t)stages * (size_t)channels;
@@ -288,7 +290,7 @@ unsigned long llz_iir_cascade_mc_init(int channels, int stages, const double *co
         f->d_state_alt = (double *)llzs_malloc(st_bytes);
         if (!f->d_coef || !f->d_state || !f->d_state_alt) rc = LLZ_ERR_NOMEM;
     }
-    if (rc == LLZ_OK) rc = llzs_h2d(f->d_coef, c5, sizeof(double) * 5 * (size_t)stages, NULL);
+    if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_coef, c5, sizeof(double) * 5 * (size_t)stages);
     if (rc == LLZ_OK) rc = llzs_memset(f->d_state, 0, st_bytes, NULL);
     if (rc == LLZ_OK) f->float32_ok = iirm_float32_ok(c5, stages) && llzs_tune(LLZS_TUNE_IIR_F64) != 1;
     if (rc == LLZ_OK) rc = iirm_build_powers(f, c5, 16);
@@ -311,8 +313,10 @@ int llz_iir_cascade_mc_precision(unsigned long handle)
 void llz_iir_cascade_mc_uninit(unsigned long handle)
 {
     if (LLZ_HANDLE_OK(handle, iirm_t, LLZ_TAG_IIRM)) {
+        const int prev = llzs_device_enter(((iirm_t *)handle)->device);
         llzs_sync(((iirm_t *)handle)->stream);
         iirm_destroy((iirm_t *)handle);
+        llzs_device_leave(prev);
     }
 }
 
@@ -323,6 +327,8 @@ int llz_iir_cascade_mc_set_stream(unsigned long handle, void *stream)
     return LLZ_OK;
 }
 
+static int iirm_process(iirm_t *f, const float *x, float *y, int frame_len);
+
 int llz_iir_cascade_mc(unsigned long handle, const float *x, float *y, int frame_len)
 {
     if (!LLZ_HANDLE_OK(handle, iirm_t, LLZ_TAG_IIRM) || !x || !y || frame_len < 1) {
@@ -330,6 +336,14 @@ int llz_iir_cascade_mc(unsigned long handle, const float *x, float *y, int frame
         return LLZ_ERR_ARG;
     }
     iirm_t *f = (iirm_t *)handle;
+    const int prev = llzs_device_enter(f->device);
+    const int rc = iirm_process(f, x, y, frame_len);
+    llzs_device_leave(prev);
+    return rc;
+}
+
+static int iirm_process(iirm_t *f, const float *x, float *y, int frame_len)
+{
     const size_t bytes = sizeof(float) * (size_t)f->channels * (size_t)frame_len;
     const int in_dev = llzs_is_device_ptr(x), out_dev = llzs_is_device_ptr(y);
     const float *d_in = x;

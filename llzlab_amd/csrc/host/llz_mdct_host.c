@@ -6,7 +6,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include "../../../include/llz_mdct.h"
-#include "../../../include/llz_fft.h"
 #include "llz_host.h"
 
 #define LLZ_TAG_MDCT 0x4c5a4d31
@@ -59,31 +58,123 @@ int llz_mdct_kbd(double *w, int N, double alpha)
     return N;
 }
 
-/* ---- Part 1: reference symbols ---- */
+/* ---- Part 1: reference symbols ----
+ * All three algorithms of llz_mdct.c run on the device in the reference's rounding order.  A frame travels host -> device
+ * once, goes through (twiddle step, exact-order transform, twiddle step) or the defining sums, and comes back once; the
+ * host only builds the angle tables (libm, the reference's angle expressions, so that the table values are the reference's
+ * to the last bit) and moves the frame. */
+
+enum { ROT_FWD_PRE = 0, ROT_FWD_POST = 1, ROT_INV_PRE = 2, ROT_INV_POST = 3 };
 
 typedef struct {
-    int tag, type, length;
-    unsigned long h_fft;
-    double *fft_buf;
-    /* type 0: cosine matrices on the device, vectors staged through d_x / d_y */
-    double *d_cos_pos, *d_cos_inv, *d_x, *d_y;
-    /* type 1 */
-    double *pre_c_pos, *pre_s_pos, *c_pos, *s_pos, *pre_c_inv, *pre_s_inv, *c_inv, *s_inv;
-    /* type 2 */
-    double *tw_c, *tw_s, *rot, sqrt_cof;
+    int tag, form, length;          /* form: MDCT_ORIGIN (defining sums), MDCT_FFT (N-point), MDCT_FFT4 (N/4-point) */
+    int fft_size;                   /* points of the transform inside the FFT forms */
+    double norm;                    /* 1 / sqrt(length): the N/4-point form's inverse scale */
+    double *d_sum_fwd, *d_sum_inv;  /* MDCT_ORIGIN: [N/2][N] and [N][N/2] cosine kernels */
+    double *d_rot[4];               /* FFT forms: (cos, sin) pair tables of the four twiddle steps */
+    double *d_fft_cs;               /* fft_size cos then fft_size sin of 2 pi i / fft_size (llz_fft.c:222-229) */
+    double *d_frame, *d_bins, *d_work;   /* N time samples, N/2 coefficients, up to N complex points */
 } mdct1_t;
 
 static void mdct1_destroy(mdct1_t *f)
 {
     if (!f) return;
-    if (f->h_fft && f->h_fft != LLZ_BAD_HANDLE) llz_fft_uninit(f->h_fft);
-    free(f->fft_buf);
-    llzs_free(f->d_cos_pos); llzs_free(f->d_cos_inv); llzs_free(f->d_x); llzs_free(f->d_y);
-    free(f->pre_c_pos); free(f->pre_s_pos); free(f->c_pos); free(f->s_pos);
-    free(f->pre_c_inv); free(f->pre_s_inv); free(f->c_inv); free(f->s_inv);
-    free(f->tw_c); free(f->tw_s); free(f->rot);
+    llzs_free(f->d_sum_fwd); llzs_free(f->d_sum_inv);
+    for (int t = 0; t < 4; t++) {
+        int shared = 0;
+        for (int u = 0; u < t; u++) shared |= (f->d_rot[u] == f->d_rot[t]);
+        if (!shared) llzs_free(f->d_rot[t]);
+    }
+    llzs_free(f->d_fft_cs); llzs_free(f->d_frame); llzs_free(f->d_bins); llzs_free(f->d_work);
     f->tag = 0;
     free(f);
+}
+
+/* angle of entry k of a twiddle table; the expressions are the reference's (llz_mdct.c:418-441, :459-462), evaluated in
+ * its order, because the last bit of cos/sin of a differently rounded angle would differ */
+static double rot_angle(int form, int step, int k, int length)
+{
+    if (form == MDCT_FFT4) return -2 * M_PI * (k + 0.125) / length;
+    const double n0 = ((double)length / 2 + 1) / 2;
+    switch (step) {
+    case ROT_FWD_PRE:  return -(M_PI * k) / length;
+    case ROT_FWD_POST: return -2 * M_PI * n0 * (k + 0.5) / length;
+    case ROT_INV_PRE:  return (2 * M_PI * k * n0) / length;
+    default:           return M_PI * (k + n0) / length;
+    }
+}
+
+static double *rot_table_upload(int form, int step, int count, int length)
+{
+    double *host = (double *)malloc(sizeof(double) * 2 * (size_t)count);
+    double *dev = (double *)llzs_malloc(sizeof(double) * 2 * (size_t)count);
+    if (host && dev) {
+        for (int k = 0; k < count; k++) {
+            const double ang = rot_angle(form, step, k, length);
+            host[2 * k] = cos(ang);
+            host[2 * k + 1] = sin(ang);
+        }
+        if (llzs_h2d(dev, host, sizeof(double) * 2 * (size_t)count, NULL) != LLZ_OK) { llzs_free(dev); dev = NULL; }
+    } else {
+        llzs_free(dev);
+        dev = NULL;
+    }
+    free(host);
+    return dev;
+}
+
+static int mdct1_build_sums(mdct1_t *f)
+{
+    const int N = f->length, K = N >> 1;
+    const size_t cnt = (size_t)K * N;
+    double *fwd = (double *)malloc(sizeof(double) * cnt), *inv = (double *)malloc(sizeof(double) * cnt);
+    f->d_sum_fwd = (double *)llzs_malloc(sizeof(double) * cnt);
+    f->d_sum_inv = (double *)llzs_malloc(sizeof(double) * cnt);
+    int rc = (fwd && inv && f->d_sum_fwd && f->d_sum_inv) ? LLZ_OK : LLZ_ERR_NOMEM;
+    if (rc == LLZ_OK) {
+        for (int k = 0; k < K; k++)
+            for (int n = 0; n < N; n++) {
+                const double ang = (M_PI / (2 * N)) * (2 * n + 1 + K) * (2 * k + 1);      /* llz_mdct.c:392-399 */
+                fwd[(size_t)k * N + n] = inv[(size_t)n * K + k] = cos(ang);
+            }
+        rc = llzs_h2d(f->d_sum_fwd, fwd, sizeof(double) * cnt, NULL);
+        if (rc == LLZ_OK) rc = llzs_h2d(f->d_sum_inv, inv, sizeof(double) * cnt, NULL);
+    }
+    free(fwd); free(inv);
+    return rc;
+}
+
+static int mdct1_build_fft_form(mdct1_t *f)
+{
+    const int N = f->length;
+    f->fft_size = f->form == MDCT_FFT ? N : N >> 2;
+    if (f->form == MDCT_FFT) {
+        f->d_rot[ROT_FWD_PRE] = rot_table_upload(MDCT_FFT, ROT_FWD_PRE, N, N);
+        f->d_rot[ROT_FWD_POST] = rot_table_upload(MDCT_FFT, ROT_FWD_POST, N >> 1, N);
+        f->d_rot[ROT_INV_PRE] = rot_table_upload(MDCT_FFT, ROT_INV_PRE, N, N);
+        f->d_rot[ROT_INV_POST] = rot_table_upload(MDCT_FFT, ROT_INV_POST, N, N);
+    } else {
+        double *t = rot_table_upload(MDCT_FFT4, 0, N >> 2, N);          /* one table serves all four steps */
+        for (int s = 0; s < 4; s++) f->d_rot[s] = t;
+        f->norm = 1. / sqrt(N);
+    }
+    for (int s = 0; s < 4; s++)
+        if (!f->d_rot[s]) return LLZ_ERR_NOMEM;
+    const int F = f->fft_size;
+    double *cs = (double *)malloc(sizeof(double) * 2 * (size_t)F);
+    f->d_fft_cs = (double *)llzs_malloc(sizeof(double) * 2 * (size_t)F);
+    f->d_work = (double *)llzs_malloc(sizeof(double) * 2 * (size_t)F);
+    int rc = (cs && f->d_fft_cs && f->d_work) ? LLZ_OK : LLZ_ERR_NOMEM;
+    if (rc == LLZ_OK) {
+        for (int i = 0; i < F; i++) {
+            const double ang = (double)(2 * M_PI * i) / F;
+            cs[i] = cos(ang);
+            cs[F + i] = sin(ang);
+        }
+        rc = llzs_h2d(f->d_fft_cs, cs, sizeof(double) * 2 * (size_t)F, NULL);
+    }
+    free(cs);
+    return rc;
 }
 
 unsigned long llz_mdct_init(int type, int size)
@@ -92,9 +183,9 @@ unsigned long llz_mdct_init(int type, int size)
         llzs_set_error("llz_mdct_init: type %d len %d", type, size);
         return LLZ_BAD_HANDLE;
     }
-    int base = (int)(log(size) / log(2));                           /* llz_mdct.c:375-379 */
-    if ((1 << base) < size) base += 1;
-    const int length = 1 << base;
+    int log2len = (int)(log(size) / log(2));                        /* next power of two, as llz_mdct.c:375-379 */
+    if ((1 << log2len) < size) log2len += 1;
+    const int length = 1 << log2len;
     const int limit = type == MDCT_ORIGIN ? 2048 : (type == MDCT_FFT ? 4096 : 16384);
     if (length > limit || (type == MDCT_FFT4 && length < 8)) {
         llzs_set_error("llz_mdct_init: length %d out of range for type %d (at most %d)", length, type, limit);
@@ -102,72 +193,11 @@ unsigned long llz_mdct_init(int type, int size)
     }
     mdct1_t *f = (mdct1_t *)calloc(1, sizeof(*f));
     if (!f) return LLZ_BAD_HANDLE;
-    f->tag = LLZ_TAG_MDCT; f->type = type; f->length = length;
-    int rc = LLZ_OK;
-    if (type == MDCT_ORIGIN) {                                      /* llz_mdct.c:384-403 */
-        const size_t cnt = (size_t)(length >> 1) * length;
-        double *pos = (double *)malloc(sizeof(double) * cnt), *inv = (double *)malloc(sizeof(double) * cnt);
-        f->d_cos_pos = (double *)llzs_malloc(sizeof(double) * cnt);
-        f->d_cos_inv = (double *)llzs_malloc(sizeof(double) * cnt);
-        f->d_x = (double *)llzs_malloc(sizeof(double) * (size_t)length);
-        f->d_y = (double *)llzs_malloc(sizeof(double) * (size_t)length);
-        if (!pos || !inv || !f->d_cos_pos || !f->d_cos_inv || !f->d_x || !f->d_y) rc = LLZ_ERR_NOMEM;
-        if (rc == LLZ_OK) {
-            for (int k = 0; k < (length >> 1); k++)
-                for (int n = 0; n < length; n++) {
-                    const double tmp = (M_PI / (2 * length)) * (2 * n + 1 + (length >> 1)) * (2 * k + 1);
-                    pos[(size_t)k * length + n] = inv[(size_t)n * (length >> 1) + k] = cos(tmp);
-                }
-            rc = llzs_h2d(f->d_cos_pos, pos, sizeof(double) * cnt, NULL);
-            if (rc == LLZ_OK) rc = llzs_h2d(f->d_cos_inv, inv, sizeof(double) * cnt, NULL);
-        }
-        free(pos); free(inv);
-    } else if (type == MDCT_FFT) {                                  /* llz_mdct.c:404-448 */
-        const double n0 = ((double)length / 2 + 1) / 2;
-        f->h_fft = llz_fft_init(length);
-        f->fft_buf = (double *)malloc(sizeof(double) * (size_t)length * 2);
-        f->pre_c_pos = (double *)malloc(sizeof(double) * (size_t)length);
-        f->pre_s_pos = (double *)malloc(sizeof(double) * (size_t)length);
-        f->c_pos = (double *)malloc(sizeof(double) * (size_t)(length >> 1));
-        f->s_pos = (double *)malloc(sizeof(double) * (size_t)(length >> 1));
-        f->pre_c_inv = (double *)malloc(sizeof(double) * (size_t)length);
-        f->pre_s_inv = (double *)malloc(sizeof(double) * (size_t)length);
-        f->c_inv = (double *)malloc(sizeof(double) * (size_t)length);
-        f->s_inv = (double *)malloc(sizeof(double) * (size_t)length);
-        if (f->h_fft == LLZ_BAD_HANDLE || !f->fft_buf || !f->pre_c_pos || !f->pre_s_pos || !f->c_pos || !f->s_pos ||
-            !f->pre_c_inv || !f->pre_s_inv || !f->c_inv || !f->s_inv) rc = LLZ_ERR_NOMEM;
-        if (rc == LLZ_OK) {
-            for (int k = 0; k < length; k++) {
-                f->pre_c_pos[k] = cos(-(M_PI * k) / length);
-                f->pre_s_pos[k] = sin(-(M_PI * k) / length);
-            }
-            for (int k = 0; k < (length >> 1); k++) {
-                f->c_pos[k] = cos(-2 * M_PI * n0 * (k + 0.5) / length);
-                f->s_pos[k] = sin(-2 * M_PI * n0 * (k + 0.5) / length);
-            }
-            for (int k = 0; k < length; k++) {
-                f->pre_c_inv[k] = cos((2 * M_PI * k * n0) / length);
-                f->pre_s_inv[k] = sin((2 * M_PI * k * n0) / length);
-            }
-            for (int k = 0; k < length; k++) {
-                f->c_inv[k] = cos(M_PI * (k + n0) / length);
-                f->s_inv[k] = sin(M_PI * (k + n0) / length);
-            }
-        }
-    } else {                                                        /* llz_mdct.c:449-467 */
-        f->h_fft = llz_fft_init(length >> 2);
-        f->fft_buf = (double *)malloc(sizeof(double) * (size_t)(length >> 1));
-        f->sqrt_cof = 1. / sqrt(length);
-        f->rot = (double *)calloc((size_t)length, sizeof(double));
-        f->tw_c = (double *)malloc(sizeof(double) * (size_t)(length >> 2));
-        f->tw_s = (double *)malloc(sizeof(double) * (size_t)(length >> 2));
-        if (f->h_fft == LLZ_BAD_HANDLE || !f->fft_buf || !f->rot || !f->tw_c || !f->tw_s) rc = LLZ_ERR_NOMEM;
-        if (rc == LLZ_OK)
-            for (int k = 0; k < (length >> 2); k++) {
-                f->tw_c[k] = cos(-2 * M_PI * (k + 0.125) / length);
-                f->tw_s[k] = sin(-2 * M_PI * (k + 0.125) / length);
-            }
-    }
+    f->tag = LLZ_TAG_MDCT; f->form = type; f->length = length;
+    f->d_frame = (double *)llzs_malloc(sizeof(double) * (size_t)length);
+    f->d_bins = (double *)llzs_malloc(sizeof(double) * (size_t)length);
+    int rc = (f->d_frame && f->d_bins) ? LLZ_OK : LLZ_ERR_NOMEM;
+    if (rc == LLZ_OK) rc = type == MDCT_ORIGIN ? mdct1_build_sums(f) : mdct1_build_fft_form(f);
     if (rc != LLZ_OK) {
         mdct1_destroy(f);
         return LLZ_BAD_HANDLE;
@@ -180,12 +210,29 @@ void llz_mdct_uninit(unsigned long handle)
     if (LLZ_HANDLE_OK(handle, mdct1_t, LLZ_TAG_MDCT)) mdct1_destroy((mdct1_t *)handle);
 }
 
-/* the defining sums on the device: y[r] = sum_c x[c] * A[r][c] */
-static int mdct0_sums(mdct1_t *f, const double *d_A, const double *x, double *y, int rows, int cols)
+/* one direction of one frame, entirely on the device between the two copies */
+static int mdct1_run(mdct1_t *f, const double *src, double *dst, int inverse)
 {
-    int rc = llzs_h2d(f->d_x, x, sizeof(double) * (size_t)cols, NULL);
-    if (rc == LLZ_OK) rc = llzs_matvec_exact_f64(d_A, f->d_x, f->d_y, rows, cols, NULL);
-    if (rc == LLZ_OK) rc = llzs_d2h(y, f->d_y, sizeof(double) * (size_t)rows, NULL);
+    const int N = f->length, K = N >> 1;
+    const int n_src = inverse ? K : N, n_dst = inverse ? N : K;
+    double *d_src = inverse ? f->d_bins : f->d_frame, *d_dst = inverse ? f->d_frame : f->d_bins;
+    int rc = llzs_h2d(d_src, src, sizeof(double) * (size_t)n_src, NULL);
+    if (rc != LLZ_OK) return rc;
+    if (f->form == MDCT_ORIGIN) {                                    /* llz_mdct.c:185-222: the defining sums */
+        rc = llzs_matvec_exact_f64(inverse ? f->d_sum_inv : f->d_sum_fwd, d_src, d_dst, n_dst, n_src, NULL);
+    } else {
+        const int quarter = f->form == MDCT_FFT4;
+        /* the N-point form inverts with the inverse transform (llz_mdct.c:258); the N/4-point form uses the FORWARD
+         * transform in both directions (llz_mdct.c:291, :328) */
+        const int fft_inverse = inverse && !quarter;
+        rc = llzs_mdct_rot_f64(quarter, 0, d_src, f->d_work, f->d_rot[inverse ? ROT_INV_PRE : ROT_FWD_PRE], N, inverse,
+                               f->norm, NULL);
+        if (rc == LLZ_OK) rc = llzs_fft_f64(f->d_work, f->fft_size, f->d_fft_cs, fft_inverse, NULL);
+        if (rc == LLZ_OK)
+            rc = llzs_mdct_rot_f64(quarter, 1, f->d_work, d_dst, f->d_rot[inverse ? ROT_INV_POST : ROT_FWD_POST], N,
+                                   inverse, f->norm, NULL);
+    }
+    if (rc == LLZ_OK) rc = llzs_d2h(dst, d_dst, sizeof(double) * (size_t)n_dst, NULL);
     return rc;
 }
 
@@ -195,36 +242,7 @@ void llz_mdct(unsigned long handle, double *x, double *X)
         llzs_set_error("llz_mdct: bad handle or arguments");
         return;                                                     /* void in the reference ABI */
     }
-    mdct1_t *f = (mdct1_t *)handle;
-    const int N = f->length, N2 = N >> 1, N4 = N >> 2;
-    if (f->type == MDCT_ORIGIN) {                                   /* llz_mdct.c:185-202 */
-        (void)mdct0_sums(f, f->d_cos_pos, x, X, N2, N);
-    } else if (f->type == MDCT_FFT) {                               /* llz_mdct.c:225-241 */
-        for (int k = 0; k < N; k++) {
-            f->fft_buf[k + k] = x[k] * f->pre_c_pos[k];
-            f->fft_buf[k + k + 1] = x[k] * f->pre_s_pos[k];
-        }
-        llz_fft(f->h_fft, f->fft_buf);
-        for (int k = 0; k < N2; k++)
-            X[k] = f->fft_buf[k + k] * f->c_pos[k] - f->fft_buf[k + k + 1] * f->s_pos[k];
-    } else {                                                        /* llz_mdct.c:266-303 */
-        double *rot = f->rot;
-        memset(rot, 0, sizeof(double) * (size_t)f->length);
-        for (int k = 0; k < N4; k++) rot[k] = -x[k + 3 * N4];
-        for (int k = N4; k < N; k++) rot[k] = x[k - N4];
-        for (int k = 0; k < N4; k++) {
-            const double re = rot[2 * k] - rot[N - 1 - 2 * k];
-            const double im = rot[N2 - 1 - 2 * k] - rot[N2 + 2 * k];
-            f->fft_buf[k + k] = 0.5 * (re * f->tw_c[k] - im * f->tw_s[k]);
-            f->fft_buf[k + k + 1] = 0.5 * (re * f->tw_s[k] + im * f->tw_c[k]);
-        }
-        llz_fft(f->h_fft, f->fft_buf);
-        for (int k = 0; k < N4; k++) {
-            const double re = f->fft_buf[k + k], im = f->fft_buf[k + k + 1];
-            X[2 * k] = 2 * (re * f->tw_c[k] - im * f->tw_s[k]);
-            X[N2 - 1 - 2 * k] = -2 * (re * f->tw_s[k] + im * f->tw_c[k]);
-        }
-    }
+    (void)mdct1_run((mdct1_t *)handle, x, X, 0);
 }
 
 void llz_imdct(unsigned long handle, double *X, double *x)
@@ -234,45 +252,9 @@ void llz_imdct(unsigned long handle, double *X, double *x)
         return;
     }
     mdct1_t *f = (mdct1_t *)handle;
-    const int N = f->length, N2 = N >> 1, N4 = N >> 2;
-    if (f->type == MDCT_ORIGIN) {                                   /* llz_mdct.c:204-222 */
-        if (mdct0_sums(f, f->d_cos_inv, X, x, N, N2) == LLZ_OK)
-            for (int n = 0; n < N; n++) x[n] = (x[n] * 4) / N;
-    } else if (f->type == MDCT_FFT) {                               /* llz_mdct.c:243-264 */
-        for (int k = 0; k < N2; k++) {
-            f->fft_buf[k + k] = X[k] * f->pre_c_inv[k];
-            f->fft_buf[k + k + 1] = X[k] * f->pre_s_inv[k];
-        }
-        for (int k = N2, i = N2 - 1; k < N; k++, i--) {
-            f->fft_buf[k + k] = -X[i] * f->pre_c_inv[k];
-            f->fft_buf[k + k + 1] = -X[i] * f->pre_s_inv[k];
-        }
-        llz_ifft(f->h_fft, f->fft_buf);
-        for (int k = 0; k < N; k++)
-            x[k] = 2 * (f->fft_buf[k + k] * f->c_inv[k] - f->fft_buf[k + k + 1] * f->s_inv[k]);
-    } else {                                                        /* llz_mdct.c:305-353 (a forward llz_fft here too) */
-        double *rot = f->rot;
-        const double cof = f->sqrt_cof;
-        memset(rot, 0, sizeof(double) * (size_t)f->length);
-        for (int k = 0; k < N4; k++) {
-            const double re = X[2 * k], im = X[N2 - 1 - 2 * k];
-            f->fft_buf[k + k] = 0.5 * (re * f->tw_c[k] - im * f->tw_s[k]);
-            f->fft_buf[k + k + 1] = 0.5 * (re * f->tw_s[k] + im * f->tw_c[k]);
-        }
-        llz_fft(f->h_fft, f->fft_buf);
-        for (int k = 0; k < N4; k++) {
-            const double re = f->fft_buf[k + k], im = f->fft_buf[k + k + 1];
-            f->fft_buf[k + k] = 8 * cof * (re * f->tw_c[k] - im * f->tw_s[k]);
-            f->fft_buf[k + k + 1] = 8 * cof * (re * f->tw_s[k] + im * f->tw_c[k]);
-        }
-        for (int k = 0; k < N4; k++) {
-            rot[2 * k] = f->fft_buf[k + k];
-            rot[N2 + 2 * k] = f->fft_buf[k + k + 1];
-        }
-        for (int k = 1; k < N; k += 2) rot[k] = -rot[N - 1 - k];
-        for (int k = 0; k < 3 * N4; k++) x[k] = rot[N4 + k] * cof;
-        for (int k = 3 * N4; k < N; k++) x[k] = -rot[k - 3 * N4] * cof;
-    }
+    if (mdct1_run(f, X, x, 1) != LLZ_OK) return;
+    if (f->form == MDCT_ORIGIN)                                     /* llz_mdct.c:219-220: (sum * 4) / N, two roundings */
+        for (int n = 0; n < f->length; n++) x[n] = (x[n] * 4) / f->length;
 }
 
 /* ---- Part 2: batch extension ---- */

@@ -263,6 +263,7 @@ typedef struct {
     int cur;
     long long in_count, out_count;   /* samples consumed / produced per channel so far */
     void *stream;
+    int device;                 /* the device the handle's buffers live on: every call binds it */
     llz_stage_t st_in, st_out;
 } rsm_t;
 
@@ -282,11 +283,11 @@ static int rsm_upload_matrix(rsm_t *r)
 {
     const size_t count = (size_t)r->L * r->Q;
     if (r->fmt == LLZ_PCM_I16)
-        return llzs_h2d(r->d_mat, r->taps.mat, sizeof(double) * count, NULL);
+        return llzs_h2d_table(r->d_mat, r->taps.mat, sizeof(double) * count);
     float *m32 = (float *)malloc(sizeof(float) * count);
     if (!m32) return LLZ_ERR_NOMEM;
     for (size_t i = 0; i < count; i++) m32[i] = (float)r->taps.mat[i];
-    int rc = llzs_h2d(r->d_mat, m32, sizeof(float) * count, NULL);
+    int rc = llzs_h2d_table(r->d_mat, m32, sizeof(float) * count);
     if (rc == LLZ_OK && r->L == 1) {
         r->use_mfma = llzs_fir_mfma_f32_fits(r->Q, r->M) && llzs_tune(LLZS_TUNE_RS_DEC_VALU) != 1;
         /* phase taps for the decimator fast path: gp[m][j] = g[0][j*M + m], rows zero padded to tp */
@@ -297,7 +298,7 @@ static int rsm_upload_matrix(rsm_t *r)
             if (!gp) { free(m32); return LLZ_ERR_NOMEM; }
             for (int k = 0; k < r->Q; k++) gp[(size_t)(k % r->M) * r->tp + k / r->M] = m32[k];
             if (!r->d_phase) r->d_phase = (float *)llzs_malloc(sizeof(float) * (size_t)r->M * r->tp);
-            rc = r->d_phase ? llzs_h2d(r->d_phase, gp, sizeof(float) * (size_t)r->M * r->tp, NULL) : LLZ_ERR_NOMEM;
+            rc = r->d_phase ? llzs_h2d_table(r->d_phase, gp, sizeof(float) * (size_t)r->M * r->tp) : LLZ_ERR_NOMEM;
             free(gp);
         }
     }
@@ -324,6 +325,7 @@ unsigned long llz_resample_mc_init(int channels, int L, int M, double gain, win_
     rsm_t *r = (rsm_t *)calloc(1, sizeof(*r));
     if (!r) return LLZ_BAD_HANDLE;
     r->tag = LLZ_TAG_RSM;
+    r->device = llzs_device_get();
     r->channels = channels; r->L = L; r->M = M; r->fmt = pcm_format; r->gain = gain;
     const double fc = (1. / L < 1. / M) ? 1. / L : 1. / M;
     int rc = tapmat_build(&r->taps, L, M, fc, L, win_type);
@@ -353,8 +355,10 @@ unsigned long llz_resample_mc_init(int channels, int L, int M, double gain, win_
 void llz_resample_mc_uninit(unsigned long handle)
 {
     if (LLZ_HANDLE_OK(handle, rsm_t, LLZ_TAG_RSM)) {
+        const int prev = llzs_device_enter(((rsm_t *)handle)->device);
         llzs_sync(((rsm_t *)handle)->stream);
         rsm_destroy((rsm_t *)handle);
+        llzs_device_leave(prev);
     }
 }
 
@@ -403,10 +407,14 @@ int llz_resample_mc_set_matrix(unsigned long handle, const double *src, int coun
         return LLZ_ERR_ARG;
     }
     memcpy(r->taps.mat, src, sizeof(double) * (size_t)count);
+    const int prev = llzs_device_enter(r->device);
     int rc = llzs_sync(r->stream);
     if (rc == LLZ_OK) rc = rsm_upload_matrix(r);
+    llzs_device_leave(prev);
     return rc;
 }
+
+static long rsm_process(rsm_t *r, unsigned long handle, const void *in, long n_in, void *out);
 
 long llz_resample_mc(unsigned long handle, const void *in, long n_in, void *out)
 {
@@ -415,6 +423,14 @@ long llz_resample_mc(unsigned long handle, const void *in, long n_in, void *out)
         return LLZ_ERR_ARG;
     }
     rsm_t *r = (rsm_t *)handle;
+    const int prev = llzs_device_enter(r->device);
+    const long rc = rsm_process(r, handle, in, n_in, out);
+    llzs_device_leave(prev);
+    return rc;
+}
+
+static long rsm_process(rsm_t *r, unsigned long handle, const void *in, long n_in, void *out)
+{
     const long n_out = llz_resample_mc_out_len(handle, n_in);
     if (n_out < 1) return LLZ_ERR_ARG;
     /* calls must start on an L/M period boundary so that (i*M)/L stays exact across calls */

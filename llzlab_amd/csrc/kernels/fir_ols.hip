@@ -22,15 +22,11 @@
 //       k_fir_ols_walk_f32   one segment after the other (batches that fit one round of the grid)
 //       k_fir_ols_chain_f32  the prefetch is carried ACROSS segments: the last job of a segment requests the first job
 //                            and the halo of the half-wave's next segment (large batches: the headline)
-//   * HBM access shape (template parameter IO):
-//       IO_WIDE   8 bytes per lane, every wave instruction moves 512 CONTIGUOUS bytes of one job: lane (q = lane % 16,
-//                 i = lane / 16) takes columns 2q, 2q+1 of row 4m+i of the wave's lower-half job and, in a second
-//                 instruction, of its upper-half job.  A 4 x 4 transpose between the lane's quarter and four
-//                 registers (two v_permlane16_swap + two v_permlane32_swap, gfx950) then hands every sample to the
-//                 lane that transforms it: +96 vector instructions per job pair (~4 %) for accesses four times as
-//                 long as the first form's.
-//       IO_DWORD  one dword per lane, a half-wave instruction moves 128 contiguous bytes of its own job (the first
-//                 form; rows that are not 8-byte aligned, and the ragged first / last jobs of any row, use it)
+//   * HBM access shape: one dword per lane, a half-wave instruction moves 128 contiguous bytes of its job.  Wider shapes
+//     were built and measured and do not pay (profiles/r02/): a copy kernel in exactly this walk structure runs at the same
+//     rate with 4, 8 or 16 bytes per lane (6.04 / 6.02 / 6.02 ms for 32 GiB), and an 8-byte form of this kernel (512
+//     contiguous bytes per wave instruction, samples handed to their lanes by v_permlane16/32_swap transposes, commit
+//     cda1552) was 7 % slower: the 96 extra vector instructions per job pair cost more than the shorter request stream saves.
 //   * per workgroup (4 waves): LDS = 8 KB inter-pass twiddles W_1024^(a*b) + 8 KB filter spectrum + 8 x 4.1 KB
 //     transpose buffers = 49 KB; two workgroups per CU (the prefetch registers allow two waves per SIMD).
 // HBM traffic: 4 B read + 4 B written per sample, nothing re-read (PMC: profiles/pmc_traffic.json).
@@ -48,25 +44,16 @@ constexpr int OLS_WAVES = 4;
 constexpr int OLS_THREADS = 64 * OLS_WAVES;
 constexpr int OLS_SEG = 16;                        // jobs per segment at most (16 x 1536 samples of one channel)
 
-constexpr int IO_DWORD = 1, IO_WIDE = 2;
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// where a lane sits: which of the wave's two jobs it transforms, which column of the 32 x 32 decomposition it owns, and
-// (wide form) which 8-byte column pair q and row-in-group i it moves between HBM and registers
+// where a lane sits: which of the wave's two jobs it transforms and which column of the 32 x 32 decomposition it owns
 struct ols_lane {
-    int half, col, q, i;
+    int half, col;
 };
 
-template <int IO>
 __device__ __forceinline__ ols_lane ols_lane_of(int lane)
 {
     ols_lane g;
     g.half = lane >> 5;
-    g.q = lane & 15;
-    g.i = lane >> 4;
-    // wide form: after the quarter transpose lane (q, i) holds column 2q + (i & 1) of job i >> 1
-    g.col = IO == IO_WIDE ? 2 * (lane & 15) + ((lane >> 4) & 1) : (lane & 31);
+    g.col = lane & 31;
     return g;
 }
 
@@ -91,53 +78,18 @@ __device__ __forceinline__ ols_seg ols_locate(long seg, const ols_geom &G)
     return g;
 }
 
-// the 1536 new samples of a job pair as they arrive: 48 registers per lane.  direct = false: wide layout (a[4m + c]:
-// c = 0, 1 columns 2q, 2q+1 of row 4m+i of the lower job's block A, c = 2, 3 the same of the upper job; b: block B),
-// to be transposed; direct = true: a[r] / b[r] = row r of this lane's own job and column already
+// the 1536 new samples of a job, 48 registers per lane: a[r] / b[r] = row r of block A's / block B's new part, this
+// lane's column
 struct ols_raw {
     float a[24], b[24];
 };
 
-// 4 x 4 transpose between the lane's quarter (lane bits 4, 5) and four registers:
-// new (quarter i, register c) = old (quarter c, register i)
-__device__ __forceinline__ void quarter_transpose(float &r0, float &r1, float &r2, float &r3)
-{
-    auto sw16 = [](float &x, float &y) {
-        const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-        x = __uint_as_float(p[0]);
-        y = __uint_as_float(p[1]);
-    };
-    auto sw32 = [](float &x, float &y) {
-        const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-        x = __uint_as_float(p[0]);
-        y = __uint_as_float(p[1]);
-    };
-    sw16(r0, r1); sw16(r2, r3);            // lane bit 4 <-> register bit 0
-    sw32(r0, r2); sw32(r1, r3);            // lane bit 5 <-> register bit 1
-}
-
-// request the 1536 new samples of the wave's two jobs (job h: row[h] + s[h], h = 0 lower / 1 upper half-wave).
-// Returns `direct` (wave-uniform): whether the registers already are in the transform layout.
-template <int IO>
-__device__ __forceinline__ bool ols_load(ols_raw &raw, const float *const (&row)[2], const int (&s)[2],
+// request the 1536 new samples of the wave's two jobs (job h: row[h] + s[h], h = 0 lower / 1 upper half-wave); every
+// lane takes its own job's column
+__device__ __forceinline__ void ols_load(ols_raw &raw, const float *const (&row)[2], const int (&s)[2],
                                          const bool (&live)[2], const ols_lane &g, int n)
 {
     const bool whole = live[0] && live[1] && s[0] + OLS_JOB <= n && s[1] + OLS_JOB <= n;   // wave-uniform
-    if (IO == IO_WIDE && whole) {
-        const float *p0 = row[0] + s[0] + 32 * g.i + 2 * g.q;
-        const float *p1 = row[1] + s[1] + 32 * g.i + 2 * g.q;
-#pragma unroll
-        for (int m = 0; m < 6; m++) {
-            const f32x2 xa = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(p0 + 128 * m));
-            const f32x2 ya = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(p1 + 128 * m));
-            const f32x2 xb = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(p0 + OLS_VALID + 128 * m));
-            const f32x2 yb = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(p1 + OLS_VALID + 128 * m));
-            raw.a[4 * m] = xa.x; raw.a[4 * m + 1] = xa.y; raw.a[4 * m + 2] = ya.x; raw.a[4 * m + 3] = ya.y;
-            raw.b[4 * m] = xb.x; raw.b[4 * m + 1] = xb.y; raw.b[4 * m + 2] = yb.x; raw.b[4 * m + 3] = yb.y;
-        }
-        return false;
-    }
-    // this lane's own job and column, one dword per lane
     const float *r = g.half ? row[1] : row[0];
     const int so = g.half ? s[1] : s[0];
     const bool lv = g.half ? live[1] : live[0];
@@ -155,18 +107,6 @@ __device__ __forceinline__ bool ols_load(ols_raw &raw, const float *const (&row)
             const float xa = r[min(ia, n - 1)], xb = r[min(ib, n - 1)];
             raw.a[i] = (lv && ia < n) ? xa : 0.f;
             raw.b[i] = (lv && ib < n) ? xb : 0.f;
-        }
-    }
-    return true;
-}
-
-__device__ __forceinline__ void ols_raw_to_rows(ols_raw &raw, bool direct)
-{
-    if (!direct) {
-#pragma unroll
-        for (int m = 0; m < 6; m++) {
-            quarter_transpose(raw.a[4 * m], raw.a[4 * m + 1], raw.a[4 * m + 2], raw.a[4 * m + 3]);
-            quarter_transpose(raw.b[4 * m], raw.b[4 * m + 1], raw.b[4 * m + 2], raw.b[4 * m + 3]);
         }
     }
 }
@@ -210,28 +150,10 @@ __device__ __forceinline__ void ols_filter(cf (&v)[32], cf (&u)[32], float *buf,
 }
 
 // keep the 768 valid samples of each block: rows n1 = brev5(r) >= 8
-template <int IO>
 __device__ __forceinline__ void ols_store(const cf (&u)[32], float *const (&orow)[2], const int (&s)[2],
                                           const bool (&live)[2], const ols_lane &g, int n)
 {
     const bool whole = live[0] && live[1] && s[0] + OLS_JOB <= n && s[1] + OLS_JOB <= n;   // wave-uniform
-    if (IO == IO_WIDE && whole) {
-        float *p0 = orow[0] + s[0] - OLS_OVERLAP + 32 * g.i + 2 * g.q;
-        float *p1 = orow[1] + s[1] - OLS_OVERLAP + 32 * g.i + 2 * g.q;
-#pragma unroll
-        for (int m = 2; m < 8; m++) {
-            float a0 = u[brev5(4 * m)].x, a1 = u[brev5(4 * m + 1)].x, a2 = u[brev5(4 * m + 2)].x, a3 = u[brev5(4 * m + 3)].x;
-            float b0 = u[brev5(4 * m)].y, b1 = u[brev5(4 * m + 1)].y, b2 = u[brev5(4 * m + 2)].y, b3 = u[brev5(4 * m + 3)].y;
-            quarter_transpose(a0, a1, a2, a3);
-            quarter_transpose(b0, b1, b2, b3);
-            f32x2 t;
-            t.x = a0; t.y = a1; __builtin_nontemporal_store(t, reinterpret_cast<f32x2 *>(p0 + 128 * m));
-            t.x = a2; t.y = a3; __builtin_nontemporal_store(t, reinterpret_cast<f32x2 *>(p1 + 128 * m));
-            t.x = b0; t.y = b1; __builtin_nontemporal_store(t, reinterpret_cast<f32x2 *>(p0 + OLS_VALID + 128 * m));
-            t.x = b2; t.y = b3; __builtin_nontemporal_store(t, reinterpret_cast<f32x2 *>(p1 + OLS_VALID + 128 * m));
-        }
-        return;
-    }
     const bool lv = g.half ? live[1] : live[0];
     if (!lv) return;
     float *o = g.half ? orow[1] : orow[0];
@@ -298,7 +220,6 @@ __device__ __forceinline__ ols_smem ols_tables(char *smem, const float2 *__restr
 // Walk form: a half-wave runs one segment after the other (grid stride); inside a segment the next job is requested one job
 // ahead.  The request issued during a segment's last job runs past the segment's end and is discarded on purpose (skipping
 // it with a wave-uniform branch measured 8 % slower); the chain form below turns it into the next segment's first job.
-template <int IO>
 __global__ void __launch_bounds__(OLS_THREADS, 2)
 k_fir_ols_walk_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
                    const float2 *__restrict__ hfreq, const float2 *__restrict__ twid, ols_geom G)
@@ -308,7 +229,7 @@ k_fir_ols_walk_f32(const float *__restrict__ in, float *__restrict__ out, const 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l5 = lane & 31;
-    const ols_lane g = ols_lane_of<IO>(lane);
+    const ols_lane g = ols_lane_of(lane);
     const long halves_total = (long)gridDim.x * OLS_WAVES * 2;
     const long first = ((long)blockIdx.x * OLS_WAVES + wave) * 2;          // this wave's first segment pair
 
@@ -323,11 +244,10 @@ k_fir_ols_walk_f32(const float *__restrict__ in, float *__restrict__ out, const 
         ols_load_halo(halo, orow_in, hist ? hist + (size_t)own.c * G.keep : nullptr, own.j0 * OLS_JOB, g.col, G.keep,
                       own.live);
         ols_raw raw;
-        bool direct;
         {
             const int s0[2] = {sg[0].j0 * OLS_JOB, sg[1].j0 * OLS_JOB};
             const bool lv[2] = {sg[0].count > 0, sg[1].count > 0};
-            direct = ols_load<IO>(raw, row, s0, lv, g, G.n);
+            ols_load(raw, row, s0, lv, g, G.n);
         }
         const int jmax = max(sg[0].count, sg[1].count);
 #pragma unroll 1
@@ -335,15 +255,14 @@ k_fir_ols_walk_f32(const float *__restrict__ in, float *__restrict__ out, const 
             const int s[2] = {(sg[0].j0 + jj) * OLS_JOB, (sg[1].j0 + jj) * OLS_JOB};
             const bool live[2] = {jj < sg[0].count, jj < sg[1].count};
             cf v[32], u[32];
-            ols_raw_to_rows(raw, direct);
             ols_assemble(v, halo, raw);
             {
                 const int sn[2] = {s[0] + OLS_JOB, s[1] + OLS_JOB};
                 const bool ln[2] = {jj + 1 < sg[0].count, jj + 1 < sg[1].count};
-                direct = ols_load<IO>(raw, row, sn, ln, g, G.n);
+                ols_load(raw, row, sn, ln, g, G.n);
             }
             ols_filter(v, u, S.buf, S.tw, S.h, l5, g.col);
-            ols_store<IO>(u, orow, s, live, g, G.n);
+            ols_store(u, orow, s, live, g, G.n);
         }
     }
 }
@@ -351,7 +270,6 @@ k_fir_ols_walk_f32(const float *__restrict__ in, float *__restrict__ out, const 
 // Chain form: the walk form with the prefetch carried ACROSS segments.  The last job of a segment requests the first job and
 // the halo of the half-wave's NEXT segment, so every load is used and no segment start waits on memory.  Both halves of
 // a wave step through their segments together (a segment that is short at the end of a channel idles its tail).
-template <int IO>
 __global__ void __launch_bounds__(OLS_THREADS, 2)
 k_fir_ols_chain_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
                     const float2 *__restrict__ hfreq, const float2 *__restrict__ twid, ols_geom G)
@@ -361,14 +279,13 @@ k_fir_ols_chain_f32(const float *__restrict__ in, float *__restrict__ out, const
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l5 = lane & 31;
-    const ols_lane g = ols_lane_of<IO>(lane);
+    const ols_lane g = ols_lane_of(lane);
     const long halves_total = (long)gridDim.x * OLS_WAVES * 2;
     const long first = ((long)blockIdx.x * OLS_WAVES + wave) * 2;
 
     ols_seg cur[2] = {ols_locate(first, G), ols_locate(first + 1, G)};
     float halo[8];
     ols_raw raw;
-    bool direct;
     {
         const float *const row[2] = {in + (size_t)cur[0].c * G.in_pitch, in + (size_t)cur[1].c * G.in_pitch};
         const ols_seg own = g.half ? cur[1] : cur[0];
@@ -376,7 +293,7 @@ k_fir_ols_chain_f32(const float *__restrict__ in, float *__restrict__ out, const
                       g.col, G.keep, own.live);
         const int s0[2] = {cur[0].j0 * OLS_JOB, cur[1].j0 * OLS_JOB};
         const bool lv[2] = {cur[0].count > 0, cur[1].count > 0};
-        direct = ols_load<IO>(raw, row, s0, lv, g, G.n);
+        ols_load(raw, row, s0, lv, g, G.n);
     }
     for (long sp = first; sp < G.total_segs; sp += halves_total) {
         const ols_seg nxt[2] = {ols_locate(sp + halves_total, G), ols_locate(sp + halves_total + 1, G)};
@@ -394,7 +311,6 @@ k_fir_ols_chain_f32(const float *__restrict__ in, float *__restrict__ out, const
             const int s[2] = {(cur[0].j0 + jj) * OLS_JOB, (cur[1].j0 + jj) * OLS_JOB};
             const bool live[2] = {jj < cur[0].count, jj < cur[1].count};
             cf v[32], u[32];
-            ols_raw_to_rows(raw, direct);
             ols_assemble(v, halo, raw);
             // next job of this segment pair, or (after the pair's last job) the first jobs and halos of the next pair.  A
             // half whose own segment has ended while its partner's has not requests nothing.
@@ -405,13 +321,13 @@ k_fir_ols_chain_f32(const float *__restrict__ in, float *__restrict__ out, const
                                    in_pair ? s[1] + OLS_JOB : nxt[1].j0 * OLS_JOB};
                 const bool ln[2] = {in_pair ? jj + 1 < cur[0].count : nxt[0].count > 0,
                                     in_pair ? jj + 1 < cur[1].count : nxt[1].count > 0};
-                direct = ols_load<IO>(raw, lrow, sn, ln, g, G.n);
+                ols_load(raw, lrow, sn, ln, g, G.n);
             }
             if (!in_pair)
                 ols_load_halo(halo_n, g.half ? nrow[1] : nrow[0], hist ? hist + (size_t)nown.c * G.keep : nullptr,
                               nown.j0 * OLS_JOB, g.col, G.keep, nown.live);
             ols_filter(v, u, S.buf, S.tw, S.h, l5, g.col);
-            ols_store<IO>(u, orow, s, live, g, G.n);
+            ols_store(u, orow, s, live, g, G.n);
         }
         cur[0] = nxt[0];
         cur[1] = nxt[1];
@@ -468,20 +384,12 @@ extern "C" int llzs_fir_ols_f32(const float *in, float *out, const float *hist, 
     // 63 taps: 0.14 vs 0.16 ms)
     const int tuned_chain = llzs_tune(LLZS_TUNE_OLS_CHAIN);
     const bool chain = tuned_chain >= 0 ? tuned_chain == 1 : large;
-    // 8-byte accesses need 8-byte aligned rows
-    const bool even = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 7) == 0 &&
-                      ((in_pitch | out_pitch) & 1) == 0;
-    const bool wide = even && llzs_tune(LLZS_TUNE_OLS_IO) != IO_DWORD;
     const float2 *hf = reinterpret_cast<const float2 *>(hfreq), *tw = reinterpret_cast<const float2 *>(twid);
     const dim3 grid((unsigned)blocks), block(OLS_THREADS);
-    if (chain && wide)
-        hipLaunchKernelGGL(k_fir_ols_chain_f32<IO_WIDE>, grid, block, lds_bytes, as_stream(stream), in, out, hist, hf, tw, G);
-    else if (chain)
-        hipLaunchKernelGGL(k_fir_ols_chain_f32<IO_DWORD>, grid, block, lds_bytes, as_stream(stream), in, out, hist, hf, tw, G);
-    else if (wide)
-        hipLaunchKernelGGL(k_fir_ols_walk_f32<IO_WIDE>, grid, block, lds_bytes, as_stream(stream), in, out, hist, hf, tw, G);
+    if (chain)
+        hipLaunchKernelGGL(k_fir_ols_chain_f32, grid, block, lds_bytes, as_stream(stream), in, out, hist, hf, tw, G);
     else
-        hipLaunchKernelGGL(k_fir_ols_walk_f32<IO_DWORD>, grid, block, lds_bytes, as_stream(stream), in, out, hist, hf, tw, G);
+        hipLaunchKernelGGL(k_fir_ols_walk_f32, grid, block, lds_bytes, as_stream(stream), in, out, hist, hf, tw, G);
     LLZ_LAUNCH_CHECK("k_fir_ols_f32");
     return LLZ_OK;
 }

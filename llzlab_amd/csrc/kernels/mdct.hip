@@ -3,6 +3,11 @@
 //  k_matvec_exact_f64   y[r] = sum_c x[c] * A[r][c] in ascending c with a rounded multiply and a rounded add per term:
 //                       the defining sums of the reference's MDCT_ORIGIN type (mdct0 / imdct0, llz_mdct.c:185-222) in the
 //                       reference's operation order, one lane per output (bit-identical; exists for parity, not speed).
+//  k_mdct_rot_*_f64     the twiddle steps of the reference's two FFT forms (mdct1 / imdct1 around an N-point transform,
+//                       mdct2 / imdct2 around an N/4-point one, llz_mdct.c:225-353) in double with the reference's
+//                       rounding order (every product and every sum rounded, no contraction), one lane per output:
+//                       together with the exact-order transform (fft.hip) the whole single-channel MDCT runs on the
+//                       device and stays bit-identical.
 //  k_mdct4_f32          the N/4-point-FFT algorithm (mdct2 / imdct2, llz_mdct.c:266-353) for many frames at once in
 //                       float32: rotate + pre-twiddle into LDS, the shared float32 FFT passes, post-twiddle, and the
 //                       output permutation staged through LDS so that HBM sees contiguous rows on both sides.
@@ -37,6 +42,101 @@ k_matvec_q15(const short *__restrict__ A, const int *__restrict__ x, int *__rest
     unsigned acc = 0;
     for (int c = 0; c < cols; c++) acc += (unsigned)(int)(((long long)x[c] * (long long)row[c]) >> 15);
     y[r] = (int)acc;
+}
+
+
+// ---- exact-order twiddle steps of the FFT forms (double, one frame) ----------------------------------------------------
+// Tables are (cos, sin) pairs.  "N-point form" (llz_mdct.c:225-264): pre = modulate the frame into N complex points, post =
+// rotate each bin and keep the real part.  "quarter form" (llz_mdct.c:266-353): pre = fold the frame into N/4 complex
+// points and rotate, post = rotate and scatter.
+__global__ void __launch_bounds__(256)
+k_mdct_rot_full_pre_f64(const double *__restrict__ in, double *__restrict__ z, const double *__restrict__ cs2, int N,
+                        int inverse)
+{
+#pragma clang fp contract(off)
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= N) return;
+    // forward: point k = x[k] * (c, s)[k];  inverse: the N/2 coefficients extended by odd symmetry, X[k] for k < N/2 and
+    // -X[N-1-k] above
+    double v;
+    if (!inverse) v = in[k];
+    else v = k < (N >> 1) ? in[k] : -in[N - 1 - k];
+    z[2 * k] = v * cs2[2 * k];
+    z[2 * k + 1] = v * cs2[2 * k + 1];
+}
+
+__global__ void __launch_bounds__(256)
+k_mdct_rot_full_post_f64(const double *__restrict__ z, double *__restrict__ out, const double *__restrict__ cs2, int N,
+                         int inverse)
+{
+#pragma clang fp contract(off)
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= (inverse ? N : (N >> 1))) return;
+    const double a = z[2 * k] * cs2[2 * k];
+    const double b = z[2 * k + 1] * cs2[2 * k + 1];
+    const double d = a - b;
+    out[k] = inverse ? 2 * d : d;
+}
+
+__device__ __forceinline__ void mdct_quarter_rotate(double re, double im, double c, double s, double scale, double *zr,
+                                                    double *zi)
+{
+#pragma clang fp contract(off)
+    const double p = re * c, q = im * s, u = re * s, w = im * c;
+    const double dr = p - q, di = u + w;
+    *zr = scale * dr;
+    *zi = scale * di;
+}
+
+__global__ void __launch_bounds__(256)
+k_mdct_rot_quarter_pre_f64(const double *__restrict__ in, double *__restrict__ z, const double *__restrict__ cs2, int N,
+                           int inverse)
+{
+#pragma clang fp contract(off)
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int N2 = N >> 1, N4 = N >> 2;
+    if (k >= N4) return;
+    double re, im;
+    if (!inverse) {
+        // the frame rotated by N/4 with its last quarter negated in front, folded onto N/4 points
+        auto rotated = [&](int i) { return i < N4 ? -in[i + 3 * N4] : in[i - N4]; };
+        re = rotated(2 * k) - rotated(N - 1 - 2 * k);
+        im = rotated(N2 - 1 - 2 * k) - rotated(N2 + 2 * k);
+    } else {
+        re = in[2 * k];
+        im = in[N2 - 1 - 2 * k];
+    }
+    mdct_quarter_rotate(re, im, cs2[2 * k], cs2[2 * k + 1], 0.5, &z[2 * k], &z[2 * k + 1]);
+}
+
+// forward: out = X [N/2]; inverse: out = x [N], one lane per time sample
+__global__ void __launch_bounds__(256)
+k_mdct_rot_quarter_post_f64(const double *__restrict__ z, double *__restrict__ out, const double *__restrict__ cs2, int N,
+                            int inverse, double cof)
+{
+#pragma clang fp contract(off)
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int N2 = N >> 1, N4 = N >> 2;
+    if (!inverse) {
+        if (t >= N4) return;
+        double zr, zi;
+        mdct_quarter_rotate(z[2 * t], z[2 * t + 1], cs2[2 * t], cs2[2 * t + 1], 1.0, &zr, &zi);   // x 1.0 is exact
+        out[2 * t] = 2 * zr;
+        out[N2 - 1 - 2 * t] = -2 * zi;
+        return;
+    }
+    if (t >= N) return;
+    // the rotated sequence r: r[2m] = Re w[m], r[N/2 + 2m] = Im w[m] (w = 8 cof times the rotated bins), odd entries by
+    // r[i] = -r[N-1-i]; the frame is r shifted back by N/4 with the wrapped quarter negated, times cof
+    const double scale = 8 * cof;
+    auto r_even = [&](int i) {                                  // i even
+        const int m = i < N2 ? i >> 1 : (i - N2) >> 1;
+        double zr, zi;
+        mdct_quarter_rotate(z[2 * m], z[2 * m + 1], cs2[2 * m], cs2[2 * m + 1], scale, &zr, &zi);
+        return i < N2 ? zr : zi;
+    };
+    auto r_at = [&](int i) { return (i & 1) ? -r_even(N - 1 - i) : r_even(i); };
+    out[t] = t < 3 * N4 ? r_at(N4 + t) * cof : -r_at(t - 3 * N4) * cof;
 }
 
 // One workgroup transforms tpw frames of length N (N4 = N/4 complex points each).
@@ -128,6 +228,26 @@ extern "C" int llzs_matvec_exact_f64(const double *A, const double *x, double *y
     hipLaunchKernelGGL(k_matvec_exact_f64, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream), A, x, y,
                        rows, cols);
     LLZ_LAUNCH_CHECK("k_matvec_exact_f64");
+    return LLZ_OK;
+}
+
+extern "C" int llzs_mdct_rot_f64(int quarter, int post, const double *in, double *out, const double *cs2, int N, int inverse,
+                                 double cof, void *stream)
+{
+    if (!in || !out || !cs2 || N < 4) {
+        llzs_set_error("mdct_rot_f64: bad arguments");
+        return LLZ_ERR_ARG;
+    }
+    const dim3 grid((unsigned)((N + 255) / 256)), block(256);
+    if (!quarter && !post)
+        hipLaunchKernelGGL(k_mdct_rot_full_pre_f64, grid, block, 0, as_stream(stream), in, out, cs2, N, inverse);
+    else if (!quarter)
+        hipLaunchKernelGGL(k_mdct_rot_full_post_f64, grid, block, 0, as_stream(stream), in, out, cs2, N, inverse);
+    else if (!post)
+        hipLaunchKernelGGL(k_mdct_rot_quarter_pre_f64, grid, block, 0, as_stream(stream), in, out, cs2, N, inverse);
+    else
+        hipLaunchKernelGGL(k_mdct_rot_quarter_post_f64, grid, block, 0, as_stream(stream), in, out, cs2, N, inverse, cof);
+    LLZ_LAUNCH_CHECK("k_mdct_rot_f64");
     return LLZ_OK;
 }
 

@@ -32,7 +32,6 @@ int   llzs_is_device_ptr(const void *p);
 enum {
     LLZS_TUNE_OLS_CHAIN = 0,        /* 1 force / 0 forbid the chain form of the 1024-point overlap-save kernel */
     LLZS_TUNE_OLS_WG_PER_CU,        /* resident workgroups per CU the overlap-save grid is sized for */
-    LLZS_TUNE_OLS_IO,               /* 1: one dword per lane (first form) / 4: 16 bytes per lane */
     LLZS_TUNE_RS_GENERIC,           /* 1: general L/M resampler without the register-window kernel; 2: first LDS kernel */
     LLZS_TUNE_RS_TILES,             /* tiles per workgroup of the general L/M resampler */
     LLZS_TUNE_RS_DEC_VALU,          /* 1: L = 1 float32 decimator on the vector pipe (LDS polyphase kernel) */
@@ -46,9 +45,39 @@ enum {
     LLZS_TUNE_IIR_PIPE,             /* 1: stage pipeline even where the wave form would be taken */
     LLZS_TUNE_IIR_WAVE_MIN_ITEMS,   /* crossover (channel, segment) item count of the wave form */
     LLZS_TUNE_FIR_PART,             /* 1 force / 0 forbid the partitioned overlap-save for long filters */
+    LLZS_TUNE_SHARD_RCCL,           /* 1: sharded handles broadcast their tables through RCCL even on a single device */
     LLZS_TUNE_COUNT
 };
 int llzs_tune(int id);                                   /* current override or -1 */
+
+/* ---- devices, streams, events (sharded handles: llz_shard_host.c) ---- */
+int   llzs_device_get(void);                       /* current device, negative on error */
+int   llzs_device_set(int device);
+int   llzs_device_enter(int device);               /* make `device` current; returns the previous one (or -1) */
+void  llzs_device_leave(int previous);
+void *llzs_stream_create(void);                    /* non-blocking stream on the current device, NULL on failure */
+void  llzs_stream_destroy(void *stream);
+void *llzs_event_create(void);
+void  llzs_event_destroy(void *event);
+int   llzs_event_record(void *event, void *stream);
+double llzs_event_elapsed_ms(void *start, void *stop);   /* synchronises on stop; negative on error */
+
+/* Coefficient-table uploads go through llzs_h2d_table so that a sharded init can see them: mode 1 uploads and records
+ * (destination, size) of every table of the handle being built on this thread, mode 2 records WITHOUT uploading (the
+ * tables of the other shards are filled by llzs_tables_broadcast from shard 0's), mode 0 = plain upload. */
+typedef struct {
+    void *dev;
+    size_t bytes;
+} llzs_table_ref;
+#define LLZS_MAX_TABLES 16
+void llzs_table_capture(int mode);
+int  llzs_table_captured(llzs_table_ref *dst, int capacity);     /* number recorded since the last llzs_table_capture */
+int  llzs_h2d_table(void *dev_dst, const void *host_src, size_t bytes);
+/* tables[s][t]: table t of shard s (same count and sizes in every shard), shard 0 holds the data.  Shards on shard 0's
+ * device get device-to-device copies; every other device receives ONE ncclBroadcast per table over a communicator of
+ * the distinct devices (ncclCommInitAll, librccl loaded on first use) and hands copies to its further shards. */
+int  llzs_tables_broadcast(llzs_table_ref *const *tables, int ntables, int nshards, const int *device,
+                           void *const *stream);
 
 /* ---- FIR ---- */
 #define LLZS_FIR_TAP_PAD 8      /* time-domain kernels read taps in groups of 8: pad the table with zeros */
@@ -181,6 +210,10 @@ int llzs_stft_synthesis_f32(const float *re, const float *im, float *x, const fl
 
 /* MDCT (llz_mdct.c): y[r] = sum_c x[c]*A[r][c] in ascending c, separately rounded multiply and add (device doubles) */
 int llzs_matvec_exact_f64(const double *A, const double *x, double *y, int rows, int cols, void *stream);
+/* twiddle steps of the FFT forms in double, exact order, device data (mdct.hip): quarter 0 = N-point form, 1 = N/4-point
+ * form; post 0 = the step in front of the transform, 1 = the step behind it; cs2: (cos, sin) pairs */
+int llzs_mdct_rot_f64(int quarter, int post, const double *in, double *out, const double *cs2, int N, int inverse,
+                      double cof, void *stream);
 /* y[r] = sum_c (int)(((int64)x[c]*A[r][c]) >> 15), wrapping adds (llz_mdct_fixed.c:116-152) */
 int llzs_matvec_q15(const short *A, const int *x, int *y, int rows, int cols, void *stream);
 /* N/4-point-FFT MDCT / IMDCT of `count` float32 frames: forward [count][N] -> [count][N/2], inverse the other way;

@@ -670,3 +670,101 @@ def synth_i16(dst, seed, chan0=0, stream=None):
     check(capi.lib().llz_hip_synth_i16(_ptr(dst), ch, n, dst.stride(0), seed, chan0, _stream_ptr(stream)),
           "llz_hip_synth_i16")
     return dst
+
+
+# ------------------------------------------------------------------------------------------ sharded handles (llz_shard.h)
+class _Sharded:
+    """One batch handle over several GPUs of a node, single process (include/llz_shard.h): contiguous channel ranges, one
+    stream per shard, tables broadcast from the first device at init.  Buffers are passed per shard (lists)."""
+
+    def _finish_init(self, handle, what):
+        self.handle = check_handle(handle, what)
+        L = self._L
+        self.n_shards = check(L.llz_sharded_count(self.handle), "llz_sharded_count")
+        self.shards = []
+        for s in range(self.n_shards):
+            dev, c0, cnt = C.c_int(), C.c_int(), C.c_int()
+            check(L.llz_sharded_shard(self.handle, s, C.byref(dev), C.byref(c0), C.byref(cnt)), "llz_sharded_shard")
+            self.shards.append((dev.value, c0.value, cnt.value))
+
+    def _ptrs(self, bufs):
+        if len(bufs) != self.n_shards:
+            raise LlzError(f"{len(bufs)} buffers for {self.n_shards} shards")
+        return (C.c_void_p * self.n_shards)(*[_ptr(b) for b in bufs])
+
+    def split(self, tensor):
+        """views of a [channels, ...] tensor / array, one per shard (all shards on the tensor's device, or host memory)"""
+        return [tensor[c0:c0 + cnt] for (_d, c0, cnt) in self.shards]
+
+    def synchronize(self):
+        check(self._L.llz_sharded_synchronize(self.handle), "llz_sharded_synchronize")
+
+    def timer_start(self):
+        check(self._L.llz_sharded_timer_start(self.handle), "llz_sharded_timer_start")
+
+    def timer_stop(self):
+        check(self._L.llz_sharded_timer_stop(self.handle), "llz_sharded_timer_stop")
+
+    def timer_ms(self):
+        per = np.zeros(self.n_shards)
+        ms = self._L.llz_sharded_timer_ms(self.handle, per.ctypes.data_as(_dp))
+        if ms < 0:
+            raise LlzError("llz_sharded_timer_ms: " + capi.last_error())
+        return ms, per
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            self._L.llz_sharded_uninit(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
+def _devlist(devices):
+    return (C.c_int * len(devices))(*[int(d) for d in devices])
+
+
+class FirFilterMCSharded(_Sharded):
+    def __init__(self, channels, frame_len, taps, devices, algo=FIR_ALGO_AUTO):
+        self._L = capi.lib()
+        taps32 = np.ascontiguousarray(_f64(taps).astype(np.float32))
+        self.frame_len, self.flt_len = frame_len, len(taps32)
+        self._finish_init(self._L.llz_fir_filter_mc_sharded_init(channels, frame_len, taps32.ctypes.data, len(taps32), algo,
+                                                                 _devlist(devices), len(devices)),
+                          "llz_fir_filter_mc_sharded_init")
+
+    def filter(self, xs, outs):
+        check(self._L.llz_fir_filter_mc_sharded(self.handle, self._ptrs(xs), self._ptrs(outs), self.frame_len),
+              "llz_fir_filter_mc_sharded")
+        return outs
+
+    def flush(self, outs):
+        return check(self._L.llz_fir_filter_mc_sharded_flush(self.handle, self._ptrs(outs)), "llz_fir_filter_mc_sharded_flush")
+
+
+class IirCascadeMCSharded(_Sharded):
+    def __init__(self, channels, coef, devices):
+        self._L = capi.lib()
+        coef = _f64(coef).reshape(-1, 6)
+        self._finish_init(self._L.llz_iir_cascade_mc_sharded_init(channels, coef.shape[0], coef.ctypes.data,
+                                                                  _devlist(devices), len(devices)),
+                          "llz_iir_cascade_mc_sharded_init")
+
+    def filter(self, xs, outs):
+        n = xs[0].shape[-1]
+        check(self._L.llz_iir_cascade_mc_sharded(self.handle, self._ptrs(xs), self._ptrs(outs), n),
+              "llz_iir_cascade_mc_sharded")
+        return outs
+
+
+class ResampleMCSharded(_Sharded):
+    def __init__(self, channels, L, M, gain, win, fmt, devices):
+        self._L = capi.lib()
+        self.L, self.M = L, M
+        self._finish_init(self._L.llz_resample_mc_sharded_init(channels, L, M, gain, win, fmt, _devlist(devices),
+                                                               len(devices)), "llz_resample_mc_sharded_init")
+
+    def process(self, xs, outs):
+        n_in = xs[0].shape[-1]
+        return check(self._L.llz_resample_mc_sharded(self.handle, self._ptrs(xs), n_in, self._ptrs(outs)),
+                     "llz_resample_mc_sharded")

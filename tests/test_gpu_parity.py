@@ -939,14 +939,13 @@ def test_fir_ols4096_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
 
 
 # ------------------------------------------------------------------------------------------------ overlap-save, chain form
-@pytest.mark.parametrize("io", [-1, 1], ids=["wide", "dword"])
 @pytest.mark.parametrize("chain", [1, 0], ids=["chain", "walk"])
-def test_fir_ols_forms_forced(dev, oracle, chain, io):
+def test_fir_ols_forms_forced(dev, oracle, chain):
     """the launcher takes the chain form (prefetch carried across segments) only on batches far larger than a test can
-    afford to check sample by sample, and the one-dword-per-lane access form only for rows that are not 8-byte aligned:
-    llz_hip_tune forces each combination on small batches, including ragged lengths, segments shorter than 16 jobs, odd
-    row pitches (which must fall back to the dword form by themselves) and streaming across calls"""
-    with capi.tuned(ols_chain=chain, ols_io=io):
+    afford to check sample by sample (test_fir_ols_headline_shape_full_length does the large one): llz_hip_tune forces
+    either form on small batches, including ragged lengths, segments shorter than 16 jobs, odd row lengths and streaming
+    across calls"""
+    with capi.tuned(ols_chain=chain):
         for channels, n, taps_n in ((3, 1536 * 40 + 100, 257), (5, 1536 * 33, 63), (2, 1000, 129), (9, 1536 * 17 + 1, 200),
                                     (4, 1536 * 5 + 7, 257)):
             taps = oracle.fir_design(po.LPF, taps_n, 0.2, 0.0, po.KAISER)
@@ -960,7 +959,7 @@ def test_fir_ols_forms_forced(dev, oracle, chain, io):
                 f.filter(xd, yd)
                 outs.append(yd.cpu().numpy())
             f.close()
-            rms_check(np.concatenate(outs, axis=1), ref, f"fir ols chain={chain} io={io} {channels}x{n}x{taps_n}")
+            rms_check(np.concatenate(outs, axis=1), ref, f"fir ols chain={chain} {channels}x{n}x{taps_n}")
 
 
 def test_fir_ols_headline_shape_full_length(dev, oracle):
@@ -1102,3 +1101,153 @@ def test_limits_and_degenerate_calls(dev, oracle):
     q.close()
     h = oracle.iir_cascade_batch_f32(xi[:1].cpu().numpy(), np.array([[0.2066, 0.4131, 0.2066, 1.0, -0.3695, 0.1958]]))
     assert np.abs(yi[[0, 69999]].cpu().numpy() - h).max() < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ sharded handles (llz_shard.h)
+def _virtual(n):
+    """n shards, all on device 0: how a one-GPU box runs the multi-GPU code path"""
+    return [0] * n
+
+
+@pytest.mark.parametrize("n_shards", [2, 8])
+@pytest.mark.parametrize("algo,taps_n", [(filters.FIR_ALGO_OVERLAP_SAVE, 257), (filters.FIR_ALGO_TIME, 63),
+                                         (filters.FIR_ALGO_OVERLAP_SAVE_2048, 400)])
+def test_sharded_fir_equals_unsharded(dev, oracle, n_shards, algo, taps_n):
+    """the C ABI's sharded FIR handle (contiguous channel ranges, one stream per shard, tables broadcast from shard 0) gives
+    bit-identical output to one unsharded handle, over two streamed frames and the flush"""
+    channels, n = 37, 1536 * 9 + 5
+    taps = oracle.fir_design(po.LPF, taps_n, 0.15, 0.0, po.KAISER)
+    x = torch.empty(channels, 2 * n, dtype=torch.float32, device=dev)
+    filters.synth_f32(x, seed=21)
+    ref_h = filters.FirFilterMC(channels, n, taps, algo=algo)
+    sh = filters.FirFilterMCSharded(channels, n, taps, _virtual(n_shards), algo=algo)
+    assert [c for (_d, _c0, c) in sh.shards] == [channels // n_shards + (1 if s < channels % n_shards else 0) for s in range(n_shards)]
+    for o in (0, n):
+        xin = x[:, o:o + n].contiguous()
+        y_ref = torch.empty_like(xin)
+        ref_h.filter(xin, y_ref)
+        y = torch.full_like(xin, float("nan"))
+        torch.cuda.synchronize()          # the shards' streams are non-blocking: they do not wait for torch's stream
+        sh.filter(sh.split(xin), sh.split(y))
+        sh.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_ref), f"frame at {o}"
+    t_ref = torch.empty(channels, taps_n - 1, dtype=torch.float32, device=dev)
+    ref_h.flush(t_ref)
+    t = torch.empty_like(t_ref)
+    torch.cuda.synchronize()
+    assert sh.flush(sh.split(t)) == taps_n - 1
+    sh.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(t, t_ref)
+    rms_check(y_ref.cpu().numpy(),
+              oracle.fir_batch_f32(x.cpu().numpy(), taps.astype(np.float32).astype(np.float64))[:, n:], "unsharded vs oracle")
+    ref_h.close(); sh.close()
+
+
+@pytest.mark.parametrize("n_shards", [2, 8])
+@pytest.mark.parametrize("L,M,fmt", [(1, 3, filters.PCM_F32), (1, 3, filters.PCM_I16), (147, 160, filters.PCM_F32), (2, 3, filters.PCM_I16)])
+def test_sharded_resample_equals_unsharded(dev, oracle, n_shards, L, M, fmt):
+    channels = 19
+    n_in = M * 64 * (5 if L > 4 else 40)
+    n_out = n_in * L // M
+    dt = torch.float32 if fmt == filters.PCM_F32 else torch.int16
+    x = torch.empty(channels, 2 * n_in, dtype=dt, device=dev)
+    (filters.synth_f32 if fmt == filters.PCM_F32 else filters.synth_i16)(x, seed=5)
+    ref_h = filters.ResampleMC(channels, L, M, 1.0, po.BLACKMAN, fmt)
+    sh = filters.ResampleMCSharded(channels, L, M, 1.0, po.BLACKMAN, fmt, _virtual(n_shards))
+    for o in (0, n_in):
+        xin = x[:, o:o + n_in].contiguous()
+        y_ref = torch.empty(channels, n_out, dtype=dt, device=dev)
+        ref_h.process(xin, y_ref)
+        y = torch.zeros_like(y_ref)
+        torch.cuda.synchronize()
+        assert sh.process(sh.split(xin), sh.split(y)) == n_out
+        sh.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_ref), f"frame at {o}"
+    ref_h.close(); sh.close()
+
+
+@pytest.mark.parametrize("n_shards", [2, 8])
+@pytest.mark.parametrize("radius", [0.44, 0.99])
+def test_sharded_iir_equals_unsharded(dev, oracle, n_shards, radius):
+    """same kernels on channel shards: the kernel form and the time-segment count are shape dependent, so both runs are
+    pinned to one form (one segment per channel, stage pipeline) before comparing bit for bit"""
+    rows = []
+    for k in range(8):
+        r, th = radius - 0.01 * k, 0.3 + 0.2 * k
+        a1, a2 = -2 * r * np.cos(th), r * r
+        rows.append([(1 + a1 + a2) / 4, (1 + a1 + a2) / 2, (1 + a1 + a2) / 4, 1.0, a1, a2])
+    coef = np.array(rows)
+    channels, n = 21, 1024 * 12 + 36
+    x = torch.empty(channels, 2 * n, dtype=torch.float32, device=dev)
+    filters.synth_f32(x, seed=77)
+    with capi.tuned(iir_segs=1, iir_pipe=1):
+        ref_h = filters.IirCascadeMC(channels, coef)
+        sh = filters.IirCascadeMCSharded(channels, coef, _virtual(n_shards))
+        for o in (0, n):
+            xin = x[:, o:o + n].contiguous()
+            y_ref = torch.empty_like(xin)
+            ref_h.filter(xin, y_ref)
+            y = torch.zeros_like(xin)
+            torch.cuda.synchronize()
+            sh.filter(sh.split(xin), sh.split(y))
+            sh.synchronize()
+            torch.cuda.synchronize()
+            assert torch.equal(y, y_ref), f"frame at {o}"
+        ref_h.close(); sh.close()
+    ref = oracle.iir_cascade_batch_f32(x.cpu().numpy(), coef)[:, n:]
+    err = float(np.sqrt(np.mean((y_ref.cpu().numpy() - ref) ** 2)))
+    assert err <= 1e-5 * max(1.0, float(np.sqrt(np.mean(ref ** 2))))
+
+
+def test_sharded_tables_through_rccl_on_one_device(dev, oracle):
+    """the table broadcast runs through RCCL itself (dlopen of librccl, ncclCommInitAll, grouped ncclBroadcast on the shard's
+    stream, ncclCommDestroy) when llz_hip_tune("shard_rccl", 1) asks for it on a single device: a one-rank communicator,
+    the same calls a multi-GPU node makes; further shards on the device take device-to-device copies"""
+    channels, n, taps_n = 12, 4000, 129
+    taps = oracle.fir_design(po.LPF, taps_n, 0.2, 0.0, po.HAMMING)
+    x = torch.empty(channels, n, dtype=torch.float32, device=dev)
+    filters.synth_f32(x, seed=3)
+    ref_h = filters.FirFilterMC(channels, n, taps)
+    y_ref = torch.empty_like(x)
+    ref_h.filter(x, y_ref)
+    with capi.tuned(shard_rccl=1):
+        sh = filters.FirFilterMCSharded(channels, n, taps, _virtual(3))
+    y = torch.zeros_like(x)
+    torch.cuda.synchronize()
+    sh.filter(sh.split(x), sh.split(y))
+    sh.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref)
+    y2 = torch.zeros_like(x)
+    torch.cuda.synchronize()
+    sh.timer_start()
+    sh.filter(sh.split(x), sh.split(y2))
+    sh.timer_stop()
+    ms, per = sh.timer_ms()
+    assert ms > 0 and per.shape == (3,) and ms == per.max()
+    ref_h.close(); sh.close()
+
+
+def test_sharded_refusals(dev, oracle):
+    taps = oracle.fir_design(po.LPF, 33, 0.2, 0.0, po.HAMMING)
+    for devices in ([], [0, 99], [0] * 65, [-1]):
+        with pytest.raises(capi.LlzError):
+            filters.FirFilterMCSharded(8, 256, taps, devices)
+    with pytest.raises(capi.LlzError):
+        filters.FirFilterMCSharded(2, 256, taps, [0, 0, 0])    # more shards than channels
+
+
+def test_handle_binds_its_device(dev, oracle):
+    """a handle records the device it was created on and binds it in every call (the caller's current device is restored)"""
+    L = capi.lib()
+    taps = oracle.fir_design(po.LPF, 33, 0.2, 0.0, po.HAMMING)
+    f = filters.FirFilterMC(3, 512, taps)
+    x = torch.empty(3, 512, dtype=torch.float32, device=dev)
+    filters.synth_f32(x, seed=1)
+    y = torch.empty_like(x)
+    f.filter(x, y)
+    assert L.llz_hip_get_device() == 0
+    f.close()
