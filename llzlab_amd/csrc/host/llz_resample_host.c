@@ -3,6 +3,7 @@
  * (reference libllzfilter/llz_resample.c:124-617) and the multi-channel batch extension.  Prototype design and
  * the polyphase / time-varying tap matrices are host C (setup time); every sample is computed on the device.
  */
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include "../../../include/llz_resample.h"
@@ -259,6 +260,11 @@ typedef struct {
     float *d_phase;             /* F32, L == 1: M x tp phase taps for the polyphase fast path (NULL otherwise) */
     int tp;
     int use_mfma;               /* F32, L == 1: decimating FIR on the matrix cores (fir_mfma.hip) */
+    /* I16, L == 1: the bit-exact path screened on the matrix cores (fir_mfma_i8.hip) */
+    int use_screen, screen_shift;
+    long long screen_bias;
+    double screen_eps;
+    signed char *d_digits;      /* [LLZS_MX_PLANES][Q] */
     void *d_hist[2];            /* [channels][Q-1] samples of the handle's format, ping-pong */
     int cur;
     long long in_count, out_count;   /* samples consumed / produced per channel so far */
@@ -273,17 +279,83 @@ static void rsm_destroy(rsm_t *r)
 {
     if (!r) return;
     tapmat_free(&r->taps);
-    llzs_free(r->d_mat); llzs_free(r->d_phase); llzs_free(r->d_hist[0]); llzs_free(r->d_hist[1]);
+    llzs_free(r->d_mat); llzs_free(r->d_phase); llzs_free(r->d_digits); llzs_free(r->d_hist[0]); llzs_free(r->d_hist[1]);
     llz_stage_release(&r->st_in); llz_stage_release(&r->st_out);
     r->tag = 0;
     free(r);
 }
 
+/* Screen tables of the bit-exact int16 decimator (fir_mfma_i8.hip): fixed-point taps G[k] = round(gain g[k] 2^shift) as
+ * five balanced base-256 digits, the constant 128 sum G[k] of the samples' +128 offset, and eps, a bound on the distance
+ * between the screen's value v = S 2^-shift and the reference's double result y = fl(fl(sum x g) gain)
+ * (llz_resample.c:590-594), for |x| <= 32768 and u = 2^-53:
+ *   tap quantisation     |sum x (gain g - G 2^-shift)|    <= 32768 sum_k |fl(gain g[k]) - G[k] 2^-shift|   (evaluated below)
+ *                        + the rounding of fl(gain g[k])   <= 32768 u |gain| sum_k |g[k]|
+ *   reference's sum      |fl(sum x g) - sum x g|          <= Q u / (1 - Q u) sum |x g| <= Q 2^-52 32768 sum_k |g[k]|
+ *   reference's * gain   one more rounding of a value <= 32768 |gain| sum|g|
+ * eps = 2 (the sum of those) + 2^-30: the factor 2 and the constant are margin (they also cover this function's own
+ * floating-point sums).  Returns 0 when the taps do not suit the screen (the all-double kernel then runs). */
+static int rsm_build_screen(rsm_t *r)
+{
+    const int Q = r->Q;
+    const double *g = r->taps.mat;
+    const double gain = r->gain;
+    double maxabs = 0.0, sumabs = 0.0;
+    for (int k = 0; k < Q; k++) {
+        const double a = fabs(g[k] * gain);
+        if (!(a < 1e30)) return 0;
+        if (a > maxabs) maxabs = a;
+        sumabs += a;
+    }
+    if (maxabs == 0.0 || !llzs_fir_mfma_i16x_fits(Q, r->M)) return 0;
+    int e_max, e_sum;
+    (void)frexp(maxabs, &e_max);                        /* maxabs < 2^e_max */
+    (void)frexp(sumabs, &e_sum);
+    int shift = 38 - e_max;                             /* |G| < 2^38: five balanced digits hold it */
+    if (shift > 46 - e_sum) shift = 46 - e_sum;         /* 2^15 sum|G| < 2^62: the int64 total cannot wrap */
+    if (shift > 46) shift = 46;
+    if (shift < 32) return 0;                           /* (gains above ~64: the integer decision needs shift >= 32) */
+    signed char *digits = (signed char *)malloc((size_t)LLZS_MX_PLANES * Q);
+    if (!digits) return 0;
+    long long sumG = 0;
+    double qerr = 0.0;
+    int ok = 1;
+    for (int k = 0; k < Q; k++) {
+        const double gk = g[k] * gain;
+        long long G = llround(ldexp(gk, shift));
+        qerr += fabs(gk - ldexp((double)G, -shift));
+        sumG += G;
+        for (int p = 0; p < LLZS_MX_PLANES; p++) {
+            const int d = (int)(((G + 128) & 255) - 128);            /* balanced digit in [-128, 127] */
+            digits[(size_t)p * Q + k] = (signed char)d;
+            G = (G - d) / 256;
+        }
+        if (G != 0) ok = 0;
+    }
+    const double eps = 2.0 * 32768.0 * (qerr + (double)(Q + 2) * ldexp(1.0, -52) * sumabs) + ldexp(1.0, -30);
+    if (ok && eps < 0.0625) {
+        if (!r->d_digits) r->d_digits = (signed char *)llzs_malloc((size_t)LLZS_MX_PLANES * Q);
+        ok = r->d_digits && llzs_h2d_table(r->d_digits, digits, (size_t)LLZS_MX_PLANES * Q) == LLZ_OK;
+    } else {
+        ok = 0;
+    }
+    free(digits);
+    if (ok) {
+        r->screen_shift = shift;
+        r->screen_bias = 128 * sumG;
+        r->screen_eps = eps;
+    }
+    return ok;
+}
+
 static int rsm_upload_matrix(rsm_t *r)
 {
     const size_t count = (size_t)r->L * r->Q;
-    if (r->fmt == LLZ_PCM_I16)
-        return llzs_h2d_table(r->d_mat, r->taps.mat, sizeof(double) * count);
+    if (r->fmt == LLZ_PCM_I16) {
+        const int rc = llzs_h2d_table(r->d_mat, r->taps.mat, sizeof(double) * count);
+        r->use_screen = rc == LLZ_OK && r->L == 1 && llzs_tune(LLZS_TUNE_RS_I16_PATH) != 1 && rsm_build_screen(r);
+        return rc;
+    }
     float *m32 = (float *)malloc(sizeof(float) * count);
     if (!m32) return LLZ_ERR_NOMEM;
     for (size_t i = 0; i < count; i++) m32[i] = (float)r->taps.mat[i];
@@ -459,6 +531,10 @@ static long rsm_process(rsm_t *r, unsigned long handle, const void *in, long n_i
         if (r->fmt == LLZ_PCM_I16_FAST)
             rc = llzs_fir_mfma_i16((const short *)d_in, (short *)d_out, (const short *)hist, (const float *)r->d_mat,
                                    r->channels, n_in, n_out, n_in, n_out, r->Q, r->M, (float)r->gain, r->stream);
+        else if (r->fmt == LLZ_PCM_I16 && r->use_screen)
+            rc = llzs_fir_mfma_i16x((const short *)d_in, (short *)d_out, (const short *)hist, r->d_digits,
+                                    (const double *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->Q, r->M,
+                                    r->screen_shift, r->screen_bias, r->gain, r->screen_eps, r->stream);
         else if (r->fmt == LLZ_PCM_I16)
             rc = llzs_resample_i16((const short *)d_in, (short *)d_out, (const short *)hist,
                                    (const double *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->L, r->M,

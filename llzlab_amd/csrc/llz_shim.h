@@ -115,6 +115,14 @@ int llzs_fir_mfma_f32_fits(int T, int M);           /* 1 when the LDS image of o
 int llzs_fir_mfma_i16(const short *in, short *out, const short *hist, const float *taps, int channels,
                       long n_in, long n_out, long in_pitch, long out_pitch, int T, int M, float gain, void *stream);
 int llzs_fir_mfma_i16_fits(int T, int M);
+/* int16 in and out, BIT-EXACT with the reference's double loop (llz_resample.c:583-603, L = 1), screened on the matrix
+ * cores (fir_mfma_i8.hip): digits = [5][T] balanced base-256 digits of G[k] = round(g[k] 2^shift), bias = 128 sum G[k],
+ * gd = the T double taps, eps = the host's bound on |screen value - reference value| (< 0.25) */
+int llzs_fir_mfma_i16x(const short *in, short *out, const short *hist, const signed char *digits, const double *gd,
+                       int channels, long n_in, long n_out, long in_pitch, long out_pitch, int T, int M, int shift,
+                       long long bias, double gain, double eps, void *stream);
+int llzs_fir_mfma_i16x_fits(int T, int M);
+#define LLZS_MX_PLANES 5
 /* hist_new[c][:] = last (flt_len-1) samples of concat(hist_old[c], in[c][0:n]) */
 int llzs_fir_tail_f32(const float *in, const float *hist_old, float *hist_new,
                       int channels, int n, long in_pitch, int flt_len, void *stream);

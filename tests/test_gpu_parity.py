@@ -1251,3 +1251,55 @@ def test_handle_binds_its_device(dev, oracle):
     f.filter(x, y)
     assert L.llz_hip_get_device() == 0
     f.close()
+
+
+# ------------------------------------------------------------------------------------------------ int16 decimator, screened on the matrix cores
+@pytest.mark.parametrize("M,win,gain", [(3, po.BLACKMAN, 1.0), (2, po.HAMMING, 1.0), (5, po.KAISER, 1.0), (3, po.BLACKMAN, 2.5),
+                                        (4, po.HAMMING, 0.37), (3, po.HAMMING, 100.0), (2, po.BLACKMAN, 1e-3)])
+def test_resample_i16_screened_is_bit_exact(dev, oracle, M, win, gain):
+    """LLZ_PCM_I16 with L = 1 runs the integer screen on the matrix cores (fir_mfma_i8.hip) and recomputes in the reference's
+    double order only the outputs the screen cannot decide.  Bit-exact against the oracle on: random PCM, full-scale PCM that
+    drives the clamp rails, digital silence, DC (every output ON a truncation edge: all of them take the recompute path),
+    silence -> signal transitions inside a tile, streamed over two calls; and identical to the all-double kernel."""
+    info = oracle.rs_info(2, 1, M, gain, win)
+    nin = info["bytes_in"] // 2 * 24
+    ch = 9
+    x = oracle.synth_i16(ch, nin, seed=M * 19)
+    x[1] = (x[1].astype(np.int32) * 2).clip(-32768, 32767).astype(np.int16)     # clipping rails
+    x[2] = 0                                                                    # digital silence
+    x[3] = 12345                                                                # DC: output = 12345 * sum(g) * gain, near-integer
+    x[4, : nin // 2] = 0                                                        # silence, then signal
+    x[5] = -32768
+    x[6] = 32767
+    x[7] = np.where(np.arange(nin) % 2 == 0, 1, -1) * 20000                     # alternating full-ish scale
+    ref = oracle.rs_batch_i16(x, 1, M, gain, win)
+    outs, outs_plain = [], []
+    cut = (nin // 2) // M * M
+    for tuned, dst in (({}, outs), ({"rs_i16_path": 1}, outs_plain)):
+        with capi.tuned(**tuned):
+            r = filters.ResampleMC(ch, 1, M, gain, win, filters.PCM_I16)
+            for (o, e) in ((0, cut), (cut, nin)):
+                xi = torch.from_numpy(np.ascontiguousarray(x[:, o:e])).to(dev)
+                yi = torch.empty(ch, (e - o) // M, dtype=torch.int16, device=dev)
+                r.process(xi, yi)
+                dst.append(yi.cpu().numpy())
+            r.close()
+    got = np.concatenate(outs, axis=1)
+    bad = np.argwhere(got != ref)
+    assert bad.size == 0, f"{len(bad)} samples differ, first at {bad[0]}: got {got[tuple(bad[0])]} ref {ref[tuple(bad[0])]}"
+    assert np.array_equal(np.concatenate(outs_plain, axis=1), ref)
+
+
+def test_resample_i16_screened_large_batch(dev, oracle):
+    """a batch large enough for the persistent grid to walk several tiles per workgroup (prefetch path, ragged last tile,
+    many channels): bit-exact on a spread of channels"""
+    ch, nin = 300, 1536 * 29          # whole reference frames (1536 samples at 1:3), a ragged last tile
+    x = torch.empty(ch, nin, dtype=torch.int16, device=dev)
+    filters.synth_i16(x, seed=11)
+    y = torch.empty(ch, nin // 3, dtype=torch.int16, device=dev)
+    r = filters.ResampleMC(ch, 1, 3, 1.0, po.BLACKMAN, filters.PCM_I16)
+    r.process(x, y)
+    sel = [0, 1, 77, 150, 298, 299]
+    ref = oracle.rs_batch_i16(x[sel].cpu().numpy(), 1, 3, 1.0, po.BLACKMAN)
+    assert np.array_equal(y[sel].cpu().numpy(), ref)
+    r.close()
