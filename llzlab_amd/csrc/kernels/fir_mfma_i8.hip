@@ -31,6 +31,7 @@
 // registers), with 64 window samples per MFMA step and one-byte planes in LDS.
 #include "common.hpp"
 #include <math.h>
+#include <type_traits>
 #include <stdlib.h>
 #include <string.h>
 
@@ -177,17 +178,15 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         short *orow = out + (size_t)c * out_pitch;
         const bool whole = aligned_out && o0 + TILE_OUT <= n_out;
         i32x4 acc[NACC][MX_PLANES + 1];
-#pragma unroll
-        for (int a = 0; a < NACC; a++)
-#pragma unroll
-            for (int w = 0; w <= MX_PLANES; w++) acc[a][w] = (i32x4){0, 0, 0, 0};
         if (any) {
             const signed char *bp[NACC];
 #pragma unroll
             for (int a = 0; a < NACC; a++) bp[a] = xs_lo + ((wave * NACC + a) * 16 + n) * 16 * sh.M + 16 * kq;
             const signed char *ap = atab + lane * 16;
-            i32x4 a0[MX_PLANES], a1[MX_PLANES], b0[NACC][2], b1[NACC][2];
-            auto fetch = [&](int s, i32x4 (&ad)[MX_PLANES], i32x4 (&bd)[NACC][2]) {
+            // one step = 64 window samples: 5 tap planes x 2 sample planes.  The first step starts every accumulator from
+            // the constant 0 (no zeroing pass); the other resident waves cover the LDS latency of a step's operands
+            auto step = [&](int s, auto first) {
+                i32x4 ad[MX_PLANES], bd[NACC][2];
 #pragma unroll
                 for (int p = 0; p < MX_PLANES; p++) ad[p] = *reinterpret_cast<const i32x4 *>(ap + p * aplane + s * 1024);
 #pragma unroll
@@ -195,26 +194,21 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
                     bd[a][0] = *reinterpret_cast<const i32x4 *>(bp[a] + s * 64);
                     bd[a][1] = *reinterpret_cast<const i32x4 *>(bp[a] + sh.plane + s * 64);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            auto mac = [&](const i32x4 (&ad)[MX_PLANES], const i32x4 (&bd)[NACC][2]) {
 #pragma unroll
                 for (int p = 0; p < MX_PLANES; p++)
 #pragma unroll
                     for (int d = 0; d < 2; d++)
 #pragma unroll
-                        for (int a = 0; a < NACC; a++)
-                            acc[a][p + d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ad[p], bd[a][d], acc[a][p + d], 0, 0, 0);
+                        for (int a = 0; a < NACC; a++) {
+                            // weight p + d is first written by (p = 0, d = 0), (p, d = 1) for p < 5 ... in this loop order:
+                            // (p, d) is the first visitor of p + d exactly when d == 1 or p == 0
+                            const bool fresh = decltype(first)::value && (d == 1 || p == 0);
+                            const i32x4 c = fresh ? (i32x4){0, 0, 0, 0} : acc[a][p + d];
+                            acc[a][p + d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ad[p], bd[a][d], c, 0, 0, 0);
+                        }
             };
-            int s = 0;
-            fetch(0, a0, b0);                            // ksteps >= 1
-            for (; s + 2 <= sh.ksteps; s += 2) {
-                fetch(s + 1, a1, b1);
-                mac(a0, b0);
-                if (s + 2 < sh.ksteps) fetch(s + 2, a0, b0);
-                mac(a1, b1);
-            }
-            if (s < sh.ksteps) mac(a0, b0);
+            step(0, std::true_type{});
+            for (int s = 1; s < sh.ksteps; s++) step(s, std::false_type{});
         }
 
 #pragma unroll
@@ -304,8 +298,14 @@ int mx_launch(const short *in, short *out, const short *hist, const signed char 
         (void)hipGetLastError();
         cus = 256;
     }
-    int per_cu = (int)((160 * 1024) / lds_bytes);
-    if (per_cu > 3) per_cu = 3;
+    // a persistent grid: exactly the workgroups the chip holds at once (a workgroup that has to wait for a slot would
+    // run its share of the tiles after everyone else: 768 workgroups on 512 slots measured 48 ms instead of 36)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_fir_mfma_i8x<NACC, NV>),
+                                                     MX_THREADS, lds_bytes) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 2;
+    }
     if (const int v = llzs_tune(LLZS_TUNE_MFMA_WG_PER_CU); v >= 1 && v <= 8) per_cu = v;
     long grid = (long)cus * per_cu;
     if (grid > ntiles) grid = ntiles;

@@ -25,7 +25,7 @@ if what == "resample":
     for _ in range(steps):
         r.process(x, y)
 elif what == "resample_i16":
-    ch = 256
+    ch = 1024
     n = 3 * (((1 << 22) // 3) // 256 * 256)
     x = torch.empty(ch, n, dtype=torch.int16, device=dev)
     y = torch.empty(ch, n // 3, dtype=torch.int16, device=dev)
