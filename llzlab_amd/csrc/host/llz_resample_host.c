@@ -265,6 +265,9 @@ typedef struct {
     long long screen_bias;
     double screen_eps;
     signed char *d_digits;      /* [LLZS_MX_PLANES][Q] */
+    /* F32, L >= 5: the banded tap matrix in matrix-core operand order (resample_mfma.hip) */
+    float *d_band;
+    int *d_band_c0;
     void *d_hist[2];            /* [channels][Q-1] samples of the handle's format, ping-pong */
     int cur;
     long long in_count, out_count;   /* samples consumed / produced per channel so far */
@@ -279,7 +282,7 @@ static void rsm_destroy(rsm_t *r)
 {
     if (!r) return;
     tapmat_free(&r->taps);
-    llzs_free(r->d_mat); llzs_free(r->d_phase); llzs_free(r->d_digits); llzs_free(r->d_hist[0]); llzs_free(r->d_hist[1]);
+    llzs_free(r->d_mat); llzs_free(r->d_phase); llzs_free(r->d_digits); llzs_free(r->d_band); llzs_free(r->d_band_c0); llzs_free(r->d_hist[0]); llzs_free(r->d_hist[1]);
     llz_stage_release(&r->st_in); llz_stage_release(&r->st_out);
     r->tag = 0;
     free(r);
@@ -360,6 +363,33 @@ static int rsm_upload_matrix(rsm_t *r)
     if (!m32) return LLZ_ERR_NOMEM;
     for (size_t i = 0; i < count; i++) m32[i] = (float)r->taps.mat[i];
     int rc = llzs_h2d_table(r->d_mat, m32, sizeof(float) * count);
+    if (rc == LLZ_OK && r->fmt == LLZ_PCM_F32 && llzs_resample_mfma_f32_fits(r->L, r->M, r->Q) &&
+        llzs_tune(LLZS_TUNE_RS_GENERIC) < 1) {
+        /* phase tile t = phases 16t .. 16t+15; its band starts at input offset c0 - (Q-1), c0 = floor(16 t M / L), and is
+         * walked 4 samples per matrix-core step: lane (r = lane % 16, kq = lane / 16) of step s holds the tap of phase
+         * f = 16t + r that multiplies the band's sample 4s + kq, i.e. g_f[c_f - c0 + (Q-1) - (4s + kq)] */
+        const int steps = llzs_resample_mfma_f32_table_steps(r->L, r->M, r->Q), nt = (r->L + 15) / 16;
+        float *band = (float *)calloc((size_t)nt * steps * 64, sizeof(float));
+        int *c0 = (int *)malloc(sizeof(int) * (size_t)nt);
+        if (!band || !c0) { free(band); free(c0); free(m32); return LLZ_ERR_NOMEM; }
+        for (int t = 0; t < nt; t++) {
+            c0[t] = (int)(((long)16 * t * r->M) / r->L);
+            for (int s = 0; s < steps; s++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const int f = 16 * t + (lane & 15), u = 4 * s + (lane >> 4);
+                    if (f >= r->L) continue;
+                    const int k = (int)(((long)f * r->M) / r->L) - c0[t] + (r->Q - 1) - u;
+                    if (k >= 0 && k < r->Q)
+                        band[((size_t)t * steps + s) * 64 + lane] = (float)(m32[(size_t)f * r->Q + k] * (float)r->gain);
+                }
+        }
+        if (!r->d_band) r->d_band = (float *)llzs_malloc(sizeof(float) * (size_t)nt * steps * 64);
+        if (!r->d_band_c0) r->d_band_c0 = (int *)llzs_malloc(sizeof(int) * (size_t)nt);
+        rc = (r->d_band && r->d_band_c0) ? LLZ_OK : LLZ_ERR_NOMEM;
+        if (rc == LLZ_OK) rc = llzs_h2d_table(r->d_band, band, sizeof(float) * (size_t)nt * steps * 64);
+        if (rc == LLZ_OK) rc = llzs_h2d_table(r->d_band_c0, c0, sizeof(int) * (size_t)nt);
+        free(band); free(c0);
+    }
     if (rc == LLZ_OK && r->L == 1) {
         r->use_mfma = llzs_fir_mfma_f32_fits(r->Q, r->M) && llzs_tune(LLZS_TUNE_RS_DEC_VALU) != 1;
         /* phase taps for the decimator fast path: gp[m][j] = g[0][j*M + m], rows zero padded to tp */
@@ -546,6 +576,9 @@ static long rsm_process(rsm_t *r, unsigned long handle, const void *in, long n_i
             rc = llzs_resample_dec_f32((const float *)d_in, (float *)d_out, (const float *)hist, r->d_phase,
                                        r->channels, n_in, n_out, n_in, n_out, r->M, r->Q, r->tp, (float)r->gain,
                                        r->stream);
+        else if (r->d_band && r->in_count % r->M == 0 && r->out_count % r->L == 0 && r->channels <= 65535)
+            rc = llzs_resample_mfma_f32((const float *)d_in, (float *)d_out, (const float *)hist, r->d_band, r->d_band_c0,
+                                        r->channels, n_in, n_out, n_in, n_out, r->L, r->M, r->Q, r->stream);
         else
             rc = llzs_resample_f32((const float *)d_in, (float *)d_out, (const float *)hist,
                                    (const float *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->L, r->M,

@@ -15,6 +15,9 @@
 // stages run as 1-3 passes of up to four stages fused in registers (16 elements per lane), a barrier between passes. Twiddle tables come from the host
 // (never recomputed on the device: SURVEY.md H4/H5).
 #include <stdlib.h>
+#include <array>
+#include <map>
+#include <mutex>
 #include "fft_core.hpp"
 #include "fft32.hpp"
 
@@ -1542,25 +1545,36 @@ int launch_fft(typename A::data_t *data, int count, int size, const typename A::
 
 } // namespace
 
+// Derived twiddle tables (built on the device from a handle's cos/sin table): one set per (kind, size, device), kept for the
+// process.  derived_slot() hands out the set's two pointers; the caller holds g_derived_lock from the lookup until freshly
+// built tables are published, so any number of host threads and any device index are fine.
+static std::mutex g_derived_lock;
+static float2 **derived_slot(int kind, int key, int dev)
+{
+    static std::map<std::array<int, 3>, std::array<float2 *, 2>> sets;
+    return sets[{kind, key, dev}].data();
+}
+
 extern "C" int llzs_fft_f32(float *data, int count, int size, const float *cs, int inverse, void *stream)
 {
     if ((size == 64 || size == 256 || size == 4096) && data && cs && count >= 1 && llzs_tune(LLZS_TUNE_FFT_GENERIC) < 1) {
         // the [E][E] twiddle table is derived once per device and size from the caller's table (kept for the process)
-        static float2 *tables[16][3];
         int dev = 0;
         LLZ_HIP_CHECK(hipGetDevice(&dev));
-        const int E = size == 64 ? 8 : size == 256 ? 16 : 64, slot = size == 64 ? 2 : size == 256 ? 0 : 1;
-        if (dev < 0 || dev >= 16) dev = 0;
-        if (!tables[dev][slot]) {
+        const int E = size == 64 ? 8 : size == 256 ? 16 : 64;
+        std::unique_lock<std::mutex> guard(g_derived_lock);
+        float2 **set = derived_slot(1, size, dev);
+        if (!set[0]) {
             float2 *t = nullptr;
             LLZ_HIP_CHECK(hipMalloc(&t, sizeof(float2) * (size_t)size));
             hipLaunchKernelGGL(k_fft_square_table, dim3((unsigned)((size + 255) / 256)), dim3(256), 0, as_stream(stream), t,
                                cs, E);
             LLZ_LAUNCH_CHECK("k_fft_square_table");
             LLZ_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));   // published only once complete: other streams may use it
-            tables[dev][slot] = t;
+            set[0] = t;
         }
-        const float2 *tw2d = tables[dev][slot];
+        const float2 *tw2d = set[0];
+        guard.unlock();
         const unsigned blocks = (unsigned)((count + (256 / E) - 1) / (256 / E));
         if (E == 8) {
             if (inverse) hipLaunchKernelGGL((k_fft_square_f32<8, true>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d);
@@ -1576,12 +1590,12 @@ extern "C" int llzs_fft_f32(float *data, int count, int size, const float *cs, i
         return LLZ_OK;
     }
     if ((size == 128 || size == 512 || size == 2048) && data && cs && count >= 1 && llzs_tune(LLZS_TUNE_FFT_GENERIC) < 1) {
-        static float2 *tables2[16][3][2];                           // [device][size][tw2d, tw1]
         int dev = 0;
         LLZ_HIP_CHECK(hipGetDevice(&dev));
-        const int E = size == 128 ? 8 : size == 512 ? 16 : 32, slot = size == 128 ? 2 : size == 512 ? 0 : 1, H = E * E;
-        if (dev < 0 || dev >= 16) dev = 0;
-        if (!tables2[dev][slot][0]) {
+        const int E = size == 128 ? 8 : size == 512 ? 16 : 32, H = E * E;
+        std::unique_lock<std::mutex> guard(g_derived_lock);
+        float2 **set = derived_slot(2, size, dev);
+        if (!set[0]) {
             float2 *a = nullptr, *b = nullptr;
             LLZ_HIP_CHECK(hipMalloc(&a, sizeof(float2) * (size_t)H));
             LLZ_HIP_CHECK(hipMalloc(&b, sizeof(float2) * (size_t)H));
@@ -1589,10 +1603,11 @@ extern "C" int llzs_fft_f32(float *data, int count, int size, const float *cs, i
                                b, cs, E);
             LLZ_LAUNCH_CHECK("k_fft_2xsquare_tables");
             LLZ_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
-            tables2[dev][slot][1] = b;
-            tables2[dev][slot][0] = a;
+            set[1] = b;
+            set[0] = a;
         }
-        const float2 *tw2d = tables2[dev][slot][0], *tw1 = tables2[dev][slot][1];
+        const float2 *tw2d = set[0], *tw1 = set[1];
+        guard.unlock();
         const unsigned blocks = (unsigned)((count + (256 / E) - 1) / (256 / E));
         if (E == 8) {
             if (inverse) hipLaunchKernelGGL((k_fft_2xsquare_f32<8, true>), dim3(blocks), dim3(256), 0, as_stream(stream), data, count, tw2d, tw1);
@@ -1636,12 +1651,12 @@ extern "C" int llzs_mdct4_reg_f32(const float *in, float *out, int count, int N,
         llzs_set_error("mdct4_reg_f32: bad arguments");
         return LLZ_ERR_ARG;
     }
-    static float2 *tabs[16][3][2][2];                              // [device][E = 8, 16, 32][two][tw2d, tw1]
     int dev = 0;
     LLZ_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) dev = 0;
-    const int slot = E == 8 ? 0 : E == 16 ? 1 : 2, H = E * E;
-    if (!tabs[dev][slot][two][0]) {
+    const int H = E * E;
+    std::unique_lock<std::mutex> guard(g_derived_lock);
+    float2 **set = derived_slot(3, 2 * E + (two ? 1 : 0), dev);
+    if (!set[0]) {
         float2 *a = nullptr, *b = nullptr;
         LLZ_HIP_CHECK(hipMalloc(&a, sizeof(float2) * (size_t)H));
         if (two) {
@@ -1654,10 +1669,11 @@ extern "C" int llzs_mdct4_reg_f32(const float *in, float *out, int count, int N,
         }
         LLZ_LAUNCH_CHECK("mdct twiddle tables");
         LLZ_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));   // published only once complete
-        tabs[dev][slot][two][1] = b;
-        tabs[dev][slot][two][0] = a;
+        set[1] = b;
+        set[0] = a;
     }
-    const float2 *tw2d = tabs[dev][slot][two][0], *tw1 = tabs[dev][slot][two][1];
+    const float2 *tw2d = set[0], *tw1 = set[1];
+    guard.unlock();
     const unsigned blocks = (unsigned)((count + (256 / E) - 1) / (256 / E));
     const float sqrt_cof = (float)(1.0 / sqrt((double)N));
 #define LLZ_MDCT_LAUNCH(EE, TT, II)                                                                                  \
@@ -1722,22 +1738,24 @@ extern "C" int llzs_acf_fused_f32(const float *x, float *r, int frames, int n, i
         return LLZ_ERR_ARG;
     }
     if ((size == 128 || size == 512) && llzs_tune(LLZS_TUNE_FFT_GENERIC) < 1) {   // the same on square_core (E = 8, 16)
-        static float2 *tabs[16][2];
         int dev = 0;
         LLZ_HIP_CHECK(hipGetDevice(&dev));
-        if (dev < 0 || dev >= 16) dev = 0;
-        const int E = size == 128 ? 8 : 16, slot = size == 128 ? 0 : 1, H = E * E;
-        if (!tabs[dev][slot]) {
+        const int E = size == 128 ? 8 : 16, H = E * E;
+        std::unique_lock<std::mutex> guard(g_derived_lock);
+        float2 **set = derived_slot(4, size, dev);
+        if (!set[0]) {
             float2 *a = nullptr;
             LLZ_HIP_CHECK(hipMalloc(&a, sizeof(float2) * (size_t)H));
             hipLaunchKernelGGL(k_acf_sq_table, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, as_stream(stream), a, cs, E);
             LLZ_LAUNCH_CHECK("k_acf_sq_table");
             LLZ_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
-            tabs[dev][slot] = a;
+            set[0] = a;
         }
+        const float2 *sq = set[0];
+        guard.unlock();
         const unsigned blocks = (unsigned)((frames + (256 / E) - 1) / (256 / E));
-        if (E == 8) hipLaunchKernelGGL(k_acf_sq_f32<8>, dim3(blocks), dim3(256), 0, as_stream(stream), x, r, frames, n, p, tabs[dev][slot], cs);
-        else hipLaunchKernelGGL(k_acf_sq_f32<16>, dim3(blocks), dim3(256), 0, as_stream(stream), x, r, frames, n, p, tabs[dev][slot], cs);
+        if (E == 8) hipLaunchKernelGGL(k_acf_sq_f32<8>, dim3(blocks), dim3(256), 0, as_stream(stream), x, r, frames, n, p, sq, cs);
+        else hipLaunchKernelGGL(k_acf_sq_f32<16>, dim3(blocks), dim3(256), 0, as_stream(stream), x, r, frames, n, p, sq, cs);
         LLZ_LAUNCH_CHECK("k_acf_sq_f32");
         return LLZ_OK;
     }
@@ -1804,12 +1822,12 @@ static int stft_check(int channels, int frames, int F, int size, int *log2n, con
 // device from the handle's table cs
 static int stft_reg_tables(int size, const float *cs, void *stream, const float2 **tw2d, const float2 **tw1)
 {
-    static float2 *tabs[16][3][2];                                  // [device][256, 512, 2048][tw2d, tw1]
     int dev = 0;
     LLZ_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) dev = 0;
-    const int slot = size == 256 ? 0 : size == 512 ? 1 : 2, E = size == 2048 ? 32 : 16, H = E * E;
-    if (!tabs[dev][slot][0]) {
+    const int E = size == 2048 ? 32 : 16, H = E * E;
+    std::lock_guard<std::mutex> guard(g_derived_lock);
+    float2 **set = derived_slot(5, size, dev);
+    if (!set[0]) {
         float2 *a = nullptr, *b = nullptr;
         LLZ_HIP_CHECK(hipMalloc(&a, sizeof(float2) * (size_t)H));
         if (size == 256) {
@@ -1822,11 +1840,11 @@ static int stft_reg_tables(int size, const float *cs, void *stream, const float2
         }
         LLZ_LAUNCH_CHECK("stft twiddle tables");
         LLZ_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
-        tabs[dev][slot][1] = b;
-        tabs[dev][slot][0] = a;
+        set[1] = b;
+        set[0] = a;
     }
-    *tw2d = tabs[dev][slot][0];
-    *tw1 = tabs[dev][slot][1];
+    *tw2d = set[0];
+    *tw1 = set[1];
     return LLZ_OK;
 }
 
@@ -1876,19 +1894,20 @@ extern "C" int llzs_fir_ols4096_f32(const float *in, float *out, const float *hi
         llzs_set_error("fir_ols4096_f32: bad arguments (flt_len=%d, 2..3073)", flt_len);
         return LLZ_ERR_ARG;
     }
-    static float2 *tabs[16];
     int dev = 0;
     LLZ_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) dev = 0;
-    if (!tabs[dev]) {
+    std::unique_lock<std::mutex> guard(g_derived_lock);
+    float2 **set = derived_slot(6, 4096, dev);
+    if (!set[0]) {
         float2 *t = nullptr;
         LLZ_HIP_CHECK(hipMalloc(&t, sizeof(float2) * 4096));
         hipLaunchKernelGGL(k_fft_square_table, dim3(16), dim3(256), 0, as_stream(stream), t, cs, 64);
         LLZ_LAUNCH_CHECK("k_fft_square_table");
         LLZ_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
-        tabs[dev] = t;
+        set[0] = t;
     }
-    const float2 *tw2d = tabs[dev];
+    const float2 *tw2d = set[0];
+    guard.unlock();
     const int keep = flt_len - 1, V = 4096 - keep;
     const int blocks_per_channel = (n + V - 1) / V;
     const int J = (blocks_per_channel + 1) / 2;                    // jobs (pairs of blocks) per channel

@@ -168,6 +168,14 @@ int llzs_iir_df1_f64(const double *in, double *out, const double *a, const doubl
 int llzs_resample_f32(const float *in, float *out, const float *hist, const float *g,
                       int channels, long n_in, long n_out, long in_pitch, long out_pitch,
                       int L, int M, int Q, float gain, long long i0, long long in0, void *stream);
+/* general L/M float32 on the fp32 matrix cores (resample_mfma.hip): atab [ceil(L/16)][steps][64] = the banded tap matrix in
+ * MFMA operand order with the gain folded in (steps = llzs_resample_mfma_f32_table_steps), c0tab [ceil(L/16)] =
+ * floor(16 t M / L).  The call must start on a period boundary (input index % M == 0, output index % L == 0). */
+int llzs_resample_mfma_f32(const float *in, float *out, const float *hist, const float *atab, const int *c0tab,
+                           int channels, long n_in, long n_out, long in_pitch, long out_pitch, int L, int M, int Q,
+                           void *stream);
+int llzs_resample_mfma_f32_fits(int L, int M, int Q);
+int llzs_resample_mfma_f32_table_steps(int L, int M, int Q);
 /* L = 1 (decimate by M) float32 fast path: gp = M x tp phase taps gp[m][j] = g[j*M+m], zero padded, tp % 16 == 0;
  * input index of output i is i*M (calls start on a period boundary); hist as above. */
 int llzs_resample_dec_f32(const float *in, float *out, const float *hist, const float *gp, int channels,

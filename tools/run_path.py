@@ -33,6 +33,15 @@ elif what == "resample_i16":
     r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, filters.PCM_I16)
     for _ in range(steps):
         r.process(x, y)
+elif what in ("rs147", "rs160"):
+    L_, M_ = (147, 160) if what == "rs147" else (160, 147)
+    ch, n = 256, M_ * 8192
+    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+    y = torch.empty(ch, n * L_ // M_, dtype=torch.float32, device=dev)
+    filters.synth_f32(x, 1)
+    r = filters.ResampleMC(ch, L_, M_, 1.0, filters.BLACKMAN, filters.PCM_F32)
+    for _ in range(steps * 5):
+        r.process(x, y)
 elif what in ("fir_td", "fir_ols"):
     ch, n = 4096, 1 << 20
     x = torch.empty(ch, n, dtype=torch.float32, device=dev)
