@@ -87,44 +87,25 @@ k_resample_mfma_f32(const float *__restrict__ in, float *__restrict__ out, const
 
     // this wave's 16 periods: column n is period m0 + 16 wave + n; its window for a phase tile starts at image element
     // (16 wave + n) M + c0(tile)   [history H and band start c0 - (Q-1) cancel]
-    const int col = (16 * wave + n) * sh.M;
     const long mw = m0 + 16 * wave;                                  // the wave's first period
     float *orow = out + (size_t)c * out_pitch;
     // results leave through a per-wave LDS buffer [16 periods][64 phases]: a wave instruction then stores 64 CONSECUTIVE
     // outputs of one period (stored straight from the accumulators a wave instruction would touch 64 separate dwords)
     float *stage = xs + sh.img + wave * (16 * RM_SROW);
-    float a[KS];
-    {
-        const float *ap = atab + lane;
+    // Window sample d = c0 + kq + 4 s of column n sits at image position colpos + d + pad * (d / M); d < M + 4 KS, so with
+    // M >= 4 KS the quotient is 0 or 1: two base addresses and one select per step instead of a division
+    const int colpos = (16 * wave + n) * (sh.M + sh.pad);
+    auto load_tile = [&](int t, float (&av)[KS], float (&bv)[KS]) {
+        const float *ap = atab + ((size_t)t * KS) * 64 + lane;
+        const int d0 = c0tab[t] + kq;
+        const float *lo = xs + colpos + d0, *hi = lo + sh.pad;
 #pragma unroll
-        for (int s = 0; s < KS; s++) a[s] = ap[s * 64];
-    }
-    float b[KS];                                                     // the tile's 16-column window samples, one per step
-    {
-        const int e0 = col + c0tab[0] + kq;
-#pragma unroll
-        for (int s = 0; s < KS; s++) b[s] = xs[pos_of(e0 + 4 * s)];
-    }
-#pragma unroll 1
-    for (int t = 0; t < sh.ntiles; t++) {
-        float an[KS], bn[KS];                                        // the next tile's taps and samples arrive during this tile's products
-        const bool more = t + 1 < sh.ntiles;
-        if (more) {
-            const float *ap = atab + ((size_t)(t + 1) * KS) * 64 + lane;
-            const int e0 = col + c0tab[t + 1] + kq;
-#pragma unroll
-            for (int s = 0; s < KS; s++) {
-                an[s] = ap[s * 64];
-                bn[s] = xs[pos_of(e0 + 4 * s)];
-            }
+        for (int s = 0; s < KS; s++) {
+            av[s] = ap[s * 64];
+            bv[s] = (d0 + 4 * s >= sh.M ? hi : lo)[4 * s];
         }
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
-        if (more) {
-#pragma unroll
-            for (int s = 0; s < KS; s++) { a[s] = an[s]; b[s] = bn[s]; }
-        }
+    };
+    auto finish_tile = [&](int t, const f32x4 &acc) {
         // D[4 kq + j][n] = output (phase 16 t + 4 kq + j, period mw + n) -> stage[n][16 (t % CHUNK) + 4 kq + j]
         *reinterpret_cast<f32x4 *>(&stage[n * RM_SROW + 16 * (t % RM_CHUNK) + 4 * kq]) = acc;
         if ((t % RM_CHUNK) == RM_CHUNK - 1 || t == sh.ntiles - 1) {
@@ -139,6 +120,24 @@ k_resample_mfma_f32(const float *__restrict__ in, float *__restrict__ out, const
                 if (l5 < run && o < n_out) __builtin_nontemporal_store(stage[(r + half) * RM_SROW + l5], &orow[o]);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads done before the next chunk overwrites the buffer
+        }
+    };
+    auto products = [&](const float (&av)[KS], const float (&bv)[KS]) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+        return acc;
+    };
+    // two register sets in turn: a tile's taps and samples arrive during the previous tile's products
+    float a0[KS], b0[KS], a1[KS], b1[KS];
+    load_tile(0, a0, b0);
+#pragma unroll 1
+    for (int t = 0; t < sh.ntiles; t += 2) {
+        if (t + 1 < sh.ntiles) load_tile(t + 1, a1, b1);
+        finish_tile(t, products(a0, b0));
+        if (t + 1 < sh.ntiles) {
+            if (t + 2 < sh.ntiles) load_tile(t + 2, a0, b0);
+            finish_tile(t + 1, products(a1, b1));
         }
     }
 }
@@ -180,13 +179,13 @@ extern "C" int llzs_resample_mfma_f32_table_steps(int L, int M, int Q)
 
 extern "C" int llzs_resample_mfma_f32_fits(int L, int M, int Q)
 {
-    // small L: the register-window kernel; short periods (M < 32) give a workgroup too little to do per staged span:
-    // the LDS form is faster there (8:7: 1.8 against 3.8 ms)
+    // small L: the register-window kernel; short periods (M < a band's 4 KS samples) give a workgroup too little to do per
+    // staged span: the LDS form is faster there (8:7: 1.8 against 3.8 ms)
     if (L < 5 || M < 1 || Q < 1) return 0;
     if (llzs_resample_mfma_f32_ksteps(L, M, Q) > 32) return 0;
     const int waves = rm_waves(M), kst = llzs_resample_mfma_f32_table_steps(L, M, Q);
     const size_t lds = (rm_image_floats(M, Q, waves, kst) + 4 + (size_t)waves * 16 * RM_SROW) * sizeof(float);
-    return M >= 32 && lds <= 160 * 1024 && (long)16 * waves * M + Q + 128 < (long)(0x100000000ull / (unsigned)M);
+    return M >= 4 * kst && lds <= 160 * 1024 && (long)16 * waves * M + Q + 128 < (long)(0x100000000ull / (unsigned)M);
 }
 
 // atab: [ceil(L/16)][steps][64] floats (steps = llzs_resample_mfma_f32_table_steps), gain folded in; c0tab: [ceil(L/16)]
