@@ -149,6 +149,7 @@ typedef struct {
     float *d_taps;              /* flt_len floats zero-padded to a multiple of 16 */
     float *d_hfreq, *d_twid;    /* overlap-save tables (NULL for the time-domain algorithm) */
     float *d_hperm2, *d_cs2;    /* 2048- / 4096-point overlap-save: permuted spectrum and the cos/sin table */
+    float *d_tw2k;              /* 2048-point transforms split over the half-waves (<= 513 taps): W_2048^n, n < 1024 */
     float *d_hist[2];           /* [channels][flt_len-1], ping-pong */
     int cur;
     float *d_zero;              /* [channels][flt_len-1] zeros: flush input */
@@ -159,7 +160,7 @@ typedef struct {
 static void firm_destroy(firm_t *f)
 {
     if (!f) return;
-    llzs_free(f->d_taps); llzs_free(f->d_hfreq); llzs_free(f->d_twid); llzs_free(f->d_hperm2); llzs_free(f->d_cs2);
+    llzs_free(f->d_taps); llzs_free(f->d_hfreq); llzs_free(f->d_twid); llzs_free(f->d_hperm2); llzs_free(f->d_cs2); llzs_free(f->d_tw2k);
     llzs_free(f->d_hist[0]); llzs_free(f->d_hist[1]); llzs_free(f->d_zero);
     llz_stage_release(&f->st_in); llz_stage_release(&f->st_out);
     f->tag = 0;
@@ -205,6 +206,55 @@ static int firm_build_ols_tables(firm_t *f, const float *taps)
         if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_twid, tw, sizeof(float) * 2 * 1024);
     }
     free(hf); free(tw); free(cs);
+    return rc;
+}
+
+/* 258 .. 513 taps (k_fir_ols2k_walk_f32): DFT_2048(taps) / 2048 as [even bins | odd bins], the 32 x 32 twiddles of the
+ * 1024-point halves, and W_2048^n for the radix-2 step.  Direct DFT in double, setup time only. */
+static int firm_build_ols2k_tables(firm_t *f, const float *taps)
+{
+    const int N = 2048, H = 1024;
+    float *hf = (float *)malloc(sizeof(float) * 2 * (size_t)N);
+    float *tw = (float *)malloc(sizeof(float) * 2 * 1024);
+    float *w2 = (float *)malloc(sizeof(float) * 2 * (size_t)H);
+    double *cs = (double *)malloc(sizeof(double) * 2 * (size_t)N);
+    int rc = LLZ_ERR_NOMEM;
+    if (hf && tw && w2 && cs) {
+        for (int i = 0; i < N; i++) {
+            const double ang = 2.0 * M_PI * (double)i / (double)N;
+            cs[2 * i] = (i == N / 4 || i == 3 * N / 4) ? 0.0 : cos(ang);
+            cs[2 * i + 1] = (i == 0 || i == N / 2) ? 0.0 : sin(ang);
+        }
+        for (int k = 0; k < N; k++) {
+            double re = 0.0, im = 0.0;
+            for (int t = 0; t < f->flt_len; t++) {
+                const int m = (int)(((long)k * t) % N);
+                re += (double)taps[t] * cs[2 * m];
+                im -= (double)taps[t] * cs[2 * m + 1];
+            }
+            const int dst = (k & 1) * H + (k >> 1);                    /* even bins first, then odd bins */
+            hf[2 * dst] = (float)(re / N);
+            hf[2 * dst + 1] = (float)(im / N);
+        }
+        for (int a = 0; a < 32; a++)
+            for (int b = 0; b < 32; b++) {
+                const int m = (2 * a * b) % N;                         /* W_1024^(ab) = W_2048^(2ab) */
+                tw[2 * (a * 32 + b)] = (float)cs[2 * m];
+                tw[2 * (a * 32 + b) + 1] = (float)(-cs[2 * m + 1]);
+            }
+        for (int i = 0; i < H; i++) {
+            w2[2 * i] = (float)cs[2 * i];
+            w2[2 * i + 1] = (float)(-cs[2 * i + 1]);                   /* W = exp(-2 pi j i / 2048) */
+        }
+        f->d_hfreq = (float *)llzs_malloc(sizeof(float) * 2 * (size_t)N);
+        f->d_twid = (float *)llzs_malloc(sizeof(float) * 2 * 1024);
+        f->d_tw2k = (float *)llzs_malloc(sizeof(float) * 2 * (size_t)H);
+        rc = (f->d_hfreq && f->d_twid && f->d_tw2k) ? LLZ_OK : LLZ_ERR_NOMEM;
+        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_hfreq, hf, sizeof(float) * 2 * (size_t)N);
+        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_twid, tw, sizeof(float) * 2 * 1024);
+        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_tw2k, w2, sizeof(float) * 2 * (size_t)H);
+    }
+    free(hf); free(tw); free(w2); free(cs);
     return rc;
 }
 
@@ -280,9 +330,9 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
          * matrix-core form of the time domain (23.7 ms at 257 taps against 31.9 ms on the VALU) */
         if (flt_len <= 32) algo = LLZ_FIR_ALGO_TIME;
         else if (flt_len <= LLZS_OLS_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE;
-        /* 2048- against 4096-point overlap-save (4096 ch x 2^20): 12.1 against ~12.4 ms at 513 taps, 16.9 against 14.8 at
-         * 1025; both go as 1 / (valid outputs per block), which puts the crossover at ~550 taps */
-        else if (flt_len <= 550) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_2048;
+        /* 2048-point overlap-save on a whole wave (4096 ch x 2^20): 7.9 ms up to 513 taps, 10.6 ms up to 1025; the 4096-point
+         * kernel needs 13.2 / 14.8 ms at 513 / 1025 taps */
+        else if (flt_len <= LLZS_OLS2K_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_2048;
         else if (flt_len <= LLZS_OLS4_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_4096;
         else algo = llzs_fir_mfma_f32_fits(flt_len, 1) ? LLZ_FIR_ALGO_TIME_MFMA : LLZ_FIR_ALGO_TIME;
     }
@@ -330,7 +380,9 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
     if (rc == LLZ_OK) rc = llzs_memset(f->d_hist[1], 0, hist_bytes, NULL);
     if (rc == LLZ_OK) rc = llzs_memset(f->d_zero, 0, hist_bytes, NULL);
     if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE) rc = firm_build_ols_tables(f, taps);
-    if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048) rc = firm_build_ols_big_tables(f, taps, LLZS_OLS2_NFFT);
+    if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048)
+        rc = (flt_len <= LLZS_OLS2K_MAX_TAPS && llzs_tune(LLZS_TUNE_FIR_PART) != 0) ? firm_build_ols2k_tables(f, taps)
+                                                                                    : firm_build_ols_big_tables(f, taps, LLZS_OLS2_NFFT);
     if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE_4096) rc = firm_build_ols_big_tables(f, taps, LLZS_OLS4_NFFT);
     if (rc == LLZ_OK) rc = llzs_sync(NULL);
     free(padded);
@@ -427,6 +479,9 @@ static int firm_launch(firm_t *f, const float *d_in, float *d_out, int n, long p
     if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE)
         rc = llzs_fir_ols_f32(d_in, d_out, hist, f->d_hfreq, f->d_twid, f->channels, n, pitch_in, pitch_out,
                               f->flt_len, f->stream);
+    else if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048 && f->d_tw2k)
+        rc = llzs_fir_ols2k_f32(d_in, d_out, hist, f->d_hfreq, f->d_twid, f->d_tw2k, f->channels, n, pitch_in, pitch_out,
+                                f->flt_len, f->stream);
     else if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048)
         rc = llzs_fir_ols2048_f32(d_in, d_out, hist, f->d_hperm2, f->d_cs2, f->channels, n, pitch_in, pitch_out,
                                   f->flt_len, f->stream);

@@ -336,6 +336,163 @@ k_fir_ols_chain_f32(const float *__restrict__ in, float *__restrict__ out, const
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 258 .. 1025 taps: the same walk on 2048-point transforms, a WHOLE WAVE per job.
+//
+// A 2048-point transform held by one half-wave needs 64 complex registers per lane and spills (k_fir_ols2048_f32 in fft.hip:
+// 12.4 ms at 513 taps).  Here one radix-2 step splits it over the wave's two half-waves, each of which then runs the
+// 1024-point machinery above unchanged:
+//     forward (decimation in frequency):  X[2k]   = FFT_1024( a[n] + a[n+1024] )            -> lower half-wave
+//                                         X[2k+1] = FFT_1024( (a[n] - a[n+1024]) W_2048^n ) -> upper half-wave
+//     inverse (decimation in time):       y[n], y[n+1024] = S'[n] +- W_2048^-n D'[n],   S' / D' = the halves' inverse transforms
+// A block is 64 rows of 32 samples; lane (half h, l5) owns the rows of parity h (2p + h, p < 32) at column l5, so rows p
+// and p + 16 of a lane are 1024 samples apart: the butterflies are in-lane, and ONE v_permlane32_swap per register pair
+// then hands all sums to the lower and all differences to the upper half-wave (and back after the inverse transforms).
+// Because a row's parity survives the walk's shifts (the 512-sample overlap is 16 rows, a block advances by 48 rows), the
+// carried overlap stays in the lane that needs it, and ols_assemble / ols_raw are the 1024-point kernel's.  Lower and upper
+// lanes load adjacent rows: a wave instruction moves 256 contiguous bytes.  Job = two blocks (real / imaginary part) =
+// 3072 new samples of one channel.
+// Template parameter O = the overlap: 512 samples (16 rows, up to 513 taps, 1536 new samples per block) or 1024 (32 rows,
+// up to 1025 taps, 1024 new samples per block).
+
+__device__ __forceinline__ void swap32(float &x, float &y)          // x's upper half-wave <-> y's lower half-wave
+{
+    const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(p[0]);
+    y = __uint_as_float(p[1]);
+}
+
+template <int O>
+__global__ void __launch_bounds__(OLS_THREADS, 2)
+k_fir_ols2k_walk_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
+                     const float2 *__restrict__ hfreq2 /* [2][1024]: even bins, odd bins, / 2048 */,
+                     const float2 *__restrict__ twid /* [32][32] W_1024^(ab) */, const float2 *__restrict__ tw2k /* [1024] W_2048^n */,
+                     ols_geom G)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *s_tw = reinterpret_cast<float2 *>(smem);           // [1024]
+    float2 *s_h = s_tw + 1024;                                  // [2][1024]
+    float2 *s_w = s_h + 2048;                                   // [1024]
+    for (int i = threadIdx.x; i < 1024; i += OLS_THREADS) {
+        s_tw[i] = twid[i];
+        s_h[i] = hfreq2[i];
+        s_h[1024 + i] = hfreq2[1024 + i];
+        s_w[i] = tw2k[i];
+    }
+    __syncthreads();
+    constexpr int O2K_OVERLAP = O, O2K_VALID = 2048 - O, O2K_JOB = 2 * O2K_VALID;
+    constexpr int HP = O / 64, NEW = 32 - HP;                       // a lane's carried and new rows per block
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, l5 = lane & 31;
+    float *buf = reinterpret_cast<float *>(s_w + 1024) + (wave * 2 + half) * OLS_XBUF;
+    const float2 *my_h = s_h + half * 1024;
+    const long waves_total = (long)gridDim.x * OLS_WAVES;
+    const int rowoff = 32 * half + l5;                              // this lane inside a pair of rows
+
+    for (long seg = (long)blockIdx.x * OLS_WAVES + wave; seg < G.total_segs; seg += waves_total) {
+        const int c = (int)(seg / G.segs_per_channel);
+        const int j0 = (int)(seg - (long)c * G.segs_per_channel) * G.seg_len;
+        const int count = min(G.seg_len, G.jobs_per_channel - j0);
+        const float *row = in + (size_t)c * G.in_pitch;
+        float *orow = out + (size_t)c * G.out_pitch;
+        const float *hrow = hist ? hist + (size_t)c * G.keep : nullptr;
+        const int n = G.n;
+
+        // rows 2i + h (i < HP) in front of the segment: from the row, the history or zeros
+        float halo[HP];
+#pragma unroll
+        for (int i = 0; i < HP; i++) {
+            const int idx = j0 * O2K_JOB - O2K_OVERLAP + 64 * i + rowoff;
+            float v = 0.f;
+            if (idx >= 0) v = row[idx];
+            else if (hrow && idx >= -G.keep) v = hrow[G.keep + idx];
+            halo[i] = v;
+        }
+        ols_raw raw;
+        auto load = [&](int s) {                                   // the new samples of the job at s: 2 NEW per lane
+            if (s + O2K_JOB <= n) {
+#pragma unroll
+                for (int i = 0; i < NEW; i++) {
+                    raw.a[i] = __builtin_nontemporal_load(&row[s + 64 * i + rowoff]);
+                    raw.b[i] = __builtin_nontemporal_load(&row[s + O2K_VALID + 64 * i + rowoff]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NEW; i++) {
+                    const int ia = s + 64 * i + rowoff, ib = ia + O2K_VALID;
+                    const float xa = row[min(ia, n - 1)], xb = row[min(ib, n - 1)];
+                    raw.a[i] = ia < n ? xa : 0.f;
+                    raw.b[i] = ib < n ? xb : 0.f;
+                }
+            }
+        };
+        load(j0 * O2K_JOB);
+#pragma unroll 1
+        for (int jj = 0; jj < count; jj++) {
+            const int s = (j0 + jj) * O2K_JOB;
+            cf v[32], u[32];
+            // v[p] = row 2p + h of blocks A (re) and B (im): block A's first HP positions are the carried overlap, block B's
+            // are block A's last HP; the new overlap is block B's last HP
+#pragma unroll
+            for (int i = 0; i < HP; i++) {
+                v[i].x = halo[i];
+                v[i].y = raw.a[NEW - HP + i];
+                halo[i] = raw.b[NEW - HP + i];
+            }
+#pragma unroll
+            for (int i = 0; i < NEW; i++) {
+                v[HP + i].x = raw.a[i];
+                v[HP + i].y = raw.b[i];
+            }
+            load(s + O2K_JOB);                                      // (past the segment's last job: issued and discarded)
+            // ---- radix-2 step down: rows p and p + 16 are 1024 samples apart.  Every lane twiddles the differences of its
+            // own 16 rows BEFORE they move to the upper half-wave (half the multiplies the upper lanes alone would need)
+            cf w[32];
+#pragma unroll
+            for (int p = 0; p < 16; p++) {
+                cf sm = cadd(v[p], v[p + 16]);
+                const float2 t = s_w[64 * p + rowoff];              // W_2048^n, n = 32 (2p + h) + l5
+                cf df = cmul<false>(csub(v[p], v[p + 16]), cf{t.x, t.y});
+                swap32(sm.x, df.x);                                 // lower: (s_2p, s_2p+1)   upper: (d_2p, d_2p+1)
+                swap32(sm.y, df.y);
+                w[2 * p] = sm;
+                w[2 * p + 1] = df;
+            }
+            // ---- 1024 points per half-wave: forward, spectrum product, inverse
+            ols_filter(w, u, buf, s_tw, my_h, l5, l5);              // u[r] = S' or D' at row brev5(r)
+            // ---- radix-2 step up and the stores of the valid rows (positions >= HP)
+            const bool whole = s + O2K_JOB <= n;
+            const int oa = s - O2K_OVERLAP + rowoff, ob = oa + O2K_VALID;
+#pragma unroll
+            for (int p = 0; p < 16; p++) {
+                cf P = u[brev5(2 * p)], Q = u[brev5(2 * p + 1)];
+                swap32(P.x, Q.x);                                   // lower: (S_2p, D_2p)   upper: (S_2p+1, D_2p+1)
+                swap32(P.y, Q.y);
+                const float2 t = s_w[64 * p + rowoff];
+                Q = cmul<true>(Q, cf{t.x, t.y});                    // W_2048^-n on the lane's own 16 differences
+                const cf y0 = cadd(P, Q), y1 = csub(P, Q);          // rows 2p + h and 2p + h + 32 = positions p, p + 16
+                if (whole) {
+                    if (p >= HP) {
+                        __builtin_nontemporal_store(y0.x, &orow[oa + 64 * p]);
+                        __builtin_nontemporal_store(y0.y, &orow[ob + 64 * p]);
+                    }
+                    __builtin_nontemporal_store(y1.x, &orow[oa + 64 * (p + 16)]);
+                    __builtin_nontemporal_store(y1.y, &orow[ob + 64 * (p + 16)]);
+                } else {
+                    if (p >= HP) {
+                        if (oa + 64 * p < n) orow[oa + 64 * p] = y0.x;
+                        if (ob + 64 * p < n) orow[ob + 64 * p] = y0.y;
+                    }
+                    if (oa + 64 * (p + 16) < n) orow[oa + 64 * (p + 16)] = y1.x;
+                    if (ob + 64 * (p + 16) < n) orow[ob + 64 * (p + 16)] = y1.y;
+                }
+            }
+        }
+    }
+}
+
 } // namespace
 
 extern "C" int llzs_fir_ols_f32(const float *in, float *out, const float *hist, const float *hfreq,
@@ -391,5 +548,58 @@ extern "C" int llzs_fir_ols_f32(const float *in, float *out, const float *hist, 
     else
         hipLaunchKernelGGL(k_fir_ols_walk_f32, grid, block, lds_bytes, as_stream(stream), in, out, hist, hf, tw, G);
     LLZ_LAUNCH_CHECK("k_fir_ols_f32");
+    return LLZ_OK;
+}
+
+// 258 .. 1025 taps on 2048-point transforms split over the two half-waves (k_fir_ols2k_walk_f32): hfreq2 = [2][1024] complex,
+// even then odd bins of DFT_2048(taps) / 2048 in natural order; twid as above; tw2k = [1024] complex W_2048^n
+extern "C" int llzs_fir_ols2k_f32(const float *in, float *out, const float *hist, const float *hfreq2, const float *twid,
+                                  const float *tw2k, int channels, int n, long in_pitch, long out_pitch, int flt_len,
+                                  void *stream)
+{
+    if (!in || !out || !hfreq2 || !twid || !tw2k || channels <= 0 || n <= 0 || in_pitch < n || out_pitch < n ||
+        flt_len < 2 || flt_len > 1025) {
+        llzs_set_error("fir_ols2k_f32: bad arguments (flt_len=%d, 2..1025)", flt_len);
+        return LLZ_ERR_ARG;
+    }
+    const int overlap = flt_len <= 513 ? 512 : 1024;
+    const int O2K_JOB = 2 * (2048 - overlap);
+    ols_geom G;
+    G.n = n;
+    G.keep = flt_len - 1;
+    G.in_pitch = in_pitch;
+    G.out_pitch = out_pitch;
+    G.jobs_per_channel = (n + O2K_JOB - 1) / O2K_JOB;
+    const size_t lds_bytes = 4 * 1024 * sizeof(float2) + (size_t)OLS_WAVES * 2 * OLS_XBUF * sizeof(float);
+    const long max_blocks = 256L * 2;
+    const long slots = max_blocks * OLS_WAVES;                  // a wave per segment
+    int seg_len = OLS_SEG;
+    if ((long)((G.jobs_per_channel + OLS_SEG - 1) / OLS_SEG) * channels < 4 * slots) {
+        double best = 1e300;
+        for (int sl = OLS_SEG; sl >= 1; sl--) {
+            const long segs = (long)((G.jobs_per_channel + sl - 1) / sl) * channels;
+            const double cost = (double)((segs + slots - 1) / slots) * (sl + 1.0);
+            if (cost < best * 0.999) { best = cost; seg_len = sl; }
+        }
+    }
+    G.seg_len = seg_len;
+    G.segs_per_channel = (G.jobs_per_channel + seg_len - 1) / seg_len;
+    G.total_segs = (long)G.segs_per_channel * channels;
+    long blocks = (G.total_segs + OLS_WAVES - 1) / OLS_WAVES;
+    if (blocks > max_blocks) blocks = max_blocks;
+    const float2 *hf = reinterpret_cast<const float2 *>(hfreq2), *tw = reinterpret_cast<const float2 *>(twid),
+                 *w2 = reinterpret_cast<const float2 *>(tw2k);
+    if (overlap == 512) {
+        LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_ols2k_walk_f32<512>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(k_fir_ols2k_walk_f32<512>, dim3((unsigned)blocks), dim3(OLS_THREADS), lds_bytes, as_stream(stream),
+                           in, out, hist, hf, tw, w2, G);
+    } else {
+        LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_ols2k_walk_f32<1024>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(k_fir_ols2k_walk_f32<1024>, dim3((unsigned)blocks), dim3(OLS_THREADS), lds_bytes, as_stream(stream),
+                           in, out, hist, hf, tw, w2, G);
+    }
+    LLZ_LAUNCH_CHECK("k_fir_ols2k_walk_f32");
     return LLZ_OK;
 }

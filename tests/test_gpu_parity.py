@@ -149,8 +149,8 @@ def test_fir_mc_host_pointers_and_errors(dev, oracle):
     assert filters.FirFilterMC(2, 64, np.ones(257)).algo == filters.FIR_ALGO_OVERLAP_SAVE
     assert filters.FirFilterMC(2, 64, np.ones(63)).algo == filters.FIR_ALGO_OVERLAP_SAVE      # AUTO: 33..257 taps
     assert filters.FirFilterMC(2, 64, np.ones(32)).algo == filters.FIR_ALGO_TIME
-    assert filters.FirFilterMC(2, 64, np.ones(300)).algo == filters.FIR_ALGO_OVERLAP_SAVE_2048   # 258..550
-    assert filters.FirFilterMC(2, 64, np.ones(2000)).algo == filters.FIR_ALGO_OVERLAP_SAVE_4096  # 551..3073
+    assert filters.FirFilterMC(2, 64, np.ones(300)).algo == filters.FIR_ALGO_OVERLAP_SAVE_2048   # 258..1025
+    assert filters.FirFilterMC(2, 64, np.ones(2000)).algo == filters.FIR_ALGO_OVERLAP_SAVE_4096  # 1026..3073
     assert filters.FirFilterMC(2, 64, np.ones(300), algo=filters.FIR_ALGO_TIME_MFMA).algo == filters.FIR_ALGO_TIME_MFMA
 
 
@@ -880,11 +880,24 @@ def test_mdct_batch_vs_oracle(dev, oracle, n, count):
 
 
 # ------------------------------------------------------------------------------------------------ overlap-save, 2048 points
+@pytest.mark.parametrize("form", ["wave", "half-wave"])
 @pytest.mark.parametrize("taps_n,channels,n", [(258, 3, 5000), (513, 5, 1536 * 4 + 1), (1025, 2, 1024 * 7), (300, 9, 700),
-                                               (1025, 70, 1024 * 40 + 3), (2, 3, 4096)])
-def test_fir_ols2048_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
-    """filters of 258..1025 taps on the 2048-point register-transform overlap-save (k_fir_ols2048_f32): two frames (history
-    carried by the handle) and the flush tail, ragged lengths, blocks that end past the frame, and the automatic choice"""
+                                               (1025, 70, 1024 * 40 + 3), (2, 3, 4096), (513, 6, 3072 * 20 + 77),
+                                               (400, 300, 3072 * 3), (512, 1, 3072 * 17)])
+def test_fir_ols2048_vs_oracle_streaming(dev, oracle, taps_n, channels, n, form):
+    """filters of 258..1025 taps on 2048-point overlap-save: up to 513 taps the whole-wave walk kernel (k_fir_ols2k_walk_f32,
+    one radix-2 step across the half-waves), above it -- or when llz_hip_tune("fir_ols2k", 0) asks -- the half-wave kernel
+    of fft.hip: two frames (history carried by the handle) and the flush tail, ragged lengths, segments of several jobs,
+    blocks that end past the frame, and the automatic choice"""
+    if form == "half-wave":
+        capi.tune("fir_ols2k", 0)
+    try:
+        _fir_ols2048_case(dev, oracle, taps_n, channels, n)
+    finally:
+        capi.tune("fir_ols2k", -1)
+
+
+def _fir_ols2048_case(dev, oracle, taps_n, channels, n):
     taps = oracle.fir_design(po.LPF, taps_n, 0.2, 0.0, po.KAISER)
     x = oracle.synth_f32(channels, 2 * n, seed=taps_n)
     ref = oracle.fir_batch_f32(x, taps.astype(np.float32).astype(np.float64))
@@ -903,8 +916,8 @@ def test_fir_ols2048_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
     full = oracle.fir_batch_f32(np.concatenate([x, np.zeros((channels, taps_n - 1), np.float32)], axis=1),
                                 taps.astype(np.float32).astype(np.float64))
     assert np.sqrt(np.mean((tail.cpu().numpy() - full[:, 2 * n:]) ** 2)) <= TOL
-    if 257 < taps_n <= 550:
-        g = filters.FirFilterMC(channels, n, taps)                 # AUTO: 258..550 taps
+    if 257 < taps_n <= 1025:
+        g = filters.FirFilterMC(channels, n, taps)                 # AUTO: 258..1025 taps
         assert g.algo == filters.FIR_ALGO_OVERLAP_SAVE_2048
         g.close()
 
@@ -932,8 +945,8 @@ def test_fir_ols4096_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
     full = oracle.fir_batch_f32(np.concatenate([x, np.zeros((channels, taps_n - 1), np.float32)], axis=1),
                                 taps.astype(np.float32).astype(np.float64))
     assert np.sqrt(np.mean((tail.cpu().numpy() - full[:, 2 * n:]) ** 2)) <= TOL
-    if taps_n > 550:
-        g = filters.FirFilterMC(channels, n, taps)                 # AUTO: 551..3073 taps
+    if taps_n > 1025:
+        g = filters.FirFilterMC(channels, n, taps)                 # AUTO: 1026..3073 taps
         assert g.algo == filters.FIR_ALGO_OVERLAP_SAVE_4096
         g.close()
 
