@@ -30,6 +30,14 @@ class LlzError(RuntimeError):
     pass
 
 
+class WavInfo(C.Structure):                  # llz_wav_info (include/llz_pcm.h)
+    _fields_ = [("format", C.c_int), ("channels", C.c_int), ("samplerate", C.c_long), ("bytes_per_sample", C.c_int),
+                ("block_align", C.c_int), ("frames", C.c_long), ("data_offset", C.c_long)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _t in self._fields_}
+
+
 def build(force=False, extra_hipflags=""):
     """Compile every HIP kernel for gfx950 and link the shared library in-tree (hipcc cross-compiles on CPU)."""
     cmd = ["make", "-s", "-C", os.path.join(HERE, "csrc"), "-j4"]
@@ -244,6 +252,9 @@ def lib():
     # llz_pcm.h
     sig("llz_pcm_deinterleave_i16_f32", i, vp, vp, i, lng, C.c_float, vp)
     sig("llz_pcm_interleave_f32_i16", i, vp, vp, i, lng, C.c_float, vp)
+    sig("llz_wav_parse", i, C.c_char_p, lng, vp)
+    sig("llz_wav_write_header", i, vp, vp)
+    sig("llz_wav_ingest_f32", lng, C.c_char_p, lng, vp, lng, vp, vp)
     _lib = L
     # measurement harness only: LLZ_TUNE="name=value,..." is applied HERE (Python), through the public override call;
     # the C library itself never reads the environment

@@ -148,8 +148,8 @@ typedef struct {
     int channels, frame_len, flt_len, algo;
     float *d_taps;              /* flt_len floats zero-padded to a multiple of 16 */
     float *d_hfreq, *d_twid;    /* overlap-save tables (NULL for the time-domain algorithm) */
-    float *d_hperm2, *d_cs2;    /* 2048- / 4096-point overlap-save: permuted spectrum and the cos/sin table */
-    float *d_tw2k;              /* 2048-point transforms split over the half-waves (<= 513 taps): W_2048^n, n < 1024 */
+    float *d_hperm2, *d_cs2;    /* 4096-point overlap-save: permuted spectrum and the cos/sin table */
+    float *d_tw2k;              /* 2048-point overlap-save: W_2048^n, n < 1024 (d_hfreq: even | odd bins) */
     float *d_hist[2];           /* [channels][flt_len-1], ping-pong */
     int cur;
     float *d_zero;              /* [channels][flt_len-1] zeros: flush input */
@@ -209,7 +209,7 @@ static int firm_build_ols_tables(firm_t *f, const float *taps)
     return rc;
 }
 
-/* 258 .. 513 taps (k_fir_ols2k_walk_f32): DFT_2048(taps) / 2048 as [even bins | odd bins], the 32 x 32 twiddles of the
+/* 258 .. 1025 taps (k_fir_ols2k_walk_f32): DFT_2048(taps) / 2048 as [even bins | odd bins], the 32 x 32 twiddles of the
  * 1024-point halves, and W_2048^n for the radix-2 step.  Direct DFT in double, setup time only. */
 static int firm_build_ols2k_tables(firm_t *f, const float *taps)
 {
@@ -258,9 +258,9 @@ static int firm_build_ols2k_tables(firm_t *f, const float *taps)
     return rc;
 }
 
-/* 2048- and 4096-point overlap-save: the taps' spectrum / N in the output order of the register transform and the size-N
- * cos/sin table the device derives its transform tables from.  N = 2048 (2 x 32^2): [q][lane] = (H[2k], H[2k+1]),
- * k = lane + 32 brev5(q);  N = 4096 (64^2): [q][lane] = H[lane + 64 brev6(q)].  Direct DFT in double, setup time only. */
+/* 4096-point overlap-save (fft.hip): the taps' spectrum / N in the output order of the 64 x 64 register transform,
+ * [q][lane] = H[lane + 64 brev6(q)], and the size-N cos/sin table the device derives its transform tables from.  Direct DFT
+ * in double, setup time only. */
 static int firm_build_ols_big_tables(firm_t *f, const float *taps, int N)
 {
     float *hp = (float *)malloc(sizeof(float) * 2 * (size_t)N);
@@ -286,26 +286,14 @@ static int firm_build_ols_big_tables(firm_t *f, const float *taps, int N)
             hf[2 * k] = re / N;
             hf[2 * k + 1] = im / N;
         }
-        if (N == 2048) {
-            for (int q = 0; q < 32; q++) {
-                const int bq = ((q & 1) << 4) | ((q & 2) << 2) | (q & 4) | ((q & 8) >> 2) | ((q & 16) >> 4);
-                for (int l = 0; l < 32; l++) {
-                    const int k = l + 32 * bq;
-                    float *e = hp + 4 * (q * 32 + l);
-                    e[0] = (float)hf[2 * (2 * k)]; e[1] = (float)hf[2 * (2 * k) + 1];
-                    e[2] = (float)hf[2 * (2 * k + 1)]; e[3] = (float)hf[2 * (2 * k + 1) + 1];
-                }
-            }
-        } else {
-            for (int q = 0; q < 64; q++) {
-                int bq = 0;
-                for (int b = 0; b < 6; b++)
-                    if (q & (1 << b)) bq |= 1 << (5 - b);
-                for (int l = 0; l < 64; l++) {
-                    const int k = l + 64 * bq;
-                    hp[2 * (q * 64 + l)] = (float)hf[2 * k];
-                    hp[2 * (q * 64 + l) + 1] = (float)hf[2 * k + 1];
-                }
+        for (int q = 0; q < 64; q++) {
+            int bq = 0;
+            for (int b = 0; b < 6; b++)
+                if (q & (1 << b)) bq |= 1 << (5 - b);
+            for (int l = 0; l < 64; l++) {
+                const int k = l + 64 * bq;
+                hp[2 * (q * 64 + l)] = (float)hf[2 * k];
+                hp[2 * (q * 64 + l) + 1] = (float)hf[2 * k + 1];
             }
         }
         f->d_hperm2 = (float *)llzs_malloc(sizeof(float) * 2 * (size_t)N);
@@ -322,6 +310,11 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
 {
     if (channels < 1 || channels > 65535 || frame_len < 1 || !taps || flt_len < 1) {
         llzs_set_error("llz_fir_filter_mc_init: channels %d frame_len %d flt_len %d", channels, frame_len, flt_len);
+        return LLZ_BAD_HANDLE;
+    }
+    if (!llzs_fir_td_f32_fits(flt_len)) {
+        /* every handle flushes through the time-domain kernel (and AUTO falls back to it): refuse here, not at the first call */
+        llzs_set_error("llz_fir_filter_mc_init: %d taps exceed the time-domain kernel's LDS tile", flt_len);
         return LLZ_BAD_HANDLE;
     }
     if (algo == LLZ_FIR_ALGO_AUTO) {
@@ -380,9 +373,7 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
     if (rc == LLZ_OK) rc = llzs_memset(f->d_hist[1], 0, hist_bytes, NULL);
     if (rc == LLZ_OK) rc = llzs_memset(f->d_zero, 0, hist_bytes, NULL);
     if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE) rc = firm_build_ols_tables(f, taps);
-    if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048)
-        rc = (flt_len <= LLZS_OLS2K_MAX_TAPS && llzs_tune(LLZS_TUNE_FIR_PART) != 0) ? firm_build_ols2k_tables(f, taps)
-                                                                                    : firm_build_ols_big_tables(f, taps, LLZS_OLS2_NFFT);
+    if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048) rc = firm_build_ols2k_tables(f, taps);
     if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE_4096) rc = firm_build_ols_big_tables(f, taps, LLZS_OLS4_NFFT);
     if (rc == LLZ_OK) rc = llzs_sync(NULL);
     free(padded);
@@ -479,12 +470,9 @@ static int firm_launch(firm_t *f, const float *d_in, float *d_out, int n, long p
     if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE)
         rc = llzs_fir_ols_f32(d_in, d_out, hist, f->d_hfreq, f->d_twid, f->channels, n, pitch_in, pitch_out,
                               f->flt_len, f->stream);
-    else if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048 && f->d_tw2k)
+    else if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048)
         rc = llzs_fir_ols2k_f32(d_in, d_out, hist, f->d_hfreq, f->d_twid, f->d_tw2k, f->channels, n, pitch_in, pitch_out,
                                 f->flt_len, f->stream);
-    else if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048)
-        rc = llzs_fir_ols2048_f32(d_in, d_out, hist, f->d_hperm2, f->d_cs2, f->channels, n, pitch_in, pitch_out,
-                                  f->flt_len, f->stream);
     else if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_4096)
         rc = llzs_fir_ols4096_f32(d_in, d_out, hist, f->d_hperm2, f->d_cs2, f->channels, n, pitch_in, pitch_out,
                                   f->flt_len, f->stream);

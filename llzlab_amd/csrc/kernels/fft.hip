@@ -1091,125 +1091,12 @@ k_stft_synthesis_reg_f32(const float *__restrict__ re, const float *__restrict__
         for (int q = tid; q < keep; q += 256) ola_new[(size_t)c * keep + q] = carry[q];
 }
 
-// Overlap-save FIR with 2048-point transforms for filters of 258..1025 taps (the 1024-point kernel of fir_ols.hip stops at
-// 257), on the 2 x 32^2 register transform: a half-wave owns a JOB = two consecutive blocks of one channel, packed as the
-// real and imaginary part of one complex transform -- the filter is real, so IFFT(FFT(a + j b) H) = (a * h) + j (b * h) and
-// nothing has to be unpacked.  Block b yields the V = 2048 - (T-1) outputs [b V, (b+1) V) from the 2048 inputs that end
-// there; samples before the frame come from the handle's history.  hperm: the taps' spectrum / 2048 in the transform's
-// output order, [q][lane] = (H[2 kq], H[2 kq + 1]), kq = lane + 32 brev5(q).
-// INTERIOR: jobs first_job .. first_job + jobs_per_channel - 1 of every channel, all of whose samples lie inside the frame
-// (two lane pointers with immediate offsets); otherwise the edge jobs: job 0 (history) and the jobs from first_job on (frame
-// end), each access tested -- a kernel of its own, because the tested accesses cost 120 more VGPRs.
-// (two waves per SIMD: the 44 registers that do not fit are the waiting odd-bin results, spilled once and read once)
-template <bool INTERIOR>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_fir_ols2048_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
-                  const float4 *__restrict__ hperm, const float *__restrict__ cs /* 2048 cos, 2048 sin */, const float2 *__restrict__ tw1,
-                  int n, long in_pitch, long out_pitch, int flt_len, int jobs_per_channel, long total_jobs, int first_job)
-{
-    constexpr int E = 32, H = E * E, N = 2 * H, GROUPS = 256 / E, PITCH = E + 1;
-    __shared__ float bufs[GROUPS][E * PITCH];
-    __shared__ float2 s_tw[1024];                                  // W_1024^(a*b), [a][b]: the half-wave transform of fft32.hpp
-    const int tid = threadIdx.x, grp = tid / E, lg = tid % E;
-    for (int i = tid; i < 1024; i += 256) {
-        const int m = (2 * (i >> 5) * (i & 31)) & 2047;
-        s_tw[i] = make_float2(cs[m], -cs[2048 + m]);
-    }
-    __syncthreads();
-    const long job = (long)blockIdx.x * GROUPS + grp;
-    if (job >= total_jobs) return;                                 // whole groups leave together: no barrier below
-    const int c = (int)(job / jobs_per_channel), e = (int)(job - (long)c * jobs_per_channel);
-    const int jq = INTERIOR ? first_job + e : (e == 0 ? 0 : first_job + e - 1);
-    const int keep = flt_len - 1, V = N - keep;
-    const long o0 = (long)(2 * jq) * V, o1 = o0 + V;               // first outputs of the two blocks
-    const float *row = in + (size_t)c * in_pitch;
-    const float *hrow = hist ? hist + (size_t)c * keep : nullptr;
-    float *orow = out + (size_t)c * out_pitch;
-    float *buf = bufs[grp];
-    auto sample = [&](long idx) {                                  // x[idx], idx in [-keep, n): history in front, zeros behind
-        if (idx >= n) return 0.f;
-        if (idx >= 0) return row[idx];
-        return hrow ? hrow[keep + idx] : 0.f;
-    };
-    // interior jobs (no history, no frame end: all but the first and last of a channel) take their samples through two
-    // lane pointers with immediate offsets; the general path costs a 64-bit address and two tests per access
-    constexpr bool interior = INTERIOR;
-    const float *p0 = row + (o0 - keep) + lg, *p1 = p0 + V;        // (formed, not dereferenced, when not interior)
-    // The even bins (s = a + b) and the odd bins (d = (a - b) W) only meet again at the very end, so each half goes through
-    // transform, product and inverse transform on its own: s waits in 64 registers while d is worked on (with two waves per
-    // SIMD forced, what does not fit in 256 registers is spilled once and read once; reading the window a second time
-    // instead of keeping s measured 10 % slower).
-    auto window = [&](int j, cf &a, cf &b) {                       // positions m = lg + E j and m + H of both blocks
-        const int m = lg + E * j;
-        if (interior) {
-            a = cf{p0[E * j], p1[E * j]};
-            b = cf{p0[E * j + H], p1[E * j + H]};
-        } else {
-            a = cf{sample(o0 - keep + m), sample(o1 - keep + m)};
-            b = cf{sample(o0 - keep + m + H), sample(o1 - keep + m + H)};
-        }
-    };
-    cf si[E], di[E], s[E];
-    {
-        cf d[E];
-#pragma unroll
-        for (int j = 0; j < E; j++) {
-            cf a, b;
-            window(j, a, b);
-            const float2 w = tw1[j * E + lg];
-            d[j] = cmul<false>(csub(a, b), cf{w.x, w.y});
-            s[j] = cadd(a, b);
-            if ((j & 7) == 7) asm volatile("" ::: "memory");        // (loads are not to be hoisted wholesale: registers)
-        }
-        fft32<false>(d); transpose_twiddle<false>(d, buf, s_tw, lg); fft32<false>(d);   // d[q] = Z[2 kq + 1], kq = lg + E brev5(q)
-#pragma unroll
-        for (int q = 0; q < E; q++) {
-            const float2 h = reinterpret_cast<const float2 *>(hperm)[2 * (q * E + lg) + 1];
-            d[q] = cmul<false>(d[q], cf{h.x, h.y});
-            if ((q & 7) == 7) asm volatile("" ::: "memory");
-        }
-#pragma unroll
-        for (int j = 0; j < E; j++) di[j] = d[brevE<E>(j)];        // bin order -> natural order: renaming
-        fft32<true>(di); transpose_twiddle<true>(di, buf, s_tw, lg); fft32<true>(di);
-    }
-    {
-        fft32<false>(s); transpose_twiddle<false>(s, buf, s_tw, lg); fft32<false>(s);   // s[q] = Z[2 kq]
-#pragma unroll
-        for (int q = 0; q < E; q++) {
-            const float2 h = reinterpret_cast<const float2 *>(hperm)[2 * (q * E + lg)];
-            s[q] = cmul<false>(s[q], cf{h.x, h.y});
-            if ((q & 7) == 7) asm volatile("" ::: "memory");
-        }
-#pragma unroll
-        for (int j = 0; j < E; j++) si[j] = s[brevE<E>(j)];
-        fft32<true>(si); transpose_twiddle<true>(si, buf, s_tw, lg); fft32<true>(si);
-    }
-    float *q0 = orow + (o0 - keep) + lg, *q1 = q0 + V;
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int q = 0; q < E; q++) {                                  // m = lg + E brev5(q): y[m], y[m + H] = s +- d conj(W_N^m)
-        if ((q & 3) == 0) asm volatile("" ::: "memory");            // (table loads not hoisted wholesale either)
-        const int mo = E * brevE<E>(q), m = lg + mo;
-        const float2 w = tw1[brevE<E>(q) * E + lg];
-        const cf wd = cmul<true>(di[q], cf{w.x, w.y});
-        const cf y0 = cadd(si[q], wd), y1 = csub(si[q], wd);
-        // the first T-1 outputs of a block are circular wrap-around: dropped (m + H >= 1024 >= T-1 always)
-        if (interior) {
-            if (m >= keep) { q0[mo] = y0.x; q1[mo] = y0.y; }
-            q0[mo + H] = y1.x; q1[mo + H] = y1.y;
-        } else {
-            if (m >= keep) {
-                if (o0 + m - keep < n) orow[o0 + m - keep] = y0.x;
-                if (o1 + m - keep < n) orow[o1 + m - keep] = y0.y;
-            }
-            if (o0 + m + H - keep < n) orow[o0 + m + H - keep] = y1.x;
-            if (o1 + m + H - keep < n) orow[o1 + m + H - keep] = y1.y;
-        }
-    }
-}
-
-// The same with 4096-point transforms (64 x 64, a whole wave per job) for filters of 1026..3073 taps: no radix-2 step, so
-// the packed pair of blocks goes through one transform, the spectrum product and one inverse transform.
+// Overlap-save FIR with 4096-point transforms (64 x 64, a whole wave per job) for filters of 1026..3073 taps (fir_ols.hip covers
+// up to 1025): a JOB = two consecutive blocks of one channel, packed as the real and imaginary part of one complex transform --
+// the filter is real, so IFFT(FFT(a + j b) H) = (a * h) + j (b * h) and nothing has to be unpacked.  Block b yields the
+// V = 4096 - (T-1) outputs [b V, (b+1) V) from the 4096 inputs that end there; samples before the frame come from the
+// handle's history.  INTERIOR: jobs all of whose samples lie inside the frame (lane pointers with immediate offsets);
+// otherwise the edge jobs (history, frame end), each access tested.
 // hperm: [q][lane] = H[lane + 64 brev6(q)] / 4096.
 // (interior instantiation: two waves per SIMD asked for, as for k_fft_square_f32<64>: 1537 taps 29.6 -> 17.4 ms)
 template <bool INTERIOR>
@@ -1845,42 +1732,6 @@ static int stft_reg_tables(int size, const float *cs, void *stream, const float2
     }
     *tw2d = set[0];
     *tw1 = set[1];
-    return LLZ_OK;
-}
-
-// overlap-save FIR, 2048-point transforms: hperm = the taps' spectrum / 2048 permuted as k_fir_ols2048_f32 documents (built
-// by the host), cs = device table of size 2048 (cos then sin) the transform tables are derived from on first use
-extern "C" int llzs_fir_ols2048_f32(const float *in, float *out, const float *hist, const float *hperm, const float *cs,
-                                    int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream)
-{
-    if (!in || !out || !hperm || !cs || channels <= 0 || n <= 0 || flt_len < 2 || flt_len > 1025 || in_pitch < n ||
-        out_pitch < n || !hist) {
-        llzs_set_error("fir_ols2048_f32: bad arguments (flt_len=%d, 2..1025)", flt_len);
-        return LLZ_ERR_ARG;
-    }
-    const float2 *tw2d = nullptr, *tw1 = nullptr;
-    const int trc = stft_reg_tables(2048, cs, stream, &tw2d, &tw1);
-    if (trc != LLZ_OK) return trc;
-    const int V = 2048 - (flt_len - 1);
-    const int blocks_per_channel = (n + V - 1) / V;
-    const int J = (blocks_per_channel + 1) / 2;                    // jobs (pairs of blocks) per channel
-    const int j_full = n / (2 * V);                                // jobs 0 .. j_full-1 end inside the frame
-    // (only job 0 reaches into the history: 2 V >= 2046 >= T-1 for every T <= 1025)
-    const int int_first = 1, int_count = j_full - 1 > 0 ? j_full - 1 : 0;          // interior: 1 .. j_full-1
-    const int edge_first = j_full > 1 ? j_full : 1;                // edge: 0 and edge_first .. J-1
-    const int edge_count = 1 + (J - edge_first > 0 ? J - edge_first : 0);
-    const float4 *hp = reinterpret_cast<const float4 *>(hperm);
-    if (int_count > 0) {
-        const long total = (long)int_count * channels;
-        hipLaunchKernelGGL(k_fir_ols2048_f32<true>, dim3((unsigned)((total + 7) / 8)), dim3(256), 0, as_stream(stream), in,
-                           out, hist, hp, cs, tw1, n, in_pitch, out_pitch, flt_len, int_count, total, int_first);
-    }
-    {
-        const long total = (long)edge_count * channels;
-        hipLaunchKernelGGL(k_fir_ols2048_f32<false>, dim3((unsigned)((total + 7) / 8)), dim3(256), 0, as_stream(stream), in,
-                           out, hist, hp, cs, tw1, n, in_pitch, out_pitch, flt_len, edge_count, total, edge_first);
-    }
-    LLZ_LAUNCH_CHECK("k_fir_ols2048_f32");
     return LLZ_OK;
 }
 

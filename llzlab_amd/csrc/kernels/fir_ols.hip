@@ -340,8 +340,8 @@ k_fir_ols_chain_f32(const float *__restrict__ in, float *__restrict__ out, const
 // ---------------------------------------------------------------------------------------------------------------------
 // 258 .. 1025 taps: the same walk on 2048-point transforms, a WHOLE WAVE per job.
 //
-// A 2048-point transform held by one half-wave needs 64 complex registers per lane and spills (k_fir_ols2048_f32 in fft.hip:
-// 12.4 ms at 513 taps).  Here one radix-2 step splits it over the wave's two half-waves, each of which then runs the
+// A 2048-point transform held by one half-wave needs 64 complex registers per lane and spills (round 1's kernel of that
+// shape: 12.4 ms at 513 taps, 17 ms at 1025).  Here one radix-2 step splits it over the wave's two half-waves, each of which then runs the
 // 1024-point machinery above unchanged:
 //     forward (decimation in frequency):  X[2k]   = FFT_1024( a[n] + a[n+1024] )            -> lower half-wave
 //                                         X[2k+1] = FFT_1024( (a[n] - a[n+1024]) W_2048^n ) -> upper half-wave

@@ -148,6 +148,16 @@ k_fir_td_f64_exact(const double *__restrict__ in, double *__restrict__ out, cons
 
 } // namespace
 
+static size_t td_lds_bytes(int flt_len)
+{
+    const int tpad = (flt_len + 15) & ~15;
+    const int total = TD_TILE + tpad;
+    return (size_t)(total + (total >> 3) * 4 + 16) * sizeof(float);
+}
+
+// 1 when a filter of flt_len taps fits the kernel's LDS tile (the flush of every FIR handle runs through this kernel)
+extern "C" int llzs_fir_td_f32_fits(int flt_len) { return flt_len >= 1 && td_lds_bytes(flt_len) <= 160 * 1024; }
+
 extern "C" int llzs_fir_td_f32(const float *in, float *out, const float *hist, const float *taps_padded,
                                int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream)
 {
@@ -157,8 +167,7 @@ extern "C" int llzs_fir_td_f32(const float *in, float *out, const float *hist, c
         return LLZ_ERR_ARG;
     }
     const int tpad = (flt_len + 15) & ~15;
-    const int total = TD_TILE + tpad;
-    const size_t lds_bytes = (size_t)(total + (total >> 3) * 4 + 16) * sizeof(float);
+    const size_t lds_bytes = td_lds_bytes(flt_len);
     if (lds_bytes > 160 * 1024) {
         llzs_set_error("fir_td_f32: %d taps need %zu B of LDS", flt_len, lds_bytes);
         return LLZ_ERR_RANGE;

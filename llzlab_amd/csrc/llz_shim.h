@@ -44,7 +44,6 @@ enum {
     LLZS_TUNE_IIR_F64,              /* 1: double arithmetic whatever the noise-gain check says */
     LLZS_TUNE_IIR_PIPE,             /* 1: stage pipeline even where the wave form would be taken */
     LLZS_TUNE_IIR_WAVE_MIN_ITEMS,   /* crossover (channel, segment) item count of the wave form */
-    LLZS_TUNE_FIR_PART,             /* 0: 2048-point overlap-save on the half-wave kernel of fft.hip even below 514 taps */
     LLZS_TUNE_SHARD_RCCL,           /* 1: sharded handles broadcast their tables through RCCL even on a single device */
     LLZS_TUNE_COUNT
 };
@@ -88,22 +87,19 @@ int  llzs_tables_broadcast(llzs_table_ref *const *tables, int ntables, int nshar
  * in/out planar with row pitch in_pitch/out_pitch elements. taps: flt_len floats padded to a multiple of 8. */
 int llzs_fir_td_f32(const float *in, float *out, const float *hist, const float *taps_padded,
                     int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream);
+int llzs_fir_td_f32_fits(int flt_len);      /* 1 when the taps fit the time-domain kernel's LDS tile */
 /* overlap-save: hfreq = 1024 complex floats, FFT(taps)/1024 in natural bin order; twid = 32x32 complex
  * W_1024^(a*b).  Requires flt_len <= 257. */
 int llzs_fir_ols_f32(const float *in, float *out, const float *hist, const float *hfreq, const float *twid,
                      int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream);
-/* overlap-save with 2048-point transforms for 258..1025 taps: hperm [32][32] float4 = (H[2k], H[2k+1]) / 2048 with
- * k = lane + 32 brev5(q) at [q][lane]; cs: device table, 2048 cos then 2048 sin of 2 pi i / 2048 */
-int llzs_fir_ols2048_f32(const float *in, float *out, const float *hist, const float *hperm, const float *cs,
-                         int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream);
-/* the same transform size split over the two half-waves of a wave (fir_ols.hip), up to 1025 taps: hfreq2 [2][1024] complex =
+/* overlap-save with 2048-point transforms split over the two half-waves of a wave (fir_ols.hip), 2..1025 taps: hfreq2 [2][1024] complex =
  * even then odd bins of DFT_2048(taps) / 2048, twid [32][32] W_1024^(ab), tw2k [1024] W_2048^n */
 int llzs_fir_ols2k_f32(const float *in, float *out, const float *hist, const float *hfreq2, const float *twid,
                        const float *tw2k, int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream);
 #define LLZS_OLS2K_MAX_TAPS 1025
 #define LLZS_OLS2_NFFT 2048
 #define LLZS_OLS2_MAX_TAPS 1025
-/* the same with 4096-point transforms for up to 3073 taps: hperm [64][64] float2 = H[lane + 64 brev6(q)] / 4096; cs: device
+/* overlap-save with 4096-point transforms (one wave per transform, fft.hip) for up to 3073 taps: hperm [64][64] float2 = H[lane + 64 brev6(q)] / 4096; cs: device
  * table, 4096 cos then 4096 sin */
 int llzs_fir_ols4096_f32(const float *in, float *out, const float *hist, const float *hperm, const float *cs,
                          int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream);

@@ -28,6 +28,16 @@ def _ptr(buf):
     raise LlzError(f"unsupported buffer type {type(buf)}")
 
 
+def _typed(buf, dtype, numel, what):
+    """address of `buf` after checking that it holds exactly `numel` elements of `dtype` ("float32", "int16", ...): the C
+    ABI takes plain pointers, so a wrong dtype or a short buffer would be read / written past its end"""
+    name = str(buf.dtype).replace("torch.", "")
+    size = buf.numel() if hasattr(buf, "numel") else buf.size
+    if name != dtype or size != numel:
+        raise LlzError(f"{what}: expected {numel} x {dtype}, got {size} x {name}")
+    return _ptr(buf)
+
+
 def _stream_ptr(stream):
     if stream is None:
         return None
@@ -135,11 +145,15 @@ class FirFilterMC:
 
     def filter(self, x, out):
         """x, out: [channels, frame_len] float32 (torch device tensors or numpy). Returns out."""
-        check(self._L.llz_fir_filter_mc(self.handle, _ptr(x), _ptr(out), self.frame_len), "llz_fir_filter_mc")
+        count = self.channels * self.frame_len
+        check(self._L.llz_fir_filter_mc(self.handle, _typed(x, "float32", count, "FirFilterMC.filter x"),
+                                        _typed(out, "float32", count, "FirFilterMC.filter out"), self.frame_len),
+              "llz_fir_filter_mc")
         return out
 
     def flush(self, out):
-        check(self._L.llz_fir_filter_mc_flush(self.handle, _ptr(out)), "llz_fir_filter_mc_flush")
+        check(self._L.llz_fir_filter_mc_flush(self.handle, _typed(out, "float32", self.channels * (self.flt_len - 1),
+                                                                  "FirFilterMC.flush out")), "llz_fir_filter_mc_flush")
         return out
 
     def close(self):
@@ -202,7 +216,9 @@ class IirCascadeMC:
 
     def filter(self, x, out):
         n = x.shape[-1]
-        check(self._L.llz_iir_cascade_mc(self.handle, _ptr(x), _ptr(out), n), "llz_iir_cascade_mc")
+        check(self._L.llz_iir_cascade_mc(self.handle, _typed(x, "float32", self.channels * n, "IirCascadeMC.filter x"),
+                                         _typed(out, "float32", self.channels * n, "IirCascadeMC.filter out"), n),
+              "llz_iir_cascade_mc")
         return out
 
     def close(self):
@@ -286,7 +302,11 @@ class ResampleMC:
 
     def process(self, x, out):
         n_in = x.shape[-1]
-        return check(self._L.llz_resample_mc(self.handle, _ptr(x), n_in, _ptr(out)), "llz_resample_mc")
+        dt = "float32" if self.fmt == PCM_F32 else "int16"
+        n_out = self.out_len(n_in)
+        return check(self._L.llz_resample_mc(self.handle, _typed(x, dt, self.channels * n_in, "ResampleMC.process x"), n_in,
+                                             _typed(out, dt, self.channels * n_out, "ResampleMC.process out")),
+                     "llz_resample_mc")
 
     def close(self):
         if getattr(self, "handle", 0):

@@ -1350,3 +1350,89 @@ void orc_synth_i16(short *dst, int channels, long n, unsigned seed, int chan0)
             dst[(size_t)c * n + i] = (short)((int32_t)(u >> 17) - 16384);
         }
 }
+
+
+/* ---- PCM ingest / egress and the WAV header ------------------------------------------------- */
+
+/* planar float = interleaved int16 * scale: the data order of a WAV data chunk is sample-major, channels inside a sample
+ * (what example/llz_resample/main.c:96-114 reads for one channel) */
+void orc_pcm_deinterleave_i16_f32(const short *in, float *out, int channels, long n, float scale)
+{
+    for (long i = 0; i < n; i++)
+        for (int c = 0; c < channels; c++) out[(size_t)c * n + i] = (float)in[(size_t)i * channels + c] * scale;
+}
+
+/* the reference's float -> int16 rule: clamp to [-32768, 32767], then the C conversion toward zero (llz_resample.c:596-601) */
+void orc_pcm_interleave_f32_i16(const float *in, short *out, int channels, long n, float scale)
+{
+    for (long i = 0; i < n; i++)
+        for (int c = 0; c < channels; c++) {
+            float y = in[(size_t)c * n + i] * scale;
+            if (y > 32767) y = 32767;
+            if (y < -32768) y = -32768;
+            out[(size_t)i * channels + c] = (short)y;
+        }
+}
+
+static unsigned long orc_le(const unsigned char *p, int bytes)
+{
+    unsigned long v = 0;
+    for (int i = bytes - 1; i >= 0; i--) v = (v << 8) | p[i];
+    return v;
+}
+
+/* The chunk walk of llz_wavfmt_readheader (libllzaudio/llz_wavfmt.c:82-159) on a memory image: "RIFF" size "WAVE", chunks
+ * skipped up to "fmt ", PCM format, channels, rate, bits -> bytes per sample (rounded up), block_align recomputed as
+ * bytes_per_sample * channels (:136), the rest of the fmt chunk skipped, chunks skipped up to "data", frames = data bytes /
+ * block_align (:155).  Returns 0, or -1 where the reference prints and exits / would read past the file.
+ * out: format, channels, samplerate, bytes_per_sample, block_align, frames, data_offset */
+int orc_wav_parse(const unsigned char *b, long len, long *out)
+{
+    long pos = 0;
+    if (len < 12 || memcmp(b, "RIFF", 4) != 0 || memcmp(b + 8, "WAVE", 4) != 0) return -1;
+    pos = 12;
+    for (;;) {                                                   /* llz_wavfmt.c:108-114 (the id is re-read after a skip) */
+        if (pos + 8 > len) return -1;
+        if (memcmp(b + pos, "fmt ", 4) == 0) break;
+        pos += 8 + (long)orc_le(b + pos + 4, 4);
+    }
+    long x_size = (long)orc_le(b + pos + 4, 4);
+    pos += 8;
+    if (x_size < 16 || pos + x_size > len) return -1;
+    const unsigned long format = orc_le(b + pos, 2), channels = orc_le(b + pos + 2, 2);
+    const unsigned long rate = orc_le(b + pos + 4, 4), bits = orc_le(b + pos + 14, 2);
+    if (format != 1 || channels == 0) return -1;                 /* WAVE_FORMAT_PCM only (:118-121) */
+    const unsigned long bps = (bits + 7) / 8;
+    if (bps == 0) return -1;
+    pos += x_size;
+    for (;;) {                                                   /* :146-152 */
+        if (pos + 8 > len) return -1;
+        if (memcmp(b + pos, "data", 4) == 0) break;
+        pos += 8 + (long)orc_le(b + pos + 4, 4);
+    }
+    const unsigned long data_size = orc_le(b + pos + 4, 4);
+    out[0] = (long)format; out[1] = (long)channels; out[2] = (long)rate; out[3] = (long)bps;
+    out[4] = (long)(bps * channels); out[5] = (long)(data_size / (bps * channels)); out[6] = pos + 8;
+    return 0;
+}
+
+/* the 44-byte header of llz_wavfmt_writeheader (:185-213) */
+void orc_wav_header(unsigned char *h, int channels, long samplerate, int bytes_per_sample, long frames)
+{
+    const unsigned long block = (unsigned long)channels * bytes_per_sample, data = (unsigned long)frames * block;
+    memcpy(h, "RIFF", 4);
+    unsigned long v = data + 36;
+    for (int i = 0; i < 4; i++) h[4 + i] = (unsigned char)(v >> (8 * i));
+    memcpy(h + 8, "WAVEfmt ", 8);
+    v = 16;
+    for (int i = 0; i < 4; i++) h[16 + i] = (unsigned char)(v >> (8 * i));
+    h[20] = 1; h[21] = 0;
+    h[22] = (unsigned char)channels; h[23] = (unsigned char)(channels >> 8);
+    for (int i = 0; i < 4; i++) h[24 + i] = (unsigned char)((unsigned long)samplerate >> (8 * i));
+    v = (unsigned long)channels * (unsigned long)samplerate * bytes_per_sample;
+    for (int i = 0; i < 4; i++) h[28 + i] = (unsigned char)(v >> (8 * i));
+    h[32] = (unsigned char)block; h[33] = (unsigned char)(block >> 8);
+    h[34] = (unsigned char)(bytes_per_sample * 8); h[35] = 0;
+    memcpy(h + 36, "data", 4);
+    for (int i = 0; i < 4; i++) h[40 + i] = (unsigned char)(data >> (8 * i));
+}

@@ -146,6 +146,14 @@ long   orc_rs_batch_i16(const short *in, short *out, int channels, long n_in, in
 void   orc_synth_f32(float *dst, int channels, long n, unsigned seed, int chan0);
 void   orc_synth_i16(short *dst, int channels, long n, unsigned seed, int chan0);
 
+/* PCM ingest / egress (sample-interleaved int16 <-> planar float32) and the WAV header walk of
+ * libllzaudio/llz_wavfmt.c:82-213 on a memory image.  orc_wav_parse out[7]: format, channels, samplerate, bytes per
+ * sample, block_align, frames, data offset */
+void   orc_pcm_deinterleave_i16_f32(const short *in, float *out, int channels, long n, float scale);
+void   orc_pcm_interleave_f32_i16(const float *in, short *out, int channels, long n, float scale);
+int    orc_wav_parse(const unsigned char *bytes, long len, long *out);
+void   orc_wav_header(unsigned char *h44, int channels, long samplerate, int bytes_per_sample, long frames);
+
 #ifdef __cplusplus
 }
 #endif

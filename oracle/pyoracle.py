@@ -154,6 +154,10 @@ class Oracle:
         L.orc_rs_batch_i16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_double, C.c_int]
         L.orc_synth_f32.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_uint, C.c_int]
         L.orc_synth_i16.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_uint, C.c_int]
+        L.orc_pcm_deinterleave_i16_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_float]
+        L.orc_pcm_interleave_f32_i16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_float]
+        L.orc_wav_parse.argtypes = [C.c_char_p, C.c_long, C.POINTER(C.c_long)]
+        L.orc_wav_header.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_long]
 
     # ---- design -------------------------------------------------------------------------------
     def window(self, win, n, beta=None):
@@ -453,15 +457,81 @@ class Oracle:
         self.lib.orc_synth_f32(out.ctypes.data, channels, n, seed, chan0)
         return out
 
+    def pcm_deinterleave(self, il, scale=1.0 / 32768.0):
+        """il: [n][channels] int16 -> planar [channels][n] float32"""
+        il = np.ascontiguousarray(il, dtype=np.int16)
+        n, ch = il.shape
+        out = np.zeros((ch, n), dtype=np.float32)
+        self.lib.orc_pcm_deinterleave_i16_f32(il.ctypes.data, out.ctypes.data, ch, n, scale)
+        return out
+
+    def pcm_interleave(self, pl, scale=32768.0):
+        pl = np.ascontiguousarray(pl, dtype=np.float32)
+        ch, n = pl.shape
+        out = np.zeros((n, ch), dtype=np.int16)
+        self.lib.orc_pcm_interleave_f32_i16(pl.ctypes.data, out.ctypes.data, ch, n, scale)
+        return out
+
+    def wav_parse(self, data):
+        out = (C.c_long * 7)()
+        if self.lib.orc_wav_parse(bytes(data), len(data), out) != 0:
+            return None
+        return dict(zip(("format", "channels", "samplerate", "bytes_per_sample", "block_align", "frames", "data_offset"),
+                        [int(v) for v in out]))
+
+    def wav_header(self, channels, samplerate, bytes_per_sample, frames):
+        h = np.zeros(44, dtype=np.uint8)
+        self.lib.orc_wav_header(h.ctypes.data, channels, samplerate, bytes_per_sample, frames)
+        return h.tobytes()
+
     def synth_i16(self, channels, n, seed, chan0=0):
         out = np.zeros((channels, n), dtype=np.int16)
         self.lib.orc_synth_i16(out.ctypes.data, channels, n, seed, chan0)
         return out
 
 
+class _RefWavFmt(C.Structure):               # llz_wavfmt_t (libllzaudio/llz_wavfmt.h)
+    _fields_ = [("format", C.c_ushort), ("channels", C.c_ushort), ("samplerate", C.c_ulong),
+                ("bytes_per_sample", C.c_ushort), ("block_align", C.c_ushort), ("data_size", C.c_ulong)]
+
+
 class Ref:
     """The reference's own compiled C files (llz_* API, handles are unsigned long)."""
     name = "ref"
+
+    def wav_readheader(self, path):
+        """llz_wavfmt_readheader on a file (the reference's own reader, FILE* from libc); returns the struct's fields and the
+        file offset of the first data byte"""
+        libc = C.CDLL(None)
+        libc.fopen.restype = C.c_void_p
+        libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+        libc.fclose.argtypes = [C.c_void_p]
+        libc.ftell.restype = C.c_long
+        libc.ftell.argtypes = [C.c_void_p]
+        self.lib.llz_wavfmt_readheader.restype = _RefWavFmt
+        self.lib.llz_wavfmt_readheader.argtypes = [C.c_void_p]
+        fp = libc.fopen(path.encode(), b"rb")
+        assert fp
+        f = self.lib.llz_wavfmt_readheader(fp)
+        off = libc.ftell(fp)
+        libc.fclose(fp)
+        return {"format": f.format, "channels": f.channels, "samplerate": f.samplerate,
+                "bytes_per_sample": f.bytes_per_sample, "block_align": f.block_align, "frames": f.data_size,
+                "data_offset": off}
+
+    def wav_writeheader(self, path, channels, samplerate, bytes_per_sample, frames):
+        libc = C.CDLL(None)
+        libc.fopen.restype = C.c_void_p
+        libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+        libc.fclose.argtypes = [C.c_void_p]
+        self.lib.llz_wavfmt_writeheader.argtypes = [_RefWavFmt, C.c_void_p]
+        self.lib.llz_wavfmt_writeheader.restype = None
+        fmt = _RefWavFmt(1, channels, samplerate, bytes_per_sample, channels * bytes_per_sample, frames)
+        fp = libc.fopen(path.encode(), b"wb")
+        assert fp
+        self.lib.llz_wavfmt_writeheader(fmt, fp)
+        libc.fclose(fp)
+        return open(path, "rb").read()
 
     def __init__(self):
         if not have_ref():

@@ -690,15 +690,15 @@ def test_autocorr_fast_mc_vs_oracle(dev, oracle, frames, n, p):
 # ------------------------------------------------------------------------------------------------ PCM ingest (8f rank 2)
 @pytest.mark.parametrize("channels,n", [(1, 5000), (1, 4099), (2, 48000), (2, 4099), (3, 1001), (6, 1000), (64, 4097), (64, 4096),
                                         (100, 333), (4096, 70), (4096, 128)])
-def test_pcm_deinterleave_and_back_exact(dev, channels, n):
-    """numpy restatement: planar = ileaved.T / 32768 (exact in float32); back: clamp, truncate toward zero
-    (reference llz_resample.c:596-601)"""
+def test_pcm_deinterleave_and_back_exact(dev, oracle, channels, n):
+    """against the oracle's PCM functions (orc_pcm_*: planar = interleaved / 32768, exact in float32; back: clamp, then
+    the C conversion toward zero, reference llz_resample.c:596-601)"""
     rng = np.random.default_rng(channels * 7 + n)
     il = rng.integers(-32768, 32768, (n, channels)).astype(np.int16)
     ild = torch.from_numpy(il).to(dev)
     pl = torch.empty(channels, n, dtype=torch.float32, device=dev)
     filters.pcm_deinterleave(ild, pl)
-    assert np.array_equal(pl.cpu().numpy(), (il.T.astype(np.float32) / np.float32(32768.0)))
+    assert np.array_equal(pl.cpu().numpy(), oracle.pcm_deinterleave(il))
     back = torch.empty(n, channels, dtype=torch.int16, device=dev)
     filters.pcm_interleave(pl, back)
     assert np.array_equal(back.cpu().numpy(), il)                      # round trip is the identity
@@ -706,8 +706,7 @@ def test_pcm_deinterleave_and_back_exact(dev, channels, n):
     x = rng.uniform(-1.5, 1.5, (channels, n)).astype(np.float32)
     out = np.zeros((n, channels), dtype=np.int16)
     filters.pcm_interleave(x, out)                                      # host buffers
-    ref = np.trunc(np.clip(x.astype(np.float32) * np.float32(32768.0), -32768, 32767)).astype(np.int16).T
-    assert np.array_equal(out, ref)
+    assert np.array_equal(out, oracle.pcm_interleave(x))
 
 
 # ------------------------------------------------------------------------------------------------ windowed-FFT frames (8f rank 3)
@@ -880,24 +879,14 @@ def test_mdct_batch_vs_oracle(dev, oracle, n, count):
 
 
 # ------------------------------------------------------------------------------------------------ overlap-save, 2048 points
-@pytest.mark.parametrize("form", ["wave", "half-wave"])
 @pytest.mark.parametrize("taps_n,channels,n", [(258, 3, 5000), (513, 5, 1536 * 4 + 1), (1025, 2, 1024 * 7), (300, 9, 700),
                                                (1025, 70, 1024 * 40 + 3), (2, 3, 4096), (513, 6, 3072 * 20 + 77),
                                                (400, 300, 3072 * 3), (512, 1, 3072 * 17)])
-def test_fir_ols2048_vs_oracle_streaming(dev, oracle, taps_n, channels, n, form):
-    """filters of 258..1025 taps on 2048-point overlap-save: up to 513 taps the whole-wave walk kernel (k_fir_ols2k_walk_f32,
-    one radix-2 step across the half-waves), above it -- or when llz_hip_tune("fir_ols2k", 0) asks -- the half-wave kernel
-    of fft.hip: two frames (history carried by the handle) and the flush tail, ragged lengths, segments of several jobs,
-    blocks that end past the frame, and the automatic choice"""
-    if form == "half-wave":
-        capi.tune("fir_ols2k", 0)
-    try:
-        _fir_ols2048_case(dev, oracle, taps_n, channels, n)
-    finally:
-        capi.tune("fir_ols2k", -1)
-
-
-def _fir_ols2048_case(dev, oracle, taps_n, channels, n):
+def test_fir_ols2048_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
+    """filters of 258..1025 taps on 2048-point overlap-save (k_fir_ols2k_walk_f32: one radix-2 step across the half-waves of a
+    wave around the 1024-point machinery; 512 samples of overlap up to 513 taps, 1024 above): two frames (history carried by
+    the handle) and the flush tail, ragged lengths, segments of several jobs, blocks that end past the frame, and the
+    automatic choice"""
     taps = oracle.fir_design(po.LPF, taps_n, 0.2, 0.0, po.KAISER)
     x = oracle.synth_f32(channels, 2 * n, seed=taps_n)
     ref = oracle.fir_batch_f32(x, taps.astype(np.float32).astype(np.float64))
