@@ -429,6 +429,20 @@ def extra_paths(torch, filters, capi, dev, stream):
         out[name] = {"Msamples_s": ch * n / ms / 1e3, "GBs": 8 * ch * n / ms / 1e6,
                      "hbm_frac": 8 * ch * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms}
         f.close()
+    del x, y
+    # the reference CLI's default ratio 147:160 (48 kHz -> 44.1 kHz) and its inverse, 256 channels, float32 (general L/M path)
+    for (L_, M_) in ((147, 160), (160, 147)):
+        ch, n = 256, M_ * 8192
+        x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+        y = torch.empty(ch, n * L_ // M_, dtype=torch.float32, device=dev)
+        filters.synth_f32(x, SEED, stream=stream)
+        r = filters.ResampleMC(ch, L_, M_, 1.0, filters.BLACKMAN, filters.PCM_F32, stream=stream)
+        ms = timeit(lambda: r.process(x, y), 20)
+        gb = (4 + 4 * L_ / M_) * ch * n / ms / 1e6
+        out[f"resample_{L_}to{M_}_f32_256ch"] = {"Msamples_in_s": ch * n / ms / 1e3, "GBs": gb, "hbm_frac": gb / HBM_PEAK_GBS,
+                                                "ms": ms}
+        r.close()
+        del x, y
     return out
 
 
