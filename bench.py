@@ -80,10 +80,8 @@ def cpu_baseline(taps64, oracle_mod):
 
 
 def ols_kernel_name(channels, n):
-    """which overlap-save kernel the launcher takes (llzs_fir_ols_f32 in csrc/kernels/fir_ols.hip): the chain form when a
-    half-wave walks several 16-job segments, the walk form on batches that fit one round"""
-    jobs = (n + 1535) // 1536
-    return "k_fir_ols_chain_f32" if ((jobs + 15) // 16) * channels >= 4 * 4096 else "k_fir_ols_walk_f32"
+    """the 1024-point overlap-save kernel (llzs_fir_ols_f32 in csrc/kernels/fir_ols.hip)"""
+    return "k_fir_ols_chain_f32"
 
 
 def kernel_source_sha():

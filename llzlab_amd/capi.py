@@ -272,7 +272,7 @@ def tune(name, value):
 
 
 class tuned:
-    """with capi.tuned(ols_chain=1): ...  -- overrides set on entry and cleared on exit."""
+    """with capi.tuned(iir_segs=4): ...  -- overrides set on entry and cleared on exit."""
 
     def __init__(self, **kw):
         self.kw = kw

@@ -209,7 +209,7 @@ static int firm_build_ols_tables(firm_t *f, const float *taps)
     return rc;
 }
 
-/* 258 .. 1025 taps (k_fir_ols2k_walk_f32): DFT_2048(taps) / 2048 as [even bins | odd bins], the 32 x 32 twiddles of the
+/* 258 .. 1025 taps (k_fir_ols2k_chain_f32): DFT_2048(taps) / 2048 as [even bins | odd bins], the 32 x 32 twiddles of the
  * 1024-point halves, and W_2048^n for the radix-2 step.  Direct DFT in double, setup time only. */
 static int firm_build_ols2k_tables(firm_t *f, const float *taps)
 {

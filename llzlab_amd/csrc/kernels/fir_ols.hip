@@ -18,10 +18,8 @@
 //     free (register renaming), so FFT -> multiply by H -> IFFT needs no permutation pass at all.
 //   * a half-wave walks a SEGMENT of up to 16 consecutive jobs of one channel and carries the 256-sample overlap in
 //     registers from job to job, so every input sample is requested from memory exactly once; the next job's samples
-//     are requested (into registers) before the current job is transformed.  Two kernels share that job step:
-//       k_fir_ols_walk_f32   one segment after the other (batches that fit one round of the grid)
-//       k_fir_ols_chain_f32  the prefetch is carried ACROSS segments: the last job of a segment requests the first job
-//                            and the halo of the half-wave's next segment (large batches: the headline)
+//     are requested (into registers) before the current job is transformed, across segment boundaries as well
+//     (k_fir_ols_chain_f32: the last job of a segment requests the first job and the halo of the half-wave's next segment).
 //   * HBM access shape: one dword per lane, a half-wave instruction moves 128 contiguous bytes of its job.  Wider shapes
 //     were built and measured and do not pay (profiles/r02/): a copy kernel in exactly this walk structure runs at the same
 //     rate with 4, 8 or 16 bytes per lane (6.04 / 6.02 / 6.02 ms for 32 GiB), and an 8-byte form of this kernel (512
@@ -217,59 +215,12 @@ __device__ __forceinline__ ols_smem ols_tables(char *smem, const float2 *__restr
     return m;
 }
 
-// Walk form: a half-wave runs one segment after the other (grid stride); inside a segment the next job is requested one job
-// ahead.  The request issued during a segment's last job runs past the segment's end and is discarded on purpose (skipping
-// it with a wave-uniform branch measured 8 % slower); the chain form below turns it into the next segment's first job.
-__global__ void __launch_bounds__(OLS_THREADS, 2)
-k_fir_ols_walk_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
-                   const float2 *__restrict__ hfreq, const float2 *__restrict__ twid, ols_geom G)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const ols_smem S = ols_tables(smem, hfreq, twid);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int l5 = lane & 31;
-    const ols_lane g = ols_lane_of(lane);
-    const long halves_total = (long)gridDim.x * OLS_WAVES * 2;
-    const long first = ((long)blockIdx.x * OLS_WAVES + wave) * 2;          // this wave's first segment pair
-
-    for (long sp = first; sp < G.total_segs; sp += halves_total) {
-        const ols_seg sg[2] = {ols_locate(sp, G), ols_locate(sp + 1, G)};
-        const float *const row[2] = {in + (size_t)sg[0].c * G.in_pitch, in + (size_t)sg[1].c * G.in_pitch};
-        float *const orow[2] = {out + (size_t)sg[0].c * G.out_pitch, out + (size_t)sg[1].c * G.out_pitch};
-        const ols_seg own = g.half ? sg[1] : sg[0];
-        const float *orow_in = g.half ? row[1] : row[0];
-
-        float halo[8];
-        ols_load_halo(halo, orow_in, hist ? hist + (size_t)own.c * G.keep : nullptr, own.j0 * OLS_JOB, g.col, G.keep,
-                      own.live);
-        ols_raw raw;
-        {
-            const int s0[2] = {sg[0].j0 * OLS_JOB, sg[1].j0 * OLS_JOB};
-            const bool lv[2] = {sg[0].count > 0, sg[1].count > 0};
-            ols_load(raw, row, s0, lv, g, G.n);
-        }
-        const int jmax = max(sg[0].count, sg[1].count);
-#pragma unroll 1
-        for (int jj = 0; jj < jmax; jj++) {
-            const int s[2] = {(sg[0].j0 + jj) * OLS_JOB, (sg[1].j0 + jj) * OLS_JOB};
-            const bool live[2] = {jj < sg[0].count, jj < sg[1].count};
-            cf v[32], u[32];
-            ols_assemble(v, halo, raw);
-            {
-                const int sn[2] = {s[0] + OLS_JOB, s[1] + OLS_JOB};
-                const bool ln[2] = {jj + 1 < sg[0].count, jj + 1 < sg[1].count};
-                ols_load(raw, row, sn, ln, g, G.n);
-            }
-            ols_filter(v, u, S.buf, S.tw, S.h, l5, g.col);
-            ols_store(u, orow, s, live, g, G.n);
-        }
-    }
-}
-
-// Chain form: the walk form with the prefetch carried ACROSS segments.  The last job of a segment requests the first job and
-// the halo of the half-wave's NEXT segment, so every load is used and no segment start waits on memory.  Both halves of
-// a wave step through their segments together (a segment that is short at the end of a channel idles its tail).
+// A half-wave runs one segment after the other (grid stride over segment pairs), with the prefetch carried ACROSS segments: the
+// last job of a segment requests the first job and the halo of the half-wave's NEXT segment, so every load is used and no
+// segment start waits on memory (a first form requested past the segment's end and discarded the data: 1/16 of the input
+// fetched twice, 3 % slower on the headline; it was also slower on batches of a single round: 0.21 against 0.13 ms on 64
+// channels x 63 taps).  Both halves of a wave step through their segments together (a segment that is short at the end of a
+// channel idles its tail).
 __global__ void __launch_bounds__(OLS_THREADS, 2)
 k_fir_ols_chain_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
                     const float2 *__restrict__ hfreq, const float2 *__restrict__ twid, ols_geom G)
@@ -365,7 +316,7 @@ __device__ __forceinline__ void swap32(float &x, float &y)          // x's upper
 
 template <int O>
 __global__ void __launch_bounds__(OLS_THREADS, 2)
-k_fir_ols2k_walk_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
+k_fir_ols2k_chain_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
                      const float2 *__restrict__ hfreq2 /* [2][1024]: even bins, odd bins, / 2048 */,
                      const float2 *__restrict__ twid /* [32][32] W_1024^(ab) */, const float2 *__restrict__ tw2k /* [1024] W_2048^n */,
                      ols_geom G)
@@ -391,47 +342,67 @@ k_fir_ols2k_walk_f32(const float *__restrict__ in, float *__restrict__ out, cons
     const long waves_total = (long)gridDim.x * OLS_WAVES;
     const int rowoff = 32 * half + l5;                              // this lane inside a pair of rows
 
-    for (long seg = (long)blockIdx.x * OLS_WAVES + wave; seg < G.total_segs; seg += waves_total) {
-        const int c = (int)(seg / G.segs_per_channel);
-        const int j0 = (int)(seg - (long)c * G.segs_per_channel) * G.seg_len;
-        const int count = min(G.seg_len, G.jobs_per_channel - j0);
-        const float *row = in + (size_t)c * G.in_pitch;
-        float *orow = out + (size_t)c * G.out_pitch;
-        const float *hrow = hist ? hist + (size_t)c * G.keep : nullptr;
-        const int n = G.n;
-
-        // rows 2i + h (i < HP) in front of the segment: from the row, the history or zeros
-        float halo[HP];
+    // segment -> (channel row, first job, job count); a wave past the last segment gets an empty one
+    struct segd { const float *row; float *orow; const float *hrow; int j0, count; };
+    auto locate = [&](long seg) {
+        segd d;
+        const bool live = seg < G.total_segs;
+        const int c = live ? (int)(seg / G.segs_per_channel) : 0;
+        d.j0 = live ? (int)(seg - (long)c * G.segs_per_channel) * G.seg_len : 0;
+        d.count = live ? min(G.seg_len, G.jobs_per_channel - d.j0) : 0;
+        d.row = in + (size_t)c * G.in_pitch;
+        d.orow = out + (size_t)c * G.out_pitch;
+        d.hrow = hist ? hist + (size_t)c * G.keep : nullptr;
+        return d;
+    };
+    const int n = G.n;
+    // rows 2i + h (i < HP) in front of a segment: from the row, the history or zeros
+    auto load_halo = [&](float (&halo)[HP], const segd &d) {
 #pragma unroll
         for (int i = 0; i < HP; i++) {
-            const int idx = j0 * O2K_JOB - O2K_OVERLAP + 64 * i + rowoff;
+            const int idx = d.j0 * O2K_JOB - O2K_OVERLAP + 64 * i + rowoff;
             float v = 0.f;
-            if (idx >= 0) v = row[idx];
-            else if (hrow && idx >= -G.keep) v = hrow[G.keep + idx];
+            if (d.count > 0) {
+                if (idx >= 0) v = d.row[idx];
+                else if (d.hrow && idx >= -G.keep) v = d.hrow[G.keep + idx];
+            }
             halo[i] = v;
         }
-        ols_raw raw;
-        auto load = [&](int s) {                                   // the new samples of the job at s: 2 NEW per lane
-            if (s + O2K_JOB <= n) {
+    };
+    ols_raw raw;
+    auto load = [&](const float *row, int s, bool live) {          // the new samples of the job at s: 2 NEW per lane
+        if (live && s + O2K_JOB <= n) {
 #pragma unroll
-                for (int i = 0; i < NEW; i++) {
-                    raw.a[i] = __builtin_nontemporal_load(&row[s + 64 * i + rowoff]);
-                    raw.b[i] = __builtin_nontemporal_load(&row[s + O2K_VALID + 64 * i + rowoff]);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < NEW; i++) {
-                    const int ia = s + 64 * i + rowoff, ib = ia + O2K_VALID;
-                    const float xa = row[min(ia, n - 1)], xb = row[min(ib, n - 1)];
-                    raw.a[i] = ia < n ? xa : 0.f;
-                    raw.b[i] = ib < n ? xb : 0.f;
-                }
+            for (int i = 0; i < NEW; i++) {
+                raw.a[i] = __builtin_nontemporal_load(&row[s + 64 * i + rowoff]);
+                raw.b[i] = __builtin_nontemporal_load(&row[s + O2K_VALID + 64 * i + rowoff]);
             }
-        };
-        load(j0 * O2K_JOB);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NEW; i++) {
+                const int ia = s + 64 * i + rowoff, ib = ia + O2K_VALID;
+                const float xa = row[min(ia, n - 1)], xb = row[min(ib, n - 1)];
+                raw.a[i] = (live && ia < n) ? xa : 0.f;
+                raw.b[i] = (live && ib < n) ? xb : 0.f;
+            }
+        }
+    };
+
+    long seg = (long)blockIdx.x * OLS_WAVES + wave;
+    segd cur = locate(seg);
+    float halo[HP];
+    load_halo(halo, cur);
+    load(cur.row, cur.j0 * O2K_JOB, cur.count > 0);
+    for (; seg < G.total_segs; seg += waves_total) {
+        const segd nxt = locate(seg + waves_total);
+        float halo_n[HP];
+#pragma unroll
+        for (int i = 0; i < HP; i++) halo_n[i] = 0.f;
 #pragma unroll 1
-        for (int jj = 0; jj < count; jj++) {
-            const int s = (j0 + jj) * O2K_JOB;
+        for (int jj = 0; jj < cur.count; jj++) {
+            const int s = (cur.j0 + jj) * O2K_JOB;
+            const float *row = cur.row;
+            float *orow = cur.orow;
             cf v[32], u[32];
             // v[p] = row 2p + h of blocks A (re) and B (im): block A's first HP positions are the carried overlap, block B's
             // are block A's last HP; the new overlap is block B's last HP
@@ -446,7 +417,10 @@ k_fir_ols2k_walk_f32(const float *__restrict__ in, float *__restrict__ out, cons
                 v[HP + i].x = raw.a[i];
                 v[HP + i].y = raw.b[i];
             }
-            load(s + O2K_JOB);                                      // (past the segment's last job: issued and discarded)
+            // the next job of this segment, or -- after its last job -- the first job and the halo of the wave's next segment
+            const bool in_seg = jj + 1 < cur.count;                  // wave-uniform
+            load(in_seg ? row : nxt.row, in_seg ? s + O2K_JOB : nxt.j0 * O2K_JOB, in_seg || nxt.count > 0);
+            if (!in_seg) load_halo(halo_n, nxt);
             // ---- radix-2 step down: rows p and p + 16 are 1024 samples apart.  Every lane twiddles the differences of its
             // own 16 rows BEFORE they move to the upper half-wave (half the multiplies the upper lanes alone would need)
             cf w[32];
@@ -490,6 +464,9 @@ k_fir_ols2k_walk_f32(const float *__restrict__ in, float *__restrict__ out, cons
                 }
             }
         }
+        cur = nxt;
+#pragma unroll
+        for (int i = 0; i < HP; i++) halo[i] = halo_n[i];
     }
 }
 
@@ -537,21 +514,14 @@ extern "C" int llzs_fir_ols_f32(const float *in, float *out, const float *hist, 
     G.total_segs = (long)G.segs_per_channel * channels;
     long blocks = (G.total_segs + 2 * OLS_WAVES - 1) / (2 * OLS_WAVES);
     if (blocks > max_blocks) blocks = max_blocks;
-    // chain form when a half-wave walks several segments; on a batch that fits one round the walk form is faster (64 ch x
-    // 63 taps: 0.14 vs 0.16 ms)
-    const int tuned_chain = llzs_tune(LLZS_TUNE_OLS_CHAIN);
-    const bool chain = tuned_chain >= 0 ? tuned_chain == 1 : large;
     const float2 *hf = reinterpret_cast<const float2 *>(hfreq), *tw = reinterpret_cast<const float2 *>(twid);
     const dim3 grid((unsigned)blocks), block(OLS_THREADS);
-    if (chain)
-        hipLaunchKernelGGL(k_fir_ols_chain_f32, grid, block, lds_bytes, as_stream(stream), in, out, hist, hf, tw, G);
-    else
-        hipLaunchKernelGGL(k_fir_ols_walk_f32, grid, block, lds_bytes, as_stream(stream), in, out, hist, hf, tw, G);
+    hipLaunchKernelGGL(k_fir_ols_chain_f32, grid, block, lds_bytes, as_stream(stream), in, out, hist, hf, tw, G);
     LLZ_LAUNCH_CHECK("k_fir_ols_f32");
     return LLZ_OK;
 }
 
-// 258 .. 1025 taps on 2048-point transforms split over the two half-waves (k_fir_ols2k_walk_f32): hfreq2 = [2][1024] complex,
+// 258 .. 1025 taps on 2048-point transforms split over the two half-waves (k_fir_ols2k_chain_f32): hfreq2 = [2][1024] complex,
 // even then odd bins of DFT_2048(taps) / 2048 in natural order; twid as above; tw2k = [1024] complex W_2048^n
 extern "C" int llzs_fir_ols2k_f32(const float *in, float *out, const float *hist, const float *hfreq2, const float *twid,
                                   const float *tw2k, int channels, int n, long in_pitch, long out_pitch, int flt_len,
@@ -590,16 +560,16 @@ extern "C" int llzs_fir_ols2k_f32(const float *in, float *out, const float *hist
     const float2 *hf = reinterpret_cast<const float2 *>(hfreq2), *tw = reinterpret_cast<const float2 *>(twid),
                  *w2 = reinterpret_cast<const float2 *>(tw2k);
     if (overlap == 512) {
-        LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_ols2k_walk_f32<512>),
+        LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_ols2k_chain_f32<512>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(k_fir_ols2k_walk_f32<512>, dim3((unsigned)blocks), dim3(OLS_THREADS), lds_bytes, as_stream(stream),
+        hipLaunchKernelGGL(k_fir_ols2k_chain_f32<512>, dim3((unsigned)blocks), dim3(OLS_THREADS), lds_bytes, as_stream(stream),
                            in, out, hist, hf, tw, w2, G);
     } else {
-        LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_ols2k_walk_f32<1024>),
+        LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_ols2k_chain_f32<1024>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(k_fir_ols2k_walk_f32<1024>, dim3((unsigned)blocks), dim3(OLS_THREADS), lds_bytes, as_stream(stream),
+        hipLaunchKernelGGL(k_fir_ols2k_chain_f32<1024>, dim3((unsigned)blocks), dim3(OLS_THREADS), lds_bytes, as_stream(stream),
                            in, out, hist, hf, tw, w2, G);
     }
-    LLZ_LAUNCH_CHECK("k_fir_ols2k_walk_f32");
+    LLZ_LAUNCH_CHECK("k_fir_ols2k_chain_f32");
     return LLZ_OK;
 }

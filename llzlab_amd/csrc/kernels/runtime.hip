@@ -22,7 +22,7 @@ extern "C" const char *llz_hip_last_error(void) { return g_err; }
 #include <string.h>
 static std::atomic<int> g_tune[LLZS_TUNE_COUNT];
 static const char *const g_tune_names[LLZS_TUNE_COUNT] = {
-    "ols_chain", "ols_wg_per_cu", "rs_generic", "rs_tiles", "rs_dec_valu", "rs_i16_path", "mfma_nacc",
+    "ols_wg_per_cu", "rs_generic", "rs_tiles", "rs_dec_valu", "rs_i16_path", "mfma_nacc",
     "mfma_wg_per_cu", "fft_generic", "iir_segs", "iir_unpacked", "iir_f64", "iir_pipe", "iir_wave_min_items",
     "shard_rccl"};
 namespace {

@@ -30,8 +30,7 @@ int   llzs_is_device_ptr(const void *p);
  * choice can be overridden for A/B measurements and for tests that force a rarely taken form through the public
  * llz_hip_tune(name, value) (include/llz_hip.h).  value < 0 = unset (the library's own choice). */
 enum {
-    LLZS_TUNE_OLS_CHAIN = 0,        /* 1 force / 0 forbid the chain form of the 1024-point overlap-save kernel */
-    LLZS_TUNE_OLS_WG_PER_CU,        /* resident workgroups per CU the overlap-save grid is sized for */
+    LLZS_TUNE_OLS_WG_PER_CU = 0,        /* resident workgroups per CU the overlap-save grid is sized for */
     LLZS_TUNE_RS_GENERIC,           /* 1: general L/M resampler without the register-window kernel; 2: first LDS kernel */
     LLZS_TUNE_RS_TILES,             /* tiles per workgroup of the general L/M resampler */
     LLZS_TUNE_RS_DEC_VALU,          /* 1: L = 1 float32 decimator on the vector pipe (LDS polyphase kernel) */

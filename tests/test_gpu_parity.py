@@ -883,7 +883,7 @@ def test_mdct_batch_vs_oracle(dev, oracle, n, count):
                                                (1025, 70, 1024 * 40 + 3), (2, 3, 4096), (513, 6, 3072 * 20 + 77),
                                                (400, 300, 3072 * 3), (512, 1, 3072 * 17)])
 def test_fir_ols2048_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
-    """filters of 258..1025 taps on 2048-point overlap-save (k_fir_ols2k_walk_f32: one radix-2 step across the half-waves of a
+    """filters of 258..1025 taps on 2048-point overlap-save (k_fir_ols2k_chain_f32: one radix-2 step across the half-waves of a
     wave around the 1024-point machinery; 512 samples of overlap up to 513 taps, 1024 above): two frames (history carried by
     the handle) and the flush tail, ragged lengths, segments of several jobs, blocks that end past the frame, and the
     automatic choice"""
@@ -941,27 +941,24 @@ def test_fir_ols4096_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
 
 
 # ------------------------------------------------------------------------------------------------ overlap-save, chain form
-@pytest.mark.parametrize("chain", [1, 0], ids=["chain", "walk"])
-def test_fir_ols_forms_forced(dev, oracle, chain):
-    """the launcher takes the chain form (prefetch carried across segments) only on batches far larger than a test can
-    afford to check sample by sample (test_fir_ols_headline_shape_full_length does the large one): llz_hip_tune forces
-    either form on small batches, including ragged lengths, segments shorter than 16 jobs, odd row lengths and streaming
-    across calls"""
-    with capi.tuned(ols_chain=chain):
-        for channels, n, taps_n in ((3, 1536 * 40 + 100, 257), (5, 1536 * 33, 63), (2, 1000, 129), (9, 1536 * 17 + 1, 200),
-                                    (4, 1536 * 5 + 7, 257)):
-            taps = oracle.fir_design(po.LPF, taps_n, 0.2, 0.0, po.KAISER)
-            x = oracle.synth_f32(channels, 2 * n, seed=taps_n)
-            ref = oracle.fir_batch_f32(x, taps.astype(np.float32).astype(np.float64))
-            f = filters.FirFilterMC(channels, n, taps, algo=filters.FIR_ALGO_OVERLAP_SAVE)
-            outs = []
-            for o in (0, n):                                    # two frames: the history carried between calls
-                xd = torch.from_numpy(np.ascontiguousarray(x[:, o:o + n])).to(dev)
-                yd = torch.empty_like(xd)
-                f.filter(xd, yd)
-                outs.append(yd.cpu().numpy())
-            f.close()
-            rms_check(np.concatenate(outs, axis=1), ref, f"fir ols chain={chain} {channels}x{n}x{taps_n}")
+def test_fir_ols_small_and_ragged_batches(dev, oracle):
+    """the 1024-point overlap-save kernel on batches far smaller than the headline (test_fir_ols_headline_shape_full_length
+    does the large one): ragged lengths, segments shorter than 16 jobs, fewer segments than half-wave slots, odd row lengths
+    and streaming across calls"""
+    for channels, n, taps_n in ((3, 1536 * 40 + 100, 257), (5, 1536 * 33, 63), (2, 1000, 129), (9, 1536 * 17 + 1, 200),
+                                (4, 1536 * 5 + 7, 257), (700, 1536 * 3, 99)):
+        taps = oracle.fir_design(po.LPF, taps_n, 0.2, 0.0, po.KAISER)
+        x = oracle.synth_f32(channels, 2 * n, seed=taps_n)
+        ref = oracle.fir_batch_f32_mt(x, taps.astype(np.float32).astype(np.float64))
+        f = filters.FirFilterMC(channels, n, taps, algo=filters.FIR_ALGO_OVERLAP_SAVE)
+        outs = []
+        for o in (0, n):                                    # two frames: the history carried between calls
+            xd = torch.from_numpy(np.ascontiguousarray(x[:, o:o + n])).to(dev)
+            yd = torch.empty_like(xd)
+            f.filter(xd, yd)
+            outs.append(yd.cpu().numpy())
+        f.close()
+        rms_check(np.concatenate(outs, axis=1), ref, f"fir ols {channels}x{n}x{taps_n}")
 
 
 def test_fir_ols_headline_shape_full_length(dev, oracle):

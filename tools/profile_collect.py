@@ -9,7 +9,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "profile_" + tag)
 dst = os.path.join(root, "profiles")
@@ -27,6 +27,24 @@ for name in ("bench.json", "bench_under_rocprof.json"):
     open(os.path.join(dst, f"{tag}_{name}"), "w").write(line)
 bench = json.loads([l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][0])
 kern = bench["roofline"]["kernel"]
+
+# warm launches only: the kernel trace of the profiled run lists every dispatch; the timed region of bench.py is dispatches
+# warmup .. warmup + steps - 1 of the headline kernel (the first `warmup` are untimed, later ones belong to the memcpy /
+# parity legs)
+prof = json.loads([l for l in open(os.path.join(src, "bench_under_rocprof.json")) if l.startswith("{")][0])
+trace = newest(src + "/stats/*/*_kernel_trace.csv")
+durs = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+        for r in csv.DictReader(open(trace)) if kern in r["Kernel_Name"]]
+durs = [d for _t, d in sorted(durs)]
+w, k = prof["warmup"], prof["steps"]
+timed = durs[w:w + k]
+warm = {"kernel": kern, "command": f"rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu  (steps {k}, warmup {w})",
+        "dispatches": len(durs), "all_ms": [round(d, 4) for d in durs],
+        "timed_region_avg_ms": sum(timed) / len(timed), "timed_region_min_ms": min(timed), "timed_region_max_ms": max(timed),
+        "bench_line_kernel_ms_avg_same_run": prof["roofline"]["kernel_ms_avg"],
+        "bench_line_frac_same_run": prof["roofline"]["frac"],
+        "frac_from_trace": prof["roofline"]["algorithmic_bytes_per_launch"] / (sum(timed) / len(timed) * 1e-3) / 1e9 / 8000.0}
+json.dump(warm, open(os.path.join(dst, f"{tag}_headline_kernel_trace.json"), "w"), indent=1)
 
 
 def counters(sub):
@@ -55,6 +73,9 @@ out = {
     "fetch_bytes_per_launch_corrected_x2": 2 * fetch["FETCH_SIZE"] * 1024,
     "write_bytes_per_launch": write["WRITE_SIZE"] * 1024,
     "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+    "kernel_source_sha256": __import__("hashlib").sha256(
+        b"".join(open(os.path.join(root, "llzlab_amd", "csrc", "kernels", f), "rb").read() for f in ("fir_ols.hip", "fft32.hpp"))
+    ).hexdigest(),
     "calibration": {
         "k_fir_tail_f32_FETCH_SIZE_KB_raw": tailf.get("FETCH_SIZE"),
         "k_fir_tail_f32_true_read_bytes": 4096 * 256 * 4,
@@ -82,5 +103,27 @@ with open(os.path.join(dst, f"{tag}_sq_counters.json"), "w") as f:
     json.dump({"kernel": kern, "per_launch_average": sq,
                "command": "rocprofv3 --pmc <8 counters> -- python3 bench.py --steps 3 --warmup 1 --no-cpu (two passes)"},
               f, indent=1)
+# matrix-pipe utilisation of the kernels that use MFMA (north_star: "MFMA utilisation reported"): busy cycles of the matrix
+# pipe over the SIMD-cycles of the dispatch (duration x shader clock x 1024 SIMDs; clock from GRBM_GUI_ACTIVE of the sq2 pass)
+mf = counters("pmc_mfma")
+sq2 = counters("pmc_sq2")
+stats = {r["Name"]: r for r in csv.DictReader(open(newest(src + "/stats/*/*_kernel_stats.csv")))}
+util = {}
+for name, v in mf.items():
+    busy = v.get("SQ_VALU_MFMA_BUSY_CYCLES")
+    if not busy or sum(busy) == 0:
+        continue
+    ns = float(stats[name]["AverageNs"]) if name in stats else None
+    gui = sq2.get(name, {}).get("GRBM_GUI_ACTIVE")
+    clock_ghz = (sum(gui) / len(gui) / 8) / ns if (gui and ns) else None
+    simd_cycles = ns * clock_ghz * 1024 if clock_ghz else None
+    util[name[:90]] = {"mfma_busy_cycles_per_launch": sum(busy) / len(busy),
+                       "mfma_instructions_per_launch": sum(v["SQ_INSTS_MFMA"]) / len(v["SQ_INSTS_MFMA"]),
+                       "avg_ms": ns / 1e6 if ns else None, "shader_clock_GHz": clock_ghz,
+                       "mfma_busy_fraction_of_simd_cycles": (sum(busy) / len(busy)) / simd_cycles if simd_cycles else None}
+json.dump({"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA ... -- python3 bench.py --steps 3 --warmup 1 --no-cpu",
+           "kernels": util}, open(os.path.join(dst, f"{tag}_mfma_utilisation.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 print(json.dumps(sq, indent=1))
+print(json.dumps(util, indent=1))
+print(json.dumps({k: v for k, v in warm.items() if k != "all_ms"}, indent=1))

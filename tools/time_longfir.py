@@ -18,8 +18,7 @@ def timed(fn, steps=5):
     return ms
 for T in taps_list:
     taps = filters.fir_design("lpf", T, 0.1, 0.0, filters.KAISER)
-    for name, tune in (("default", {}), ("half-wave 2048", {"fir_ols2k": 0})):
-        if T > 513 and tune: continue
+    for name, tune in (("default", {}),):
         with capi.tuned(**tune):
             f = filters.FirFilterMC(ch, n, taps)
             ms = timed(lambda: f.filter(x, y))
