@@ -108,6 +108,8 @@ typedef struct {
     double *d_coef;      /* stages x {b0,b1,b2,a1,a2} */
     double *d_pd, *d_pl; /* state-transition powers for the pipelined kernel: [S][6][4] and [S][64][12] */
     float *d_coef32, *d_pd32, *d_pl32;   /* float copies for the wave-autonomous float32 kernel: [S][5], [S][16], [S][64][12] */
+    float *d_pd32w, *d_pl32w, *d_ph32w;   /* 32-sample-per-lane packed kernel: powers of A^32, ph [S][40] (b0 folded) */
+    float in_gain32;     /* the product of the b0's (that kernel scales the input once) */
     float *d_ph32;       /* [S][24]: (h1[k], h2[k]) k < 8 = zero-input outputs of the unit start states, b0 b1 b2 a1 a2, pad */
     double *d_state;     /* [channels][stages][x1,x2,y1,y2]: the current state */
     double *d_state_alt; /* where a time-segmented launch writes the frame's end state (then the two swap) */
@@ -123,6 +125,7 @@ static void iirm_destroy(iirm_t *f)
     if (!f) return;
     llzs_free(f->d_coef); llzs_free(f->d_state); llzs_free(f->d_state_alt); llzs_free(f->d_pd); llzs_free(f->d_pl);
     llzs_free(f->d_coef32); llzs_free(f->d_pd32); llzs_free(f->d_pl32); llzs_free(f->d_ph32);
+    llzs_free(f->d_pd32w); llzs_free(f->d_pl32w); llzs_free(f->d_ph32w);
     llz_stage_release(&f->st_in); llz_stage_release(&f->st_out);
     f->tag = 0;
     free(f);
@@ -200,6 +203,71 @@ static int iirm_build_powers(iirm_t *f, const double *c5, int lane_run)
         }
     }
     free(pd); free(pl);
+    return rc;
+}
+
+/* Tables of the packed float32 kernel with 32 samples per lane and the b0 gains folded out (k_iir_cascade_wave_pk32):
+ * powers of P = A^32 for the lane scan, the homogeneous responses h1[k], h2[k] for k < 16, the section's b1/b0, b2/b0,
+ * a1, a2, and the state scales xfac_s = prod_{t >= s} b0_t, yfac_s = prod_{t > s} b0_t.  Built only when every b0 is
+ * usable as a divisor (no zero gain, partial products between 1e-6 and 1e6); otherwise the 16-sample kernel runs. */
+static int iirm_build_run32(iirm_t *f, const double *c5)
+{
+    const int S = f->stages;
+    if (S > 8 || !f->float32_ok) return LLZ_OK;
+    double xfac[9];
+    xfac[S] = 1.0;
+    for (int s = S - 1; s >= 0; s--) {
+        const double b0 = c5[5 * s];
+        xfac[s] = xfac[s + 1] * b0;
+        if (!(fabs(b0) > 1e-6) || !(fabs(xfac[s]) > 1e-6 && fabs(xfac[s]) < 1e6) ||
+            !(fabs(c5[5 * s + 1] / b0) < 1e4) || !(fabs(c5[5 * s + 2] / b0) < 1e4)) return LLZ_OK;
+    }
+    float *t = (float *)calloc((size_t)S * (16 + 768 + 40), sizeof(float));
+    if (!t) return LLZ_ERR_NOMEM;
+    float *pd = t, *pl = t + 16 * S, *ph = pl + 768 * S;
+    for (int s = 0; s < S; s++) {
+        const double a1 = c5[5 * s + 3], a2 = c5[5 * s + 4];
+        const double A[4] = {-a1, -a2, 1.0, 0.0};
+        double P[4] = {1.0, 0.0, 0.0, 1.0};
+        for (int i = 0; i < 32; i++) mat2_mul(A, P, P);
+        double pw2[4][4];                                          /* P^(2^d), d < 4 */
+        memcpy(pw2[0], P, sizeof(P));
+        for (int d = 1; d < 4; d++) mat2_mul(pw2[d - 1], pw2[d - 1], pw2[d]);
+        for (int d = 0; d < 4; d++)
+            for (int i = 0; i < 4; i++) pd[16 * s + 4 * d + i] = (float)pw2[d][i];
+        double pw[65][4];
+        pw[0][0] = 1.0; pw[0][1] = 0.0; pw[0][2] = 0.0; pw[0][3] = 1.0;
+        for (int k = 1; k <= 64; k++) mat2_mul(P, pw[k - 1], pw[k]);
+        for (int lane = 0; lane < 64; lane++) {                    /* per lane: P^lane, P^(lane%16+1), P^(lane%32+1) */
+            float *l = pl + ((size_t)s * 64 + lane) * 12;
+            for (int i = 0; i < 4; i++) {
+                l[i] = (float)pw[lane][i]; l[4 + i] = (float)pw[lane % 16 + 1][i]; l[8 + i] = (float)pw[lane % 32 + 1][i];
+            }
+        }
+        double p1 = 1.0, p2 = 0.0, q1 = 0.0, q2 = 1.0;             /* y[k] from (y[-1], y[-2]) = (1,0) and (0,1) */
+        for (int k = 0; k < 16; k++) {
+            const double h1 = -a1 * p1 - a2 * p2, h2 = -a1 * q1 - a2 * q2;
+            ph[40 * s + 2 * k] = (float)h1; ph[40 * s + 2 * k + 1] = (float)h2;
+            p2 = p1; p1 = h1; q2 = q1; q1 = h2;
+        }
+        const double b0 = c5[5 * s];
+        ph[40 * s + 32] = 1.f;
+        ph[40 * s + 33] = (float)(c5[5 * s + 1] / b0);
+        ph[40 * s + 34] = (float)(c5[5 * s + 2] / b0);
+        ph[40 * s + 35] = (float)a1;
+        ph[40 * s + 36] = (float)a2;
+        ph[40 * s + 37] = (float)xfac[s];
+        ph[40 * s + 38] = (float)xfac[s + 1];
+    }
+    f->in_gain32 = (float)xfac[0];
+    f->d_pd32w = (float *)llzs_malloc(sizeof(float) * 16 * (size_t)S);
+    f->d_pl32w = (float *)llzs_malloc(sizeof(float) * 768 * (size_t)S);
+    f->d_ph32w = (float *)llzs_malloc(sizeof(float) * 40 * (size_t)S);
+    int rc = (f->d_pd32w && f->d_pl32w && f->d_ph32w) ? LLZ_OK : LLZ_ERR_NOMEM;
+    if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_pd32w, pd, sizeof(float) * 16 * (size_t)S);
+    if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_pl32w, pl, sizeof(float) * 768 * (size_t)S);
+    if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_ph32w, ph, sizeof(float) * 40 * (size_t)S);
+    free(t);
     return rc;
 }
 
@@ -294,6 +362,7 @@ unsigned long llz_iir_cascade_mc_init(int channels, int stages, const double *co
     if (rc == LLZ_OK) rc = llzs_memset(f->d_state, 0, st_bytes, NULL);
     if (rc == LLZ_OK) f->float32_ok = iirm_float32_ok(c5, stages) && llzs_tune(LLZS_TUNE_IIR_F64) != 1;
     if (rc == LLZ_OK) rc = iirm_build_powers(f, c5, 16);
+    if (rc == LLZ_OK && llzs_tune(LLZS_TUNE_IIR_UNPACKED) < 1) rc = iirm_build_run32(f, c5);
     if (rc == LLZ_OK) f->warm_chunks = iirm_memory_chunks(c5, stages);
     if (rc == LLZ_OK) rc = llzs_sync(NULL);
     free(c5);
@@ -371,19 +440,35 @@ static int iirm_process(iirm_t *f, const float *x, float *y, int frame_len)
     const int min_items = llzs_tune(LLZS_TUNE_IIR_WAVE_MIN_ITEMS) >= 0 ? llzs_tune(LLZS_TUNE_IIR_WAVE_MIN_ITEMS) : 2048;
     const int wave_form = f->stages <= 8 && seg_items >= min_items && llzs_tune(LLZS_TUNE_IIR_PIPE) != 1 &&
                           (!f->float32_ok || f->d_pl32);
-    if (rc == LLZ_OK && n_fast > 0 && wave_form && f->float32_ok)
-        rc = llzs_iir_cascade_wave_f32(d_in, d_out, f->d_coef32, f->d_pd32, f->d_pl32, f->d_ph32, f->d_state, f->d_state_alt, f->channels, n_fast,
-                                       frame_len, frame_len, f->stages, f->warm_chunks, f->stream);
-    else if (rc == LLZ_OK && n_fast > 0 && wave_form)
-        rc = llzs_iir_cascade_wave_f64(d_in, d_out, f->d_coef, f->d_pd, f->d_pl, f->d_state, f->d_state_alt, f->channels, n_fast,
-                                       frame_len, frame_len, f->stages, f->warm_chunks, f->stream);
-    else if (rc == LLZ_OK && n_fast > 0)
-        rc = llzs_iir_cascade_pipe_f32(d_in, d_out, f->d_coef, f->d_pd, f->d_pl, f->d_state, f->d_state_alt, f->channels, n_fast,
-                                       frame_len, frame_len, f->stages, f->warm_chunks, f->float32_ok, f->stream);
-    if (rc == LLZ_OK && n_fast > 0) {                 /* the launch read d_state and wrote d_state_alt */
-        double *t = f->d_state;
-        f->d_state = f->d_state_alt;
-        f->d_state_alt = t;
+    /* packed float32 form with 32 samples per lane on the whole 2048-sample chunks, the 16-sample forms on what is left of
+     * the 1024-sample chunks; every launch reads d_state and writes d_state_alt, which then swap */
+    int done = 0;
+    if (rc == LLZ_OK && wave_form && f->float32_ok && f->d_ph32w && n_fast >= 2048) {
+        const int n32 = n_fast - n_fast % 2048;
+        rc = llzs_iir_cascade_wave32_f32(d_in, d_out, f->d_pd32w, f->d_pl32w, f->d_ph32w, f->d_state, f->d_state_alt,
+                                         f->channels, n32, frame_len, frame_len, f->stages, f->warm_chunks, f->in_gain32,
+                                         f->stream);
+        if (rc == LLZ_OK) {
+            double *t = f->d_state; f->d_state = f->d_state_alt; f->d_state_alt = t;
+            done = n32;
+        }
+    }
+    const int n16 = n_fast - done;
+    if (rc == LLZ_OK && n16 > 0) {
+        if (wave_form && f->float32_ok)
+            rc = llzs_iir_cascade_wave_f32(d_in + done, d_out + done, f->d_coef32, f->d_pd32, f->d_pl32, f->d_ph32, f->d_state,
+                                           f->d_state_alt, f->channels, n16, frame_len, frame_len, f->stages, f->warm_chunks,
+                                           f->stream);
+        else if (wave_form)
+            rc = llzs_iir_cascade_wave_f64(d_in + done, d_out + done, f->d_coef, f->d_pd, f->d_pl, f->d_state, f->d_state_alt,
+                                           f->channels, n16, frame_len, frame_len, f->stages, f->warm_chunks, f->stream);
+        else
+            rc = llzs_iir_cascade_pipe_f32(d_in + done, d_out + done, f->d_coef, f->d_pd, f->d_pl, f->d_state, f->d_state_alt,
+                                           f->channels, n16, frame_len, frame_len, f->stages, f->warm_chunks, f->float32_ok,
+                                           f->stream);
+        if (rc == LLZ_OK) {
+            double *t = f->d_state; f->d_state = f->d_state_alt; f->d_state_alt = t;
+        }
     }
     if (rc == LLZ_OK && n_fast < frame_len)
         rc = llzs_iir_cascade_f32(d_in + n_fast, d_out + n_fast, f->d_coef, f->d_state, f->channels,

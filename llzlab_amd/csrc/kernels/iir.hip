@@ -669,6 +669,211 @@ k_iir_cascade_wave_pk(const float *__restrict__ in, float *__restrict__ out,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_iir_cascade_wave_pk32: the packed float32 cascade with 32 samples per lane and the b0 gains folded out.
+//
+// In k_iir_cascade_wave_pk a section costs ~114 vector instructions per 1024-sample chunk, of which the part that does not
+// grow with the lane's run -- the lane scan (6 steps), the state hand-over and the half-run end values -- is ~45.  With
+// 32 samples per lane (16 pairs U[j] = (u[j], u[j+16]), 2048-sample chunks) that part is paid once per 32 samples instead
+// of once per 16.  And because a section's b0 only scales its output, the cascade's b0's are folded into ONE gain applied
+// to the input: a section computes  w = u + b1' u[-1] + b2' u[-2]  (b' = b / b0, two packed FMAs per pair instead of a
+// multiply and two FMAs), and its delay-line states are kept scaled by the product of the b0's still to come (xfac for the
+// inputs, yfac for the outputs; the handle's state stays in the true convention: scaled on load, unscaled on store).
+// Per sample and section: 2 (feed-forward) + 2 (zero-state recurrence) + 2 (start-state correction) packed-pair FMAs and
+// ~1.4 instructions of scan and bookkeeping, against 7 + 2.8 before.
+// Tables: pd32 / pl32 as above but for P = A^32; ph32 [S][40] = (h1[k], h2[k]) k < 16, then 1 b1' b2' a1 a2 xfac yfac pad.
+// The 32 h values of a section are fetched when the section starts (they are first used after its ~64 recurrence
+// instructions); the 8 coefficients and the scan powers one section ahead, as before.
+template <int S>
+__global__ void __launch_bounds__(256)
+k_iir_cascade_wave_pk32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ pd32,
+                        const float *__restrict__ pl32, const float *__restrict__ ph32 /* [S][40] */,
+                        const double *__restrict__ state_in, double *__restrict__ state, int nchunks_total, long in_pitch,
+                        long out_pitch, int segs, int seg_chunks, int warm, long items, float in_gain)
+{
+    constexpr int HP = 16, RUN = 32, CHUNK = 64 * RUN;
+    __shared__ __attribute__((aligned(16))) float s_pl[S * 64 * 12];
+    __shared__ __attribute__((aligned(16))) float s_pd[S * 16];
+    // A lane owns 32 CONSECUTIVE samples (the recurrence runs along them), i.e. 128 bytes.  Loaded straight into the lane
+    // that consumes them, a wave instruction touches 64 different 128-byte lines for 16 bytes each, and the eight
+    // instructions of a chunk fetch every line eight times over from L2 (measured: the kernel sat on L2 -> L1 bandwidth,
+    // 2.3 ms whatever the arithmetic cost).  So a chunk travels between HBM and registers in LINEAR order (a wave
+    // instruction = 1 KB contiguous) and is turned lane-major through a wave-private LDS buffer: 32 floats of data per 36 of
+    // pitch, which makes both the linear 16-byte accesses and the per-lane 16-byte accesses bank-conflict free.
+    __shared__ __attribute__((aligned(16))) float s_turn[4][CHUNK + CHUNK / 8];
+    for (int e = threadIdx.x; e < S * 768; e += 256) s_pl[e] = pl32[(e & ~3) | ((e & 1) << 1) | ((e >> 1) & 1)];
+    if (threadIdx.x < S * 16) {
+        const int e = threadIdx.x;
+        s_pd[e] = pd32[(e & ~3) | ((e & 1) << 1) | ((e >> 1) & 1)];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+    if (item >= items) return;
+    const int c = (int)(item / segs), seg = (int)(item - (long)c * segs);
+    const int skip = seg > 0 ? warm : 0;
+    const int chunk0 = seg * seg_chunks - skip;
+    const int nchunks = min(nchunks_total, (seg + 1) * seg_chunks) - chunk0;
+
+    float su1[S], su2[S], sy1[S], sy2[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        su1[s] = su2[s] = sy1[s] = sy2[s] = 0;
+        if (seg == 0) {
+            const double *st = state_in + ((size_t)c * S + s) * 4;
+            const float xf = ph32[s * 40 + 37], yf = ph32[s * 40 + 38];
+            su1[s] = (float)st[0] * xf; su2[s] = (float)st[1] * xf; sy1[s] = (float)st[2] * yf; sy2[s] = (float)st[3] * yf;
+        }
+    }
+    // linear order: instruction q of a chunk moves floats [256 q, 256 q + 256), 16 bytes per lane
+    const float *row = in + (size_t)c * in_pitch + (size_t)chunk0 * CHUNK + 4 * lane;
+    float *orow = out + (size_t)c * out_pitch + (size_t)chunk0 * CHUNK + 4 * lane;
+    float *turn = s_turn[threadIdx.x >> 6];
+    float *t_lin = turn + 4 * lane + 4 * (lane >> 3);       // + 288 q: float 256 q + 4 lane at pitch 36 per 32
+    float *t_own = turn + 36 * lane;                        // + 4 j: the lane's own run
+    float4 pre[8];
+    if (nchunks > 0) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(row + 256 * q)); pre[q] = make_float4(t.x, t.y, t.z, t.w); }
+    }
+    f16v h0, h1;                    // the current section's (h1[k], h2[k]): k < 8 and 8 <= k < 16
+    f8v cA, cB;
+    pk_tabs TA, TB;
+#define LLZ_PK_TIE asm volatile("" : "+v"(U[0]), "+v"(U[HP - 1]))
+#define LLZ_PK_FETCH(SEC, CX, TX)                                                                                    \
+    {                                                                                                                \
+        const lds_cv_f4v *tl = (const lds_cv_f4v *)(s_pl + ((SEC) * 64 + lane) * 12);                                \
+        const lds_cv_f4v *tp = (const lds_cv_f4v *)(s_pd + (SEC) * 16);                                              \
+        TX.l0 = tl[0]; TX.l1 = tl[1]; TX.l2 = tl[2];                                                                 \
+        TX.p0 = tp[0]; TX.p1 = tp[1]; TX.p2 = tp[2]; TX.p3 = tp[3];                                                  \
+        asm volatile("s_load_dwordx8 %0, %1, %2" : "=&s"(CX) : "s"(ph32), "n"((SEC) * 160 + 128) : "memory");         \
+        LLZ_PK_TIE;                                                                                                  \
+    }
+#define LLZ_PK_FETCH_H(SEC)                                                                                          \
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4"                                          \
+                 : "=&s"(h0), "=&s"(h1) : "s"(ph32), "n"((SEC) * 160), "n"((SEC) * 160 + 64) : "memory")
+#define LLZ_PK_WAIT(CX)                                                                                              \
+    {                                                                                                                \
+        LLZ_PK_TIE;                                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(CX));                                                             \
+    }
+    f2 U[HP];                                                          // U[j] = (u[j], u[j + 16])
+    U[0] = U[HP - 1] = splat(0.f);
+    LLZ_PK_FETCH(0, cA, TA)
+    const f2 G = splat(in_gain);
+    for (int chunk = 0; chunk < nchunks; chunk++) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) *reinterpret_cast<float4 *>(t_lin + 288 * q) = pre[q];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 8; q++) pre[q] = *reinterpret_cast<const float4 *>(t_own + 4 * q);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            U[4 * q + 0] = G * f2{pre[q].x, pre[q + 4].x}; U[4 * q + 1] = G * f2{pre[q].y, pre[q + 4].y};
+            U[4 * q + 2] = G * f2{pre[q].z, pre[q + 4].z}; U[4 * q + 3] = G * f2{pre[q].w, pre[q + 4].w};
+        }
+        if (chunk + 1 < nchunks) {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                { const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(row + (size_t)(chunk + 1) * CHUNK + 256 * q)); pre[q] = make_float4(t.x, t.y, t.z, t.w); }
+        }
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            // this section's constants: waited for here, the next section's requested, then the section's own h values
+            f8v &cc = (s & 1) ? cB : cA;
+            pk_tabs &T = (s & 1) ? TB : TA;
+            if ((s & 1) == 0) {
+                LLZ_PK_WAIT(cA);
+                if (s + 1 < S) LLZ_PK_FETCH(s + 1, cB, TB)
+            } else {
+                LLZ_PK_WAIT(cB);
+                LLZ_PK_FETCH((s + 1 < S ? s + 1 : 0), cA, TA)
+            }
+            LLZ_PK_FETCH_H(s);
+            const float b1 = cc[1], b2 = cc[2], a1 = cc[3], a2 = cc[4];
+            float um1 = dpp_<DPP_WAVE_SHR1, 0xF>(U[HP - 1].y), um2 = dpp_<DPP_WAVE_SHR1, 0xF>(U[HP - 2].y);
+            if (lane == 0) { um1 = su1[s]; um2 = su2[s]; }
+            su1[s] = lane63_(U[HP - 1].y); su2[s] = lane63_(U[HP - 2].y);
+            {   // feed-forward part in place, from the top so that U[j-1], U[j-2] are still the inputs (b0 folded out)
+                const f2 Um1 = f2{um1, U[HP - 1].x}, Um2 = f2{um2, U[HP - 2].x};
+                const f2 B1 = splat(b1), B2 = splat(b2);
+#pragma unroll
+                for (int j = HP - 1; j >= 2; j--) U[j] = pk_fma(B2, U[j - 2], pk_fma(B1, U[j - 1], U[j]));
+                U[1] = pk_fma(B2, Um1, pk_fma(B1, U[0], U[1]));
+                U[0] = pk_fma(B2, Um2, pk_fma(B1, Um1, U[0]));
+            }
+            {   // both half runs from the zero state: U[j] <- (w[j], w[j + 16])
+                const f2 A1 = splat(-a1), A2 = splat(-a2);
+                f2 Z1 = U[0], Z2;
+                U[1] = pk_fma(A1, U[0], U[1]);
+                Z2 = Z1; Z1 = U[1];
+#pragma unroll
+                for (int j = 2; j < HP; j++) {
+                    const f2 Y = pk_fma(A1, Z1, pk_fma(A2, Z2, U[j]));
+                    U[j] = Y;
+                    Z2 = Z1; Z1 = Y;
+                }
+            }
+            LLZ_PK_TIE;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(h0), "+s"(h1));     // the section's h values (requested ~64 instructions ago)
+            // the lane's zero-state end state (yz[31], yz[30]): the second half run started from (w[15], w[14])
+            f2 ZZ;
+            ZZ.x = fma_(h1[14], U[HP - 1].x, fma_(h1[15], U[HP - 2].x, U[HP - 1].y));
+            ZZ.y = fma_(h1[12], U[HP - 1].x, fma_(h1[13], U[HP - 2].x, U[HP - 2].y));
+#define LLZ_SCAN_STEP(CTRL, MASK, M)                                                                                 \
+            {                                                                                                        \
+                const f2 Q = dpp2_<CTRL, MASK>(ZZ);                                                                  \
+                ZZ = pk_fma(f2{M.x, M.y}, splat(Q.x), pk_fma(f2{M.z, M.w}, splat(Q.y), ZZ));                         \
+            }
+            LLZ_SCAN_STEP(DPP_ROW_SHR + 1, 0xF, T.p0) LLZ_SCAN_STEP(DPP_ROW_SHR + 2, 0xF, T.p1)
+            LLZ_SCAN_STEP(DPP_ROW_SHR + 4, 0xF, T.p2) LLZ_SCAN_STEP(DPP_ROW_SHR + 8, 0xF, T.p3)
+            LLZ_SCAN_STEP(DPP_BCAST15, 0xA, T.l1) LLZ_SCAN_STEP(DPP_BCAST31, 0xC, T.l2)
+#undef LLZ_SCAN_STEP
+            // the lane's start state (y[-1], y[-2]), then the true (y[15], y[14]): the start state of the second half run
+            const f2 Y0 = pk_fma(f2{T.l0.x, T.l0.y}, splat(sy1[s]), pk_fma(f2{T.l0.z, T.l0.w}, splat(sy2[s]), dpp2_<DPP_WAVE_SHR1, 0xF>(ZZ)));
+            const float ym1 = fma_(h1[14], Y0.x, fma_(h1[15], Y0.y, U[HP - 1].x));
+            const float ym2 = fma_(h1[12], Y0.x, fma_(h1[13], Y0.y, U[HP - 2].x));
+            const f2 SA = f2{Y0.x, ym1}, SB = f2{Y0.y, ym2};
+#pragma unroll
+            for (int j = 0; j < 8; j++) U[j] = pk_fma(splat(h0[2 * j]), SA, pk_fma(splat(h0[2 * j + 1]), SB, U[j]));
+#pragma unroll
+            for (int j = 0; j < 8; j++) U[8 + j] = pk_fma(splat(h1[2 * j]), SA, pk_fma(splat(h1[2 * j + 1]), SB, U[8 + j]));
+            sy1[s] = lane63_(U[HP - 1].y); sy2[s] = lane63_(U[HP - 2].y);
+            if ((s & 1) == 0 && s + 1 == S) LLZ_PK_FETCH(0, cA, TA)   // odd S: set A is free only now (once per chunk)
+        }
+        if (chunk >= skip) {
+            float *dst = orow + (size_t)chunk * CHUNK;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                *reinterpret_cast<float4 *>(t_own + 4 * q) = make_float4(U[4 * q].x, U[4 * q + 1].x, U[4 * q + 2].x, U[4 * q + 3].x);
+                *reinterpret_cast<float4 *>(t_own + 16 + 4 * q) = make_float4(U[4 * q].y, U[4 * q + 1].y, U[4 * q + 2].y, U[4 * q + 3].y);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const f4v v = *reinterpret_cast<const f4v *>(t_lin + 288 * q);
+                __builtin_nontemporal_store(v, reinterpret_cast<f4v *>(dst + 256 * q));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // read out before the next chunk is written in
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // nothing in flight when the wave ends
+#undef LLZ_PK_FETCH
+#undef LLZ_PK_FETCH_H
+#undef LLZ_PK_TIE
+#undef LLZ_PK_WAIT
+    if (lane == 0 && seg == segs - 1) {
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            double *st = state + ((size_t)c * S + s) * 4;
+            const float xf = ph32[s * 40 + 37], yf = ph32[s * 40 + 38];
+            st[0] = (double)su1[s] / (double)xf; st[1] = (double)su2[s] / (double)xf;
+            st[2] = (double)sy1[s] / (double)yf; st[3] = (double)sy2[s] / (double)yf;
+        }
+    }
+}
 // ---------------------------------------------------------------------------------------------------------------
 // k_iir_cascade_wave_pf64: the double wave-autonomous cascade with the same one-section-ahead fetch.  k_iir_cascade_wave
 // <double, 8> needs 348 VGPRs (the compiler hoists every section's powers out of the chunk loop) and so runs one wave per
@@ -1038,4 +1243,63 @@ extern "C" int llzs_iir_cascade_wave_f64(const float *in, float *out, const doub
 {
     return launch_iir_wave<double>(in, out, coef, pd, pl, nullptr, state_in, state, channels, n, in_pitch, out_pitch, stages, warm_chunks,
                                    24, stream);
+}
+
+// 32 samples per lane, b0 folded out (k_iir_cascade_wave_pk32): n a multiple of 2048, rows 16-byte aligned, 1..8 sections,
+// warm_chunks in units of 1024 samples as everywhere; tables for P = A^32: pd32 [S][16], pl32 [S][64][12], ph32 [S][40];
+// in_gain = the product of the b0's
+extern "C" int llzs_iir_cascade_wave32_f32(const float *in, float *out, const float *pd32, const float *pl32,
+                                           const float *ph32, const double *state_in, double *state, int channels, int n,
+                                           long in_pitch, long out_pitch, int stages, int warm_chunks, float in_gain,
+                                           void *stream)
+{
+    if (!in || !out || !pd32 || !pl32 || !ph32 || !state || !state_in || state == state_in || channels <= 0 || n <= 0 ||
+        (n % 2048) || stages < 1 || stages > 8 || warm_chunks < 1 || in_pitch < n || out_pitch < n || (in_pitch & 3) ||
+        (out_pitch & 3) || (reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) {
+        llzs_set_error("iir_cascade_wave32_f32: bad arguments");
+        return LLZ_ERR_ARG;
+    }
+    static const void *const tab[8] = {
+        (const void *)k_iir_cascade_wave_pk32<1>, (const void *)k_iir_cascade_wave_pk32<2>, (const void *)k_iir_cascade_wave_pk32<3>,
+        (const void *)k_iir_cascade_wave_pk32<4>, (const void *)k_iir_cascade_wave_pk32<5>, (const void *)k_iir_cascade_wave_pk32<6>,
+        (const void *)k_iir_cascade_wave_pk32<7>, (const void *)k_iir_cascade_wave_pk32<8>};
+    const void *kfn = tab[stages - 1];
+    int blocks_per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kfn, 256, 0) != hipSuccess || blocks_per_cu < 1) {
+        (void)hipGetLastError();
+        blocks_per_cu = 2;
+    }
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+        (void)hipGetLastError();
+        cus = 256;
+    }
+    const long slots = 4L * blocks_per_cu * cus;
+    const int nchunks = n / 2048, warm = (warm_chunks + 1) / 2;
+    // time segments per channel as for the 16-sample kernels: about three rounds of (channel, segment) items while a
+    // segment stays long (>= 32 chunks of 2048), else one round; segments at least 8 x the warm-up
+    int segs = 1;
+    for (int rounds = 3; rounds >= 1; rounds--) {
+        segs = (int)((rounds * slots + channels / 2) / channels);
+        if (segs < 1) segs = 1;
+        if (segs > 64) segs = 64;
+        if (rounds == 1 || nchunks / segs >= 32) break;
+    }
+    while (segs > 1 && nchunks / segs < 8 * warm) segs--;
+    if (const int v = llzs_tune(LLZS_TUNE_IIR_SEGS); v >= 1 && v <= 64) segs = v;
+    const int seg_chunks = (nchunks + segs - 1) / segs;
+    segs = (nchunks + seg_chunks - 1) / seg_chunks;
+    const long items = (long)channels * segs;
+    const dim3 grid((unsigned)((items + 3) / 4));
+#define LLZ_PK32_LAUNCH(S)                                                                                           \
+    hipLaunchKernelGGL((k_iir_cascade_wave_pk32<S>), grid, dim3(256), 0, as_stream(stream), in, out, pd32, pl32, ph32,  \
+                       state_in, state, nchunks, in_pitch, out_pitch, segs, seg_chunks, warm, items, in_gain)
+    switch (stages) {
+    case 1: LLZ_PK32_LAUNCH(1); break; case 2: LLZ_PK32_LAUNCH(2); break; case 3: LLZ_PK32_LAUNCH(3); break;
+    case 4: LLZ_PK32_LAUNCH(4); break; case 5: LLZ_PK32_LAUNCH(5); break; case 6: LLZ_PK32_LAUNCH(6); break;
+    case 7: LLZ_PK32_LAUNCH(7); break; default: LLZ_PK32_LAUNCH(8); break;
+    }
+#undef LLZ_PK32_LAUNCH
+    LLZ_LAUNCH_CHECK("k_iir_cascade_wave_pk32");
+    return LLZ_OK;
 }

@@ -154,6 +154,11 @@ int llzs_iir_cascade_wave_f32(const float *in, float *out, const float *coef32, 
                                                    * unpacked kernel */,
                               const double *state_in, double *state_out, int channels, int n, long in_pitch, long out_pitch, int stages,
                               int warm_chunks, void *stream);
+/* the same with 32 samples per lane and the b0 gains folded into in_gain (iir.hip: k_iir_cascade_wave_pk32): n % 2048 == 0;
+ * tables for P = A^32; ph32 [S][40] = (h1[k], h2[k]) k < 16, then 1 b1/b0 b2/b0 a1 a2 xfac yfac pad */
+int llzs_iir_cascade_wave32_f32(const float *in, float *out, const float *pd32, const float *pl32, const float *ph32,
+                                const double *state_in, double *state_out, int channels, int n, long in_pitch,
+                                long out_pitch, int stages, int warm_chunks, float in_gain, void *stream);
 /* the same in double from the pipelined kernel's tables; at most 8 sections */
 int llzs_iir_cascade_wave_f64(const float *in, float *out, const double *coef, const double *pd, const double *pl,
                               const double *state_in, double *state_out, int channels, int n, long in_pitch, long out_pitch, int stages,
