@@ -693,7 +693,9 @@ k_iir_cascade_wave_pk32(const float *__restrict__ in, float *__restrict__ out, c
                         long out_pitch, int segs, int seg_chunks, int warm, long items, float in_gain)
 {
     constexpr int HP = 16, RUN = 32, CHUNK = 64 * RUN;
-    __shared__ __attribute__((aligned(16))) float s_pl[S * 64 * 12];
+    // per-lane scan powers: P^lane for 64 lanes, P^(lane%16+1) for 16, P^(lane%32+1) for 32 (the global table repeats the
+    // last two for every lane; keeping one copy leaves room for three workgroups per CU next to the turn buffers)
+    __shared__ __attribute__((aligned(16))) float s_pl[S * 448];
     __shared__ __attribute__((aligned(16))) float s_pd[S * 16];
     // A lane owns 32 CONSECUTIVE samples (the recurrence runs along them), i.e. 128 bytes.  Loaded straight into the lane
     // that consumes them, a wave instruction touches 64 different 128-byte lines for 16 bytes each, and the eight
@@ -702,7 +704,14 @@ k_iir_cascade_wave_pk32(const float *__restrict__ in, float *__restrict__ out, c
     // instruction = 1 KB contiguous) and is turned lane-major through a wave-private LDS buffer: 32 floats of data per 36 of
     // pitch, which makes both the linear 16-byte accesses and the per-lane 16-byte accesses bank-conflict free.
     __shared__ __attribute__((aligned(16))) float s_turn[4][CHUNK + CHUNK / 8];
-    for (int e = threadIdx.x; e < S * 768; e += 256) s_pl[e] = pl32[(e & ~3) | ((e & 1) << 1) | ((e >> 1) & 1)];
+    for (int e = threadIdx.x; e < S * 448; e += 256) {
+        const int sec = e / 448, r = e - sec * 448;
+        // r < 256: P^lane (lane = r / 4); r < 320: P^(i+1), i = (r - 256) / 4 < 16; else P^(i+1), i = (r - 320) / 4 < 32
+        const int lane_src = r < 256 ? r >> 2 : (r < 320 ? (r - 256) >> 2 : (r - 320) >> 2);
+        const int part = r < 256 ? 0 : (r < 320 ? 4 : 8);
+        const int el = r & 3, el_t = ((el & 1) << 1) | ((el >> 1) & 1);       // (m00, m01, m10, m11) -> (m00, m10, m01, m11)
+        s_pl[e] = pl32[(sec * 64 + lane_src) * 12 + part + el_t];
+    }
     if (threadIdx.x < S * 16) {
         const int e = threadIdx.x;
         s_pd[e] = pd32[(e & ~3) | ((e & 1) << 1) | ((e >> 1) & 1)];
@@ -743,9 +752,11 @@ k_iir_cascade_wave_pk32(const float *__restrict__ in, float *__restrict__ out, c
 #define LLZ_PK_TIE asm volatile("" : "+v"(U[0]), "+v"(U[HP - 1]))
 #define LLZ_PK_FETCH(SEC, CX, TX)                                                                                    \
     {                                                                                                                \
-        const lds_cv_f4v *tl = (const lds_cv_f4v *)(s_pl + ((SEC) * 64 + lane) * 12);                                \
+        const float *ts = s_pl + (SEC) * 448;                                                                        \
         const lds_cv_f4v *tp = (const lds_cv_f4v *)(s_pd + (SEC) * 16);                                              \
-        TX.l0 = tl[0]; TX.l1 = tl[1]; TX.l2 = tl[2];                                                                 \
+        TX.l0 = *(const lds_cv_f4v *)(ts + 4 * lane);                                                                \
+        TX.l1 = *(const lds_cv_f4v *)(ts + 256 + 4 * (lane & 15));                                                   \
+        TX.l2 = *(const lds_cv_f4v *)(ts + 320 + 4 * (lane & 31));                                                   \
         TX.p0 = tp[0]; TX.p1 = tp[1]; TX.p2 = tp[2]; TX.p3 = tp[3];                                                  \
         asm volatile("s_load_dwordx8 %0, %1, %2" : "=&s"(CX) : "s"(ph32), "n"((SEC) * 160 + 128) : "memory");         \
         LLZ_PK_TIE;                                                                                                  \
@@ -938,6 +949,9 @@ k_iir_cascade_wave_pf64(const float *__restrict__ in, float *__restrict__ out,
 {
     __shared__ __attribute__((aligned(16))) double s_pl[S * 64 * 12];
     __shared__ __attribute__((aligned(16))) double s_pd[S * 16];
+    // chunks move between HBM and registers in linear order and are turned lane-major through a wave-private LDS buffer
+    // (16 floats of data per 20 of pitch: conflict-free both ways), as in k_iir_cascade_wave_pk32
+    extern __shared__ __attribute__((aligned(16))) float s_turn_dyn[];
     for (int e = threadIdx.x; e < S * 768; e += 256) s_pl[e] = pl[e];
     if (threadIdx.x < S * 16) s_pd[threadIdx.x] = pd[(threadIdx.x >> 4) * 24 + (threadIdx.x & 15)];
     __syncthreads();
@@ -958,12 +972,15 @@ k_iir_cascade_wave_pf64(const float *__restrict__ in, float *__restrict__ out,
             su1[s] = st[0]; su2[s] = st[1]; sy1[s] = st[2]; sy2[s] = st[3];
         }
     }
-    const float *row = in + (size_t)c * in_pitch + (size_t)chunk0 * 1024 + lane * 16;
-    float *orow = out + (size_t)c * out_pitch + (size_t)chunk0 * 1024 + lane * 16;
+    const float *row = in + (size_t)c * in_pitch + (size_t)chunk0 * 1024 + 4 * lane;
+    float *orow = out + (size_t)c * out_pitch + (size_t)chunk0 * 1024 + 4 * lane;
+    float *turn = s_turn_dyn + (threadIdx.x >> 6) * 1280;
+    float *t_lin = turn + 4 * lane + 4 * (lane >> 2);       // + 320 q: float 256 q + 4 lane at pitch 20 per 16
+    float *t_own = turn + 20 * lane;                        // + 4 j: the lane's own run
     float4 pre[4];
     if (nchunks > 0) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) pre[q] = *reinterpret_cast<const float4 *>(row + 4 * q);
+        for (int q = 0; q < 4; q++) pre[q] = *reinterpret_cast<const float4 *>(row + 256 * q);
     }
     d4v cA, cB; double aA, aB;
     pf_tabs TA, TB;
@@ -988,10 +1005,16 @@ k_iir_cascade_wave_pf64(const float *__restrict__ in, float *__restrict__ out,
     LLZ_PF_FETCH(0, cA, aA, TA)
     for (int chunk = 0; chunk < nchunks; chunk++) {
 #pragma unroll
+        for (int q = 0; q < 4; q++) *reinterpret_cast<float4 *>(t_lin + 320 * q) = pre[q];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 4; q++) pre[q] = *reinterpret_cast<const float4 *>(t_own + 4 * q);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
         for (int q = 0; q < 4; q++) { u[4 * q] = pre[q].x; u[4 * q + 1] = pre[q].y; u[4 * q + 2] = pre[q].z; u[4 * q + 3] = pre[q].w; }
         if (chunk + 1 < nchunks) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) pre[q] = *reinterpret_cast<const float4 *>(row + (size_t)(chunk + 1) * 1024 + 4 * q);
+            for (int q = 0; q < 4; q++) pre[q] = *reinterpret_cast<const float4 *>(row + (size_t)(chunk + 1) * 1024 + 256 * q);
         }
 #pragma unroll
         for (int s = 0; s < S; s++) {
@@ -1010,7 +1033,14 @@ k_iir_cascade_wave_pf64(const float *__restrict__ in, float *__restrict__ out,
             float *dst = orow + (size_t)chunk * 1024;
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                *reinterpret_cast<float4 *>(dst + 4 * q) = make_float4((float)u[4 * q], (float)u[4 * q + 1], (float)u[4 * q + 2], (float)u[4 * q + 3]);
+                *reinterpret_cast<float4 *>(t_own + 4 * q) = make_float4((float)u[4 * q], (float)u[4 * q + 1], (float)u[4 * q + 2], (float)u[4 * q + 3]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f4v v = *reinterpret_cast<const f4v *>(t_lin + 320 * q);
+                __builtin_nontemporal_store(v, reinterpret_cast<f4v *>(dst + 256 * q));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // read out before the next chunk is written in
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // nothing in flight when the wave ends
@@ -1204,8 +1234,10 @@ static int launch_iir_wave(const float *in, float *out, const R *coef, const R *
 #undef LLZ_AHEAD_LAUNCH
         } else {
 #define LLZ_AHEAD_LAUNCH(S)                                                                                          \
-    hipLaunchKernelGGL((k_iir_cascade_wave_pf64<S>), grid, dim3(256), 0, as_stream(stream), in, out, coef, pd, pl,      \
-                       state_in, state, nchunks, in_pitch, out_pitch, segs, seg_chunks, warm_chunks, items)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_iir_cascade_wave_pf64<S>),                            \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 1280 * (int)sizeof(float));            \
+    hipLaunchKernelGGL((k_iir_cascade_wave_pf64<S>), grid, dim3(256), 4 * 1280 * sizeof(float), as_stream(stream), in, \
+                       out, coef, pd, pl, state_in, state, nchunks, in_pitch, out_pitch, segs, seg_chunks, warm_chunks, items)
             switch (stages) {
             case 1: LLZ_AHEAD_LAUNCH(1); break; case 2: LLZ_AHEAD_LAUNCH(2); break; case 3: LLZ_AHEAD_LAUNCH(3); break;
             case 4: LLZ_AHEAD_LAUNCH(4); break; case 5: LLZ_AHEAD_LAUNCH(5); break; case 6: LLZ_AHEAD_LAUNCH(6); break;
