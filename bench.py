@@ -380,7 +380,8 @@ def sharded_configs(torch, filters, capi, shard, dev, comm_dev, stream, rank, wo
         coef = shard.broadcast_table(coef, device=comm_dev)
         q = filters.IirCascadeMC(ch, coef, stream=stream)
         ms = timed(lambda: q.filter(x, y), 20, warm=10)      # a 2 ms kernel: clocks need tens of ms to settle after idling
-        fma = q.fma_per_sample_section if hasattr(q, "fma_per_sample_section") else 7
+        # packed-FMA equivalents per sample and section: 6 in the float32 kernel (b0 folded into one input gain), 7 in double
+        fma = 6 if q.precision == 32 else 7
         out[key] = {
             "Msamples_s": total_ch * n / ms / 1e3, "GBs_per_gpu": 8 * ch * n / ms / 1e6,
             "hbm_frac_per_gpu": 8 * ch * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "channels_per_gpu": ch,
