@@ -229,10 +229,10 @@ def main():
         if world == 1 and not args.no_cpu:
             cpu = cpu_baseline(taps, pyoracle)
 
-    # long filters on the same batch (weak scaling like the headline): 513 taps on the 2048-point overlap-save, 2049 taps
-    # on the 4096-point one (the library's own choice) -- under 'also', never part of `value`
+    # long filters on the same batch (weak scaling like the headline): 513 taps on the 2048-point overlap-save, 1025 and
+    # 2049 taps on the 4096-point one (the library's own choice) -- under 'also', never part of `value`
     if not args.no_also and fir_algo == 2:
-        for long_taps in (513, 2049):
+        for long_taps in (513, 1025, 2049):
             lt = filters.fir_design("lpf", long_taps, 0.1, 0.0, filters.KAISER)
             lf = filters.FirFilterMC(channels, n, lt, stream=stream)
             lf.filter(x, y)
@@ -288,7 +288,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": {1: "k_fir_td_f32", 2: ols_kernel_name(channels, n), 3: "k_fir_mfma_bf16x3",
-                                    4: "k_fir_ols2048_f32", 5: "k_fir_ols4096_f32"}[fir_algo],
+                                    4: "k_fir_ols2k_chain_f32", 5: "k_fir_ols4k_f32"}[fir_algo],
                          "kernel_ms_avg": kern_ms, "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * channels * n,
                          "memcpy_d2d_GBs": memcpy_gbs,
                          "frac_of_memcpy_d2d": (achieved / memcpy_gbs) if memcpy_gbs else None},

@@ -148,8 +148,8 @@ typedef struct {
     int channels, frame_len, flt_len, algo;
     float *d_taps;              /* flt_len floats zero-padded to a multiple of 16 */
     float *d_hfreq, *d_twid;    /* overlap-save tables (NULL for the time-domain algorithm) */
-    float *d_hperm2, *d_cs2;    /* 4096-point overlap-save: permuted spectrum and the cos/sin table */
     float *d_tw2k;              /* 2048-point overlap-save: W_2048^n, n < 1024 (d_hfreq: even | odd bins) */
+    float *d_tw4k;              /* 4096-point overlap-save on a whole wave (<= 3073 taps): W_4096^n, n < 2048 (d_hfreq: 4 planes) */
     float *d_hist[2];           /* [channels][flt_len-1], ping-pong */
     int cur;
     float *d_zero;              /* [channels][flt_len-1] zeros: flush input */
@@ -160,7 +160,7 @@ typedef struct {
 static void firm_destroy(firm_t *f)
 {
     if (!f) return;
-    llzs_free(f->d_taps); llzs_free(f->d_hfreq); llzs_free(f->d_twid); llzs_free(f->d_hperm2); llzs_free(f->d_cs2); llzs_free(f->d_tw2k);
+    llzs_free(f->d_taps); llzs_free(f->d_hfreq); llzs_free(f->d_twid); llzs_free(f->d_tw2k); llzs_free(f->d_tw4k);
     llzs_free(f->d_hist[0]); llzs_free(f->d_hist[1]); llzs_free(f->d_zero);
     llz_stage_release(&f->st_in); llz_stage_release(&f->st_out);
     f->tag = 0;
@@ -258,23 +258,22 @@ static int firm_build_ols2k_tables(firm_t *f, const float *taps)
     return rc;
 }
 
-/* 4096-point overlap-save (fft.hip): the taps' spectrum / N in the output order of the 64 x 64 register transform,
- * [q][lane] = H[lane + 64 brev6(q)], and the size-N cos/sin table the device derives its transform tables from.  Direct DFT
- * in double, setup time only. */
-static int firm_build_ols_big_tables(firm_t *f, const float *taps, int N)
+/* 514 .. 3073 taps (k_fir_ols4k_f32): DFT_4096(taps) / 4096 as four planes (plane j = bins 4m + j), the 32 x 32 twiddles
+ * of the 1024-point transforms, W_2048^n and W_4096^n for the two radix-2 steps.  Direct DFT in double, setup time only. */
+static int firm_build_ols4k_tables(firm_t *f, const float *taps)
 {
-    float *hp = (float *)malloc(sizeof(float) * 2 * (size_t)N);
-    float *csf = (float *)malloc(sizeof(float) * 2 * (size_t)N);
+    const int N = 4096, Q = 1024;
+    float *hf = (float *)malloc(sizeof(float) * 2 * (size_t)N);
+    float *tw = (float *)malloc(sizeof(float) * 2 * 1024);
+    float *w2 = (float *)malloc(sizeof(float) * 2 * 1024);
+    float *w4 = (float *)malloc(sizeof(float) * 2 * 2048);
     double *cs = (double *)malloc(sizeof(double) * 2 * (size_t)N);
-    double *hf = (double *)malloc(sizeof(double) * 2 * (size_t)N);
     int rc = LLZ_ERR_NOMEM;
-    if (hp && csf && cs && hf) {
+    if (hf && tw && w2 && w4 && cs) {
         for (int i = 0; i < N; i++) {
             const double ang = 2.0 * M_PI * (double)i / (double)N;
             cs[2 * i] = (i == N / 4 || i == 3 * N / 4) ? 0.0 : cos(ang);
             cs[2 * i + 1] = (i == 0 || i == N / 2) ? 0.0 : sin(ang);
-            csf[i] = (float)cs[2 * i];
-            csf[N + i] = (float)cs[2 * i + 1];
         }
         for (int k = 0; k < N; k++) {
             double re = 0.0, im = 0.0;
@@ -283,26 +282,29 @@ static int firm_build_ols_big_tables(firm_t *f, const float *taps, int N)
                 re += (double)taps[t] * cs[2 * m];
                 im -= (double)taps[t] * cs[2 * m + 1];
             }
-            hf[2 * k] = re / N;
-            hf[2 * k + 1] = im / N;
+            const int dst = (k & 3) * Q + (k >> 2);
+            hf[2 * dst] = (float)(re / N);
+            hf[2 * dst + 1] = (float)(im / N);
         }
-        for (int q = 0; q < 64; q++) {
-            int bq = 0;
-            for (int b = 0; b < 6; b++)
-                if (q & (1 << b)) bq |= 1 << (5 - b);
-            for (int l = 0; l < 64; l++) {
-                const int k = l + 64 * bq;
-                hp[2 * (q * 64 + l)] = (float)hf[2 * k];
-                hp[2 * (q * 64 + l) + 1] = (float)hf[2 * k + 1];
+        for (int a = 0; a < 32; a++)
+            for (int b = 0; b < 32; b++) {
+                const int m = (4 * a * b) % N;                         /* W_1024^(ab) = W_4096^(4ab) */
+                tw[2 * (a * 32 + b)] = (float)cs[2 * m];
+                tw[2 * (a * 32 + b) + 1] = (float)(-cs[2 * m + 1]);
             }
-        }
-        f->d_hperm2 = (float *)llzs_malloc(sizeof(float) * 2 * (size_t)N);
-        f->d_cs2 = (float *)llzs_malloc(sizeof(float) * 2 * (size_t)N);
-        rc = (f->d_hperm2 && f->d_cs2) ? LLZ_OK : LLZ_ERR_NOMEM;
-        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_hperm2, hp, sizeof(float) * 2 * (size_t)N);
-        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_cs2, csf, sizeof(float) * 2 * (size_t)N);
+        for (int i = 0; i < 1024; i++) { w2[2 * i] = (float)cs[2 * (2 * i)]; w2[2 * i + 1] = (float)(-cs[2 * (2 * i) + 1]); }
+        for (int i = 0; i < 2048; i++) { w4[2 * i] = (float)cs[2 * i]; w4[2 * i + 1] = (float)(-cs[2 * i + 1]); }
+        f->d_hfreq = (float *)llzs_malloc(sizeof(float) * 2 * (size_t)N);
+        f->d_twid = (float *)llzs_malloc(sizeof(float) * 2 * 1024);
+        f->d_tw2k = (float *)llzs_malloc(sizeof(float) * 2 * 1024);
+        f->d_tw4k = (float *)llzs_malloc(sizeof(float) * 2 * 2048);
+        rc = (f->d_hfreq && f->d_twid && f->d_tw2k && f->d_tw4k) ? LLZ_OK : LLZ_ERR_NOMEM;
+        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_hfreq, hf, sizeof(float) * 2 * (size_t)N);
+        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_twid, tw, sizeof(float) * 2 * 1024);
+        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_tw2k, w2, sizeof(float) * 2 * 1024);
+        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_tw4k, w4, sizeof(float) * 2 * 2048);
     }
-    free(hp); free(csf); free(cs); free(hf);
+    free(hf); free(tw); free(w2); free(w4); free(cs);
     return rc;
 }
 
@@ -323,18 +325,18 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
          * matrix-core form of the time domain (23.7 ms at 257 taps against 31.9 ms on the VALU) */
         if (flt_len <= 32) algo = LLZ_FIR_ALGO_TIME;
         else if (flt_len <= LLZS_OLS_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE;
-        /* 2048-point overlap-save on a whole wave (4096 ch x 2^20): 7.9 ms up to 513 taps, 10.6 ms up to 1025; the 4096-point
-         * kernel needs 13.2 / 14.8 ms at 513 / 1025 taps */
-        else if (flt_len <= LLZS_OLS2K_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_2048;
-        else if (flt_len <= LLZS_OLS4_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_4096;
+        /* whole-wave overlap-save (4096 ch x 2^20): 2048 points with 512 of overlap 7.8 ms up to 513 taps (10.6 ms with 1024
+         * of overlap); 4096 points 8.0 / 8.3 / 11.3 / 19.5 ms with 512 / 1024 / 2048 / 3072 of overlap */
+        else if (flt_len <= 513) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_2048;
+        else if (flt_len <= LLZS_OLS4K_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_4096;
         else algo = llzs_fir_mfma_f32_fits(flt_len, 1) ? LLZ_FIR_ALGO_TIME_MFMA : LLZ_FIR_ALGO_TIME;
     }
-    if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048 && (flt_len < 2 || flt_len > LLZS_OLS2_MAX_TAPS)) {
-        llzs_set_error("llz_fir_filter_mc_init: the 2048-point overlap-save takes 2..%d taps", LLZS_OLS2_MAX_TAPS);
+    if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048 && (flt_len < 2 || flt_len > LLZS_OLS2K_MAX_TAPS)) {
+        llzs_set_error("llz_fir_filter_mc_init: the 2048-point overlap-save takes 2..%d taps", LLZS_OLS2K_MAX_TAPS);
         return LLZ_BAD_HANDLE;
     }
-    if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_4096 && (flt_len < 2 || flt_len > LLZS_OLS4_MAX_TAPS)) {
-        llzs_set_error("llz_fir_filter_mc_init: the 4096-point overlap-save takes 2..%d taps", LLZS_OLS4_MAX_TAPS);
+    if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_4096 && (flt_len < 2 || flt_len > LLZS_OLS4K_MAX_TAPS)) {
+        llzs_set_error("llz_fir_filter_mc_init: the 4096-point overlap-save takes 2..%d taps", LLZS_OLS4K_MAX_TAPS);
         return LLZ_BAD_HANDLE;
     }
     if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE && flt_len > LLZS_OLS_MAX_TAPS) {
@@ -374,7 +376,8 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
     if (rc == LLZ_OK) rc = llzs_memset(f->d_zero, 0, hist_bytes, NULL);
     if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE) rc = firm_build_ols_tables(f, taps);
     if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048) rc = firm_build_ols2k_tables(f, taps);
-    if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE_4096) rc = firm_build_ols_big_tables(f, taps, LLZS_OLS4_NFFT);
+    if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE_4096)
+        rc = firm_build_ols4k_tables(f, taps);
     if (rc == LLZ_OK) rc = llzs_sync(NULL);
     free(padded);
     if (rc != LLZ_OK) {
@@ -474,8 +477,8 @@ static int firm_launch(firm_t *f, const float *d_in, float *d_out, int n, long p
         rc = llzs_fir_ols2k_f32(d_in, d_out, hist, f->d_hfreq, f->d_twid, f->d_tw2k, f->channels, n, pitch_in, pitch_out,
                                 f->flt_len, f->stream);
     else if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_4096)
-        rc = llzs_fir_ols4096_f32(d_in, d_out, hist, f->d_hperm2, f->d_cs2, f->channels, n, pitch_in, pitch_out,
-                                  f->flt_len, f->stream);
+        rc = llzs_fir_ols4k_f32(d_in, d_out, hist, f->d_hfreq, f->d_twid, f->d_tw2k, f->d_tw4k, f->channels, n, pitch_in,
+                                pitch_out, f->flt_len, f->stream);
     else if (algo == LLZ_FIR_ALGO_TIME_MFMA)
         rc = llzs_fir_mfma_f32(d_in, d_out, hist, f->d_taps, f->channels, n, n, pitch_in, pitch_out, f->flt_len, 1,
                                1.0f, f->stream);

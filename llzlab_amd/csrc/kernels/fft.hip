@@ -1091,75 +1091,6 @@ k_stft_synthesis_reg_f32(const float *__restrict__ re, const float *__restrict__
         for (int q = tid; q < keep; q += 256) ola_new[(size_t)c * keep + q] = carry[q];
 }
 
-// Overlap-save FIR with 4096-point transforms (64 x 64, a whole wave per job) for filters of 1026..3073 taps (fir_ols.hip covers
-// up to 1025): a JOB = two consecutive blocks of one channel, packed as the real and imaginary part of one complex transform --
-// the filter is real, so IFFT(FFT(a + j b) H) = (a * h) + j (b * h) and nothing has to be unpacked.  Block b yields the
-// V = 4096 - (T-1) outputs [b V, (b+1) V) from the 4096 inputs that end there; samples before the frame come from the
-// handle's history.  INTERIOR: jobs all of whose samples lie inside the frame (lane pointers with immediate offsets);
-// otherwise the edge jobs (history, frame end), each access tested.
-// hperm: [q][lane] = H[lane + 64 brev6(q)] / 4096.
-// (interior instantiation: two waves per SIMD asked for, as for k_fft_square_f32<64>: 1537 taps 29.6 -> 17.4 ms)
-template <bool INTERIOR>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INTERIOR ? 2 : 1)))
-k_fir_ols4096_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
-                  const float2 *__restrict__ hperm, const float2 *__restrict__ tw2d, int n, long in_pitch,
-                  long out_pitch, int flt_len, int jobs_per_channel, long total_jobs, int first_job, int head_jobs)
-{
-    constexpr int E = 64, N = E * E, GROUPS = 256 / E, PITCH = E + 1;
-    __shared__ float bufs[GROUPS][E * PITCH];
-    const int tid = threadIdx.x, lg = tid % E;
-    const int grp = __builtin_amdgcn_readfirstlane(tid / E);       // a whole wave per job: uniform
-    const long job = (long)blockIdx.x * GROUPS + grp;
-    if (job >= total_jobs) return;
-    const int c = (int)(job / jobs_per_channel), e = (int)(job - (long)c * jobs_per_channel);
-    // edge instantiation: the first head_jobs jobs of a channel (they reach into the history: with V < (T-1)/2 more than
-    // one does) and the jobs from first_job on (frame end)
-    const int jq = INTERIOR ? first_job + e : (e < head_jobs ? e : first_job + e - head_jobs);
-    const int keep = flt_len - 1, V = N - keep;
-    const long o0 = (long)(2 * jq) * V, o1 = o0 + V;
-    const float *row = in + (size_t)c * in_pitch;
-    const float *hrow = hist ? hist + (size_t)c * keep : nullptr;
-    float *orow = out + (size_t)c * out_pitch;
-    float *buf = bufs[grp];
-    auto sample = [&](long idx) {
-        if (idx >= n) return 0.f;
-        if (idx >= 0) return row[idx];
-        return hrow ? hrow[keep + idx] : 0.f;
-    };
-    const float *p0 = row + (o0 - keep) + lg, *p1 = p0 + V;        // (formed, not dereferenced, when not interior)
-    cf v[E];
-#pragma unroll
-    for (int j = 0; j < E; j++) {
-        const int m = lg + E * j;
-        if (INTERIOR) v[j] = cf{p0[E * j], p1[E * j]};
-        else v[j] = cf{sample(o0 - keep + m), sample(o1 - keep + m)};
-    }
-    square_core<E, false>(v, buf, tw2d, lg);                       // v[q] = Z[lg + E brev6(q)]
-#pragma unroll
-    for (int q = 0; q < E; q++) {
-        const float2 h = hperm[q * E + lg];
-        v[q] = cmul<false>(v[q], cf{h.x, h.y});
-    }
-    cf u[E];
-#pragma unroll
-    for (int j = 0; j < E; j++) u[j] = v[brevE<E>(j)];             // bin order -> natural order: renaming
-    square_core<E, true>(u, buf, tw2d, lg);                        // u[q] = y[lg + E brev6(q)]
-    float *q0 = orow + (o0 - keep) + lg, *q1 = q0 + V;
-#pragma unroll
-    for (int q = 0; q < E; q++) {
-        const int mo = E * brevE<E>(q), m = lg + mo;
-        if (m < keep) continue;                                    // circular wrap-around: dropped
-        if (INTERIOR) { q0[mo] = u[q].x; q1[mo] = u[q].y; }
-        else {
-            if (o0 + m - keep < n) orow[o0 + m - keep] = u[q].x;
-            if (o1 + m - keep < n) orow[o1 + m - keep] = u[q].y;
-        }
-    }
-}
-
-// FFT autocorrelation for fft_len = 2 E^2 on a group of E lanes (E = 8: frames of 33..64 samples, E = 16: 129..256): the
-// scheme of k_acf2048_f32 (which is the E = 32 case on the half-wave functions, with the pruned inverse) written on
-// square_core.  tw2d: [E][E] table of the E^2-point transform; w2: W_(2 E^2)^k, k < E^2.
 template <int E>
 __global__ void __launch_bounds__(256)
 k_acf_sq_f32(const float *__restrict__ x, float *__restrict__ r, int frames, int n, int p,
@@ -1732,55 +1663,6 @@ static int stft_reg_tables(int size, const float *cs, void *stream, const float2
     }
     *tw2d = set[0];
     *tw1 = set[1];
-    return LLZ_OK;
-}
-
-// overlap-save FIR, 4096-point transforms, 2..3073 taps: hperm [64][64] float2 = H[lane + 64 brev6(q)] / 4096 (host-built),
-// cs = device table of size 4096 the transform table is derived from on first use
-extern "C" int llzs_fir_ols4096_f32(const float *in, float *out, const float *hist, const float *hperm, const float *cs,
-                                    int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream)
-{
-    if (!in || !out || !hperm || !cs || !hist || channels <= 0 || n <= 0 || flt_len < 2 || flt_len > 3073 ||
-        in_pitch < n || out_pitch < n) {
-        llzs_set_error("fir_ols4096_f32: bad arguments (flt_len=%d, 2..3073)", flt_len);
-        return LLZ_ERR_ARG;
-    }
-    int dev = 0;
-    LLZ_HIP_CHECK(hipGetDevice(&dev));
-    std::unique_lock<std::mutex> guard(g_derived_lock);
-    float2 **set = derived_slot(6, 4096, dev);
-    if (!set[0]) {
-        float2 *t = nullptr;
-        LLZ_HIP_CHECK(hipMalloc(&t, sizeof(float2) * 4096));
-        hipLaunchKernelGGL(k_fft_square_table, dim3(16), dim3(256), 0, as_stream(stream), t, cs, 64);
-        LLZ_LAUNCH_CHECK("k_fft_square_table");
-        LLZ_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
-        set[0] = t;
-    }
-    const float2 *tw2d = set[0];
-    guard.unlock();
-    const int keep = flt_len - 1, V = 4096 - keep;
-    const int blocks_per_channel = (n + V - 1) / V;
-    const int J = (blocks_per_channel + 1) / 2;                    // jobs (pairs of blocks) per channel
-    const int j_full = n / (2 * V);                                // jobs 0 .. j_full-1 end inside the frame
-    int head = (keep + 2 * V - 1) / (2 * V);                       // jobs 0 .. head-1 start inside the history
-    if (head < 1) head = 1;
-    if (head > J) head = J;
-    const int int_count = j_full - head > 0 ? j_full - head : 0;   // interior: head .. j_full-1
-    const int edge_first = j_full > head ? j_full : head;          // edge: 0 .. head-1 and edge_first .. J-1
-    const int edge_count = head + (J - edge_first > 0 ? J - edge_first : 0);
-    const float2 *hp = reinterpret_cast<const float2 *>(hperm);
-    if (int_count > 0) {
-        const long total = (long)int_count * channels;
-        hipLaunchKernelGGL(k_fir_ols4096_f32<true>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, as_stream(stream), in,
-                           out, hist, hp, tw2d, n, in_pitch, out_pitch, flt_len, int_count, total, head, head);
-    }
-    {
-        const long total = (long)edge_count * channels;
-        hipLaunchKernelGGL(k_fir_ols4096_f32<false>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, as_stream(stream), in,
-                           out, hist, hp, tw2d, n, in_pitch, out_pitch, flt_len, edge_count, total, edge_first, head);
-    }
-    LLZ_LAUNCH_CHECK("k_fir_ols4096_f32");
     return LLZ_OK;
 }
 

@@ -470,6 +470,167 @@ k_fir_ols2k_chain_f32(const float *__restrict__ in, float *__restrict__ out, con
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 514 .. 3073 taps: 4096-point transforms, again a whole wave per job, as radix-2 step + TWO 2048-point problems run one
+// after the other through the split above (each of them: radix-2 step + a 1024-point transform per half-wave).
+//     X[2k] = FFT_2048( a[n] + a[n+2048] ),   X[2k+1] = FFT_2048( (a[n] - a[n+2048]) W_4096^n );   back: E'[n] +- W_4096^-n O'[n]
+// A block is 128 rows of 32 samples, a lane owns the 64 rows of its parity (positions p: row 2p + h), rows p and p + 32 are
+// 2048 samples apart (in-lane butterflies).  The overlap O is 512 / 1024 / 2048 / 3072 samples by tap count (positions
+// below O / 64 of a lane; with 2048 only the "minus" half of the last step is ever stored).  64 complex values per lane leave
+// no room for a register prefetch or a carried overlap: a job's new dwords and those of block A's overlap (an L2 hit: the
+// same wave read them one job ago) are requested when the job starts, and the second wave of the SIMD covers the wait.  A
+// workgroup is 8 waves (one per CU: the four spectra planes, three twiddle tables and sixteen transpose buffers are 132 KB
+// of LDS).
+//
+// The spectrum is split four ways: plane j = 2 half + sub holds H[4m + j] / 4096 (sub 0 = the even-bin problem E, 1 = the
+// odd-bin problem O; inside a problem the lower half-wave has its even bins, the upper its odd bins).
+constexpr int O4K_WAVES = 8, O4K_THREADS = 64 * O4K_WAVES;
+
+// one 2048-point problem of the wave: v[p] = row 2p + h (p < 32) in, y[p] out (same ownership); see k_fir_ols2k_chain_f32
+__device__ __forceinline__ void ols2k_core(cf (&v)[32], cf (&y)[32], float *buf, const float2 *s_tw, const float2 *my_h,
+                                           const float2 *s_w, int l5, int rowoff)
+{
+    cf w[32], u[32];
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+        cf sm = cadd(v[p], v[p + 16]);
+        const float2 t = s_w[64 * p + rowoff];
+        cf df = cmul<false>(csub(v[p], v[p + 16]), cf{t.x, t.y});
+        swap32(sm.x, df.x);
+        swap32(sm.y, df.y);
+        w[2 * p] = sm;
+        w[2 * p + 1] = df;
+    }
+    ols_filter(w, u, buf, s_tw, my_h, l5, l5);
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+        cf P = u[brev5(2 * p)], Q = u[brev5(2 * p + 1)];
+        swap32(P.x, Q.x);
+        swap32(P.y, Q.y);
+        const float2 t = s_w[64 * p + rowoff];
+        Q = cmul<true>(Q, cf{t.x, t.y});
+        y[p] = cadd(P, Q);
+        y[p + 16] = csub(P, Q);
+    }
+}
+
+// O = overlap (512: up to 513 taps, 1024: up to 1025, 2048: up to 2049, 3072: up to 3073); a job is two blocks = 2 (4096 - O) new samples.
+// Lane position i (0..63) of a block is sample 64 i + rowoff; positions below O / 64 are overlap.
+template <int O>
+__global__ void __launch_bounds__(O4K_THREADS, 2)
+k_fir_ols4k_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
+                const float2 *__restrict__ hfreq4 /* [4][1024] */, const float2 *__restrict__ twid /* [32][32] W_1024^(ab) */,
+                const float2 *__restrict__ tw2k /* [1024] W_2048^n */, const float2 *__restrict__ tw4k /* [2048] W_4096^n */,
+                ols_geom G)
+{
+    constexpr int V = 4096 - O, JOB = 2 * V, PO = O / 64, PV = V / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *s_tw = reinterpret_cast<float2 *>(smem);           // [1024]
+    float2 *s_w2 = s_tw + 1024;                                 // [1024]
+    float2 *s_w4 = s_w2 + 1024;                                 // [2048]
+    float2 *s_h = s_w4 + 2048;                                  // [4][1024]
+    for (int i = threadIdx.x; i < 1024; i += O4K_THREADS) {
+        s_tw[i] = twid[i];
+        s_w2[i] = tw2k[i];
+        s_w4[i] = tw4k[i];
+        s_w4[1024 + i] = tw4k[1024 + i];
+#pragma unroll
+        for (int j = 0; j < 4; j++) s_h[1024 * j + i] = hfreq4[1024 * j + i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, l5 = lane & 31;
+    float *buf = reinterpret_cast<float *>(s_h + 4096) + (wave * 2 + half) * OLS_XBUF;
+    const long waves_total = (long)gridDim.x * O4K_WAVES;
+    const int rowoff = 32 * half + l5;
+    const int n = G.n;
+
+    for (long seg = (long)blockIdx.x * O4K_WAVES + wave; seg < G.total_segs; seg += waves_total) {
+        const int c = (int)(seg / G.segs_per_channel);
+        const int j0 = (int)(seg - (long)c * G.segs_per_channel) * G.seg_len;
+        const int count = min(G.seg_len, G.jobs_per_channel - j0);
+        const float *row = in + (size_t)c * G.in_pitch;
+        float *orow = out + (size_t)c * G.out_pitch;
+        const float *hrow = hist ? hist + (size_t)c * G.keep : nullptr;
+#pragma unroll 1
+        for (int jj = 0; jj < count; jj++) {
+            const int s = (j0 + jj) * JOB;
+            // block A (real parts) = [s - O, s + V), block B (imaginary parts) = [s + V - O, s + 2V).  Block A's overlap was
+            // read by this wave one job ago: it is read again (from L2) rather than carried -- 32 more registers would spill.
+            // Block B's first O samples are block A's last O.
+            cf v[64];
+            const bool whole = s >= O && s + JOB <= n;
+            if (whole) {
+#pragma unroll
+                for (int i = 0; i < PO; i++) v[i].x = row[s - O + 64 * i + rowoff];
+#pragma unroll
+                for (int i = PO; i < 64; i++) v[i].x = __builtin_nontemporal_load(&row[s - O + 64 * i + rowoff]);
+#pragma unroll
+                for (int i = PO; i < 64; i++) v[i].y = __builtin_nontemporal_load(&row[s + V - O + 64 * i + rowoff]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 64; i++) {
+                    const int ia = s - O + 64 * i + rowoff;
+                    float xa = 0.f;
+                    if (ia >= 0) xa = row[min(ia, n - 1)];
+                    else if (hrow && ia >= -G.keep) xa = hrow[G.keep + ia];
+                    v[i].x = ia < n ? xa : 0.f;
+                }
+#pragma unroll
+                for (int i = PO; i < 64; i++) {
+                    const int ib = s + V - O + 64 * i + rowoff;
+                    const float xb = row[min(ib, n - 1)];
+                    v[i].y = ib < n ? xb : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PO; i++) v[i].y = v[i + PV].x;
+            // ---- radix-2 step down: positions p and p + 32 are 2048 samples apart
+            cf e[32], o[32];
+#pragma unroll
+            for (int p = 0; p < 32; p++) {
+                e[p] = cadd(v[p], v[p + 32]);
+                const float2 t = s_w4[64 * p + rowoff];             // W_4096^n, n = 32 (2p + h) + l5
+                o[p] = cmul<false>(csub(v[p], v[p + 32]), cf{t.x, t.y});
+            }
+            // ---- the even-bin and the odd-bin 2048-point problems, one after the other
+            cf ye[32], yo[32];
+            ols2k_core(e, ye, buf, s_tw, s_h + (2 * half) * 1024, s_w2, l5, rowoff);
+            ols2k_core(o, yo, buf, s_tw, s_h + (2 * half + 1) * 1024, s_w2, l5, rowoff);
+            // ---- radix-2 step up: position p = E' + W^-n O', position p + 32 = E' - W^-n O'; positions >= O / 64 are outputs
+            const bool all_out = s + JOB <= n;
+#pragma unroll
+            for (int p = 0; p < 32; p++) {
+                if (p + 32 < PO) continue;
+                const float2 t = s_w4[64 * p + rowoff];
+                const cf q = cmul<true>(yo[p], cf{t.x, t.y});
+                if (p >= PO) {
+                    const cf y0 = cadd(ye[p], q);
+                    const int oa = s + 64 * (p - PO) + rowoff, ob = oa + V;
+                    if (all_out) {
+                        __builtin_nontemporal_store(y0.x, &orow[oa]);
+                        __builtin_nontemporal_store(y0.y, &orow[ob]);
+                    } else {
+                        if (oa < n) orow[oa] = y0.x;
+                        if (ob < n) orow[ob] = y0.y;
+                    }
+                }
+                const cf y1 = csub(ye[p], q);
+                const int oa = s + 64 * (p + 32 - PO) + rowoff, ob = oa + V;
+                if (all_out) {
+                    __builtin_nontemporal_store(y1.x, &orow[oa]);
+                    __builtin_nontemporal_store(y1.y, &orow[ob]);
+                } else {
+                    if (oa < n) orow[oa] = y1.x;
+                    if (ob < n) orow[ob] = y1.y;
+                }
+            }
+        }
+    }
+}
+
 } // namespace
 
 extern "C" int llzs_fir_ols_f32(const float *in, float *out, const float *hist, const float *hfreq,
@@ -572,4 +733,62 @@ extern "C" int llzs_fir_ols2k_f32(const float *in, float *out, const float *hist
     }
     LLZ_LAUNCH_CHECK("k_fir_ols2k_chain_f32");
     return LLZ_OK;
+}
+
+// 514 .. 3073 taps on 4096-point transforms (k_fir_ols4k_f32; overlap 1024 / 2048 / 3072 by tap count): hfreq4 = [4][1024]
+// complex, plane j = bins 4m + j of DFT_4096(taps) / 4096; twid [32][32] W_1024^(ab); tw2k [1024] W_2048^n; tw4k [2048] W_4096^n
+template <int O>
+static int ols4k_launch(const float *in, float *out, const float *hist, const float *hfreq4, const float *twid,
+                        const float *tw2k, const float *tw4k, int channels, int n, long in_pitch, long out_pitch, int flt_len,
+                        void *stream)
+{
+    constexpr int JOB = 2 * (4096 - O);
+    ols_geom G;
+    G.n = n;
+    G.keep = flt_len - 1;
+    G.in_pitch = in_pitch;
+    G.out_pitch = out_pitch;
+    G.jobs_per_channel = (n + JOB - 1) / JOB;
+    const size_t lds_bytes = 8 * 1024 * sizeof(float2) + (size_t)O4K_WAVES * 2 * OLS_XBUF * sizeof(float);
+    const long max_blocks = 256L;                               // one 8-wave workgroup per CU
+    const long slots = max_blocks * O4K_WAVES;
+    int seg_len = OLS_SEG;
+    if ((long)((G.jobs_per_channel + OLS_SEG - 1) / OLS_SEG) * channels < 4 * slots) {
+        double best = 1e300;
+        for (int sl = OLS_SEG; sl >= 1; sl--) {
+            const long segs = (long)((G.jobs_per_channel + sl - 1) / sl) * channels;
+            const double cost = (double)((segs + slots - 1) / slots) * sl;
+            if (cost < best * 0.999) { best = cost; seg_len = sl; }
+        }
+    }
+    G.seg_len = seg_len;
+    G.segs_per_channel = (G.jobs_per_channel + seg_len - 1) / seg_len;
+    G.total_segs = (long)G.segs_per_channel * channels;
+    long blocks = (G.total_segs + O4K_WAVES - 1) / O4K_WAVES;
+    if (blocks > max_blocks) blocks = max_blocks;
+    LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_ols4k_f32<O>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(k_fir_ols4k_f32<O>, dim3((unsigned)blocks), dim3(O4K_THREADS), lds_bytes, as_stream(stream), in, out, hist,
+                       reinterpret_cast<const float2 *>(hfreq4), reinterpret_cast<const float2 *>(twid),
+                       reinterpret_cast<const float2 *>(tw2k), reinterpret_cast<const float2 *>(tw4k), G);
+    LLZ_LAUNCH_CHECK("k_fir_ols4k_f32");
+    return LLZ_OK;
+}
+
+extern "C" int llzs_fir_ols4k_f32(const float *in, float *out, const float *hist, const float *hfreq4, const float *twid,
+                                  const float *tw2k, const float *tw4k, int channels, int n, long in_pitch, long out_pitch,
+                                  int flt_len, void *stream)
+{
+    if (!in || !out || !hfreq4 || !twid || !tw2k || !tw4k || channels <= 0 || n <= 0 || in_pitch < n || out_pitch < n ||
+        flt_len < 2 || flt_len > LLZS_OLS4K_MAX_TAPS) {
+        llzs_set_error("fir_ols4k_f32: bad arguments (flt_len=%d, 2..%d)", flt_len, LLZS_OLS4K_MAX_TAPS);
+        return LLZ_ERR_ARG;
+    }
+    if (flt_len <= 513)
+        return ols4k_launch<512>(in, out, hist, hfreq4, twid, tw2k, tw4k, channels, n, in_pitch, out_pitch, flt_len, stream);
+    if (flt_len <= 1025)
+        return ols4k_launch<1024>(in, out, hist, hfreq4, twid, tw2k, tw4k, channels, n, in_pitch, out_pitch, flt_len, stream);
+    if (flt_len <= 2049)
+        return ols4k_launch<2048>(in, out, hist, hfreq4, twid, tw2k, tw4k, channels, n, in_pitch, out_pitch, flt_len, stream);
+    return ols4k_launch<3072>(in, out, hist, hfreq4, twid, tw2k, tw4k, channels, n, in_pitch, out_pitch, flt_len, stream);
 }

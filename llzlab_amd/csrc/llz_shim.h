@@ -96,14 +96,12 @@ int llzs_fir_ols_f32(const float *in, float *out, const float *hist, const float
 int llzs_fir_ols2k_f32(const float *in, float *out, const float *hist, const float *hfreq2, const float *twid,
                        const float *tw2k, int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream);
 #define LLZS_OLS2K_MAX_TAPS 1025
-#define LLZS_OLS2_NFFT 2048
-#define LLZS_OLS2_MAX_TAPS 1025
-/* overlap-save with 4096-point transforms (one wave per transform, fft.hip) for up to 3073 taps: hperm [64][64] float2 = H[lane + 64 brev6(q)] / 4096; cs: device
- * table, 4096 cos then 4096 sin */
-int llzs_fir_ols4096_f32(const float *in, float *out, const float *hist, const float *hperm, const float *cs,
-                         int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream);
-#define LLZS_OLS4_NFFT 4096
-#define LLZS_OLS4_MAX_TAPS 3073
+/* 4096-point transforms on a whole wave (fir_ols.hip: radix-2 step + two 2048-point problems), 2..3073 taps (overlap 512 / 1024 / 2048 / 3072 by tap count): hfreq4 [4][1024]
+ * complex = bins 4m + j of DFT_4096(taps) / 4096; twid [32][32] W_1024^(ab); tw2k [1024] W_2048^n; tw4k [2048] W_4096^n */
+int llzs_fir_ols4k_f32(const float *in, float *out, const float *hist, const float *hfreq4, const float *twid,
+                       const float *tw2k, const float *tw4k, int channels, int n, long in_pitch, long out_pitch, int flt_len,
+                       void *stream);
+#define LLZS_OLS4K_MAX_TAPS 3073
 /* time domain on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), with optional decimation:
  * y[c][i] = gain * sum_{k<T} taps[k] * x[c][i*M - k], x[c][<0] = hist[c][T-1+idx] (hist NULL = zeros); n_out outputs
  * per channel from n_in inputs, (n_out-1)*M < n_in.  taps: T floats (no padding needed). */

@@ -149,8 +149,8 @@ def test_fir_mc_host_pointers_and_errors(dev, oracle):
     assert filters.FirFilterMC(2, 64, np.ones(257)).algo == filters.FIR_ALGO_OVERLAP_SAVE
     assert filters.FirFilterMC(2, 64, np.ones(63)).algo == filters.FIR_ALGO_OVERLAP_SAVE      # AUTO: 33..257 taps
     assert filters.FirFilterMC(2, 64, np.ones(32)).algo == filters.FIR_ALGO_TIME
-    assert filters.FirFilterMC(2, 64, np.ones(300)).algo == filters.FIR_ALGO_OVERLAP_SAVE_2048   # 258..1025
-    assert filters.FirFilterMC(2, 64, np.ones(2000)).algo == filters.FIR_ALGO_OVERLAP_SAVE_4096  # 1026..3073
+    assert filters.FirFilterMC(2, 64, np.ones(300)).algo == filters.FIR_ALGO_OVERLAP_SAVE_2048   # 258..513
+    assert filters.FirFilterMC(2, 64, np.ones(2000)).algo == filters.FIR_ALGO_OVERLAP_SAVE_4096  # 514..3073
     assert filters.FirFilterMC(2, 64, np.ones(300), algo=filters.FIR_ALGO_TIME_MFMA).algo == filters.FIR_ALGO_TIME_MFMA
 
 
@@ -905,17 +905,20 @@ def test_fir_ols2048_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
     full = oracle.fir_batch_f32(np.concatenate([x, np.zeros((channels, taps_n - 1), np.float32)], axis=1),
                                 taps.astype(np.float32).astype(np.float64))
     assert np.sqrt(np.mean((tail.cpu().numpy() - full[:, 2 * n:]) ** 2)) <= TOL
-    if 257 < taps_n <= 1025:
-        g = filters.FirFilterMC(channels, n, taps)                 # AUTO: 258..1025 taps
+    if 257 < taps_n <= 513:
+        g = filters.FirFilterMC(channels, n, taps)                 # AUTO: 258..513 taps
         assert g.algo == filters.FIR_ALGO_OVERLAP_SAVE_2048
         g.close()
 
 
 @pytest.mark.parametrize("taps_n,channels,n", [(1026, 3, 9000), (2049, 2, 2048 * 5 + 1), (3073, 2, 1024 * 9), (1500, 40, 1024 * 30 + 3),
-                                               (2, 3, 8192), (400, 5, 1000)])
+                                               (2, 3, 8192), (400, 5, 1000), (2049, 7, 4096 * 19 + 77), (2000, 300, 4096 * 3),
+                                               (2050, 3, 4096 * 4), (1025, 4, 6144 * 3 + 5), (700, 33, 6144 * 11), (513, 6, 7168 * 5 + 77),
+                                               (2600, 5, 2048 * 9 + 31), (3073, 130, 2048 * 6)])
 def test_fir_ols4096_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
-    """filters of up to 3073 taps on the 4096-point overlap-save (k_fir_ols4096_f32, a whole wave per pair of blocks): two
-    frames, ragged lengths, blocks that end past the frame, and the automatic choice beyond 1025 taps"""
+    """filters of up to 3073 taps on the 4096-point overlap-save (k_fir_ols4k_f32, a whole wave per pair of blocks; overlap
+    512 / 1024 / 2048 / 3072 by tap count): two frames, ragged lengths, blocks that end past the frame, and the automatic
+    choice beyond 513 taps"""
     taps = oracle.fir_design(po.LPF, taps_n, 0.2, 0.0, po.KAISER)
     x = oracle.synth_f32(channels, 2 * n, seed=taps_n)
     ref = oracle.fir_batch_f32(x, taps.astype(np.float32).astype(np.float64))
@@ -934,8 +937,8 @@ def test_fir_ols4096_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
     full = oracle.fir_batch_f32(np.concatenate([x, np.zeros((channels, taps_n - 1), np.float32)], axis=1),
                                 taps.astype(np.float32).astype(np.float64))
     assert np.sqrt(np.mean((tail.cpu().numpy() - full[:, 2 * n:]) ** 2)) <= TOL
-    if taps_n > 1025:
-        g = filters.FirFilterMC(channels, n, taps)                 # AUTO: 1026..3073 taps
+    if taps_n > 513:
+        g = filters.FirFilterMC(channels, n, taps)                 # AUTO: 514..3073 taps
         assert g.algo == filters.FIR_ALGO_OVERLAP_SAVE_4096
         g.close()
 
