@@ -98,10 +98,14 @@ __device__ __forceinline__ void bfly_dit(cf &a, cf &b, int q)
         g = __builtin_fmaf(t, B.x, B.y);
         f = c;
     } else {                                                    // cotangent form: w b = s [(r b.x - b.y) + j (r b.y + b.x)]
+        // p holds -(r b.x - b.y): a negated ADDEND needs the three-operand encoding with the constant in an SGPR, which
+        // issues at about 0.6 of the rate of the constant-in-the-instruction forms (tools/ubench/valu_rate.hip)
         const float r = c / s;
-        p = __builtin_fmaf(r, B.x, -B.y);
+        p = __builtin_fmaf(-r, B.x, B.y);
         g = __builtin_fmaf(r, B.y, B.x);
-        f = s;
+        a = cf{__builtin_fmaf(-s, p, A.x), __builtin_fmaf(s, g, A.y)};
+        b = cf{__builtin_fmaf(s, p, A.x), __builtin_fmaf(-s, g, A.y)};
+        return;
     }
     a = cf{__builtin_fmaf(f, p, A.x), __builtin_fmaf(f, g, A.y)};
     b = cf{__builtin_fmaf(-f, p, A.x), __builtin_fmaf(-f, g, A.y)};
