@@ -110,6 +110,8 @@ typedef struct {
     float *d_coef32, *d_pd32, *d_pl32;   /* float copies for the wave-autonomous float32 kernel: [S][5], [S][16], [S][64][12] */
     float *d_pd32w, *d_pl32w, *d_ph32w;   /* 32-sample-per-lane packed kernel: powers of A^32, ph [S][40] (b0 folded) */
     float in_gain32;     /* the product of the b0's (that kernel scales the input once) */
+    double *d_cw64, *d_pd64w, *d_pl64w;   /* the same form in double (k_iir_cascade_wave_pf64w): cw [S][8], pd [S][16], plc [S][448] */
+    double in_gain64;
     float *d_ph32;       /* [S][24]: (h1[k], h2[k]) k < 8 = zero-input outputs of the unit start states, b0 b1 b2 a1 a2, pad */
     double *d_state;     /* [channels][stages][x1,x2,y1,y2]: the current state */
     double *d_state_alt; /* where a time-segmented launch writes the frame's end state (then the two swap) */
@@ -126,6 +128,7 @@ static void iirm_destroy(iirm_t *f)
     llzs_free(f->d_coef); llzs_free(f->d_state); llzs_free(f->d_state_alt); llzs_free(f->d_pd); llzs_free(f->d_pl);
     llzs_free(f->d_coef32); llzs_free(f->d_pd32); llzs_free(f->d_pl32); llzs_free(f->d_ph32);
     llzs_free(f->d_pd32w); llzs_free(f->d_pl32w); llzs_free(f->d_ph32w);
+    llzs_free(f->d_cw64); llzs_free(f->d_pd64w); llzs_free(f->d_pl64w);
     llz_stage_release(&f->st_in); llz_stage_release(&f->st_out);
     f->tag = 0;
     free(f);
@@ -209,7 +212,7 @@ static int iirm_build_powers(iirm_t *f, const double *c5, int lane_run)
 /* Tables of the packed float32 kernel with 32 samples per lane and the b0 gains folded out (k_iir_cascade_wave_pk32):
  * powers of P = A^32 for the lane scan, the homogeneous responses h1[k], h2[k] for k < 16, the section's b1/b0, b2/b0,
  * a1, a2, and the state scales xfac_s = prod_{t >= s} b0_t, yfac_s = prod_{t > s} b0_t.  Built only when every b0 is
- * usable as a divisor (no zero gain, partial products between 1e-6 and 1e6); otherwise the 16-sample kernel runs. */
+ * usable as a divisor (no zero gain, partial products between 1e-20 and 1e20); otherwise the 16-sample kernel runs. */
 static int iirm_build_run32(iirm_t *f, const double *c5)
 {
     const int S = f->stages;
@@ -219,7 +222,9 @@ static int iirm_build_run32(iirm_t *f, const double *c5)
     for (int s = S - 1; s >= 0; s--) {
         const double b0 = c5[5 * s];
         xfac[s] = xfac[s + 1] * b0;
-        if (!(fabs(b0) > 1e-6) || !(fabs(xfac[s]) > 1e-6 && fabs(xfac[s]) < 1e6) ||
+        /* (the scaled states and the scaled input must stay clear of the float32 denormals: signals down to 1e-10 of full
+         *  scale times a partial product of 1e-20 are still 1e-30) */
+        if (!(fabs(b0) > 1e-12) || !(fabs(xfac[s]) > 1e-20 && fabs(xfac[s]) < 1e20) ||
             !(fabs(c5[5 * s + 1] / b0) < 1e4) || !(fabs(c5[5 * s + 2] / b0) < 1e4)) return LLZ_OK;
     }
     float *t = (float *)calloc((size_t)S * (16 + 768 + 40), sizeof(float));
@@ -267,6 +272,55 @@ static int iirm_build_run32(iirm_t *f, const double *c5)
     if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_pd32w, pd, sizeof(float) * 16 * (size_t)S);
     if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_pl32w, pl, sizeof(float) * 768 * (size_t)S);
     if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_ph32w, ph, sizeof(float) * 40 * (size_t)S);
+    free(t);
+    return rc;
+}
+
+/* Tables of the double kernel with 32 samples per lane and the b0 gains folded out (k_iir_cascade_wave_pf64w), for the
+ * cascades float32 arithmetic is not good enough for: cw [S][8] = b1/b0, b2/b0, a1, a2, xfac_s, xfac_(s+1), 0, 0 with
+ * xfac_s = prod_{t >= s} b0_t; pd [S][16] = P^(2^d), d < 4, P = A^32; plc [S][448] = P^lane for 64 lanes, P^(i+1) for
+ * i < 16, P^(i+1) for i < 32 (2 x 2, row major).  The b0.s must be usable as divisors (partial products 1e-150..1e150). */
+static int iirm_build_run32d(iirm_t *f, const double *c5)
+{
+    const int S = f->stages;
+    if (S > 8 || f->float32_ok) return LLZ_OK;
+    double xfac[9];
+    xfac[S] = 1.0;
+    for (int s = S - 1; s >= 0; s--) {
+        const double b0 = c5[5 * s];
+        xfac[s] = xfac[s + 1] * b0;
+        if (!(fabs(b0) > 1e-30) || !(fabs(xfac[s]) > 1e-150 && fabs(xfac[s]) < 1e150) ||
+            !(fabs(c5[5 * s + 1] / b0) < 1e6) || !(fabs(c5[5 * s + 2] / b0) < 1e6)) return LLZ_OK;
+    }
+    double *t = (double *)calloc((size_t)S * (8 + 16 + 448), sizeof(double));
+    if (!t) return LLZ_ERR_NOMEM;
+    double *cw = t, *pd = t + 8 * S, *pl = pd + 16 * S;
+    for (int s = 0; s < S; s++) {
+        const double b0 = c5[5 * s], a1 = c5[5 * s + 3], a2 = c5[5 * s + 4];
+        const double A[4] = {-a1, -a2, 1.0, 0.0};
+        double P[4] = {1.0, 0.0, 0.0, 1.0};
+        for (int i = 0; i < 32; i++) mat2_mul(A, P, P);
+        memcpy(pd + 16 * s, P, sizeof(P));
+        for (int d = 1; d < 4; d++) mat2_mul(pd + 16 * s + 4 * (d - 1), pd + 16 * s + 4 * (d - 1), pd + 16 * s + 4 * d);
+        double pw[65][4];
+        pw[0][0] = 1.0; pw[0][1] = 0.0; pw[0][2] = 0.0; pw[0][3] = 1.0;
+        for (int k = 1; k <= 64; k++) mat2_mul(P, pw[k - 1], pw[k]);
+        double *l = pl + (size_t)s * 448;
+        for (int lane = 0; lane < 64; lane++) memcpy(l + 4 * lane, pw[lane], sizeof(pw[0]));
+        for (int i = 0; i < 16; i++) memcpy(l + 256 + 4 * i, pw[i + 1], sizeof(pw[0]));
+        for (int i = 0; i < 32; i++) memcpy(l + 320 + 4 * i, pw[i + 1], sizeof(pw[0]));
+        cw[8 * s + 0] = c5[5 * s + 1] / b0; cw[8 * s + 1] = c5[5 * s + 2] / b0;
+        cw[8 * s + 2] = a1; cw[8 * s + 3] = a2;
+        cw[8 * s + 4] = xfac[s]; cw[8 * s + 5] = xfac[s + 1];
+    }
+    f->in_gain64 = xfac[0];
+    f->d_cw64 = (double *)llzs_malloc(sizeof(double) * 8 * (size_t)S);
+    f->d_pd64w = (double *)llzs_malloc(sizeof(double) * 16 * (size_t)S);
+    f->d_pl64w = (double *)llzs_malloc(sizeof(double) * 448 * (size_t)S);
+    int rc = (f->d_cw64 && f->d_pd64w && f->d_pl64w) ? LLZ_OK : LLZ_ERR_NOMEM;
+    if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_cw64, cw, sizeof(double) * 8 * (size_t)S);
+    if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_pd64w, pd, sizeof(double) * 16 * (size_t)S);
+    if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_pl64w, pl, sizeof(double) * 448 * (size_t)S);
     free(t);
     return rc;
 }
@@ -363,6 +417,7 @@ unsigned long llz_iir_cascade_mc_init(int channels, int stages, const double *co
     if (rc == LLZ_OK) f->float32_ok = iirm_float32_ok(c5, stages) && llzs_tune(LLZS_TUNE_IIR_F64) != 1;
     if (rc == LLZ_OK) rc = iirm_build_powers(f, c5, 16);
     if (rc == LLZ_OK && llzs_tune(LLZS_TUNE_IIR_UNPACKED) < 1) rc = iirm_build_run32(f, c5);
+    if (rc == LLZ_OK && llzs_tune(LLZS_TUNE_IIR_UNPACKED) < 1) rc = iirm_build_run32d(f, c5);
     if (rc == LLZ_OK) f->warm_chunks = iirm_memory_chunks(c5, stages);
     if (rc == LLZ_OK) rc = llzs_sync(NULL);
     free(c5);
@@ -440,13 +495,24 @@ static int iirm_process(iirm_t *f, const float *x, float *y, int frame_len)
     const int min_items = llzs_tune(LLZS_TUNE_IIR_WAVE_MIN_ITEMS) >= 0 ? llzs_tune(LLZS_TUNE_IIR_WAVE_MIN_ITEMS) : 2048;
     const int wave_form = f->stages <= 8 && seg_items >= min_items && llzs_tune(LLZS_TUNE_IIR_PIPE) != 1 &&
                           (!f->float32_ok || f->d_pl32);
-    /* packed float32 form with 32 samples per lane on the whole 2048-sample chunks, the 16-sample forms on what is left of
+    /* packed float32 form (or, for cascades that need it, the double form) with 32 samples per lane on the whole
+     * 2048-sample chunks, the 16-sample forms on what is left of
      * the 1024-sample chunks; every launch reads d_state and writes d_state_alt, which then swap */
     int done = 0;
     if (rc == LLZ_OK && wave_form && f->float32_ok && f->d_ph32w && n_fast >= 2048) {
         const int n32 = n_fast - n_fast % 2048;
         rc = llzs_iir_cascade_wave32_f32(d_in, d_out, f->d_pd32w, f->d_pl32w, f->d_ph32w, f->d_state, f->d_state_alt,
                                          f->channels, n32, frame_len, frame_len, f->stages, f->warm_chunks, f->in_gain32,
+                                         f->stream);
+        if (rc == LLZ_OK) {
+            double *t = f->d_state; f->d_state = f->d_state_alt; f->d_state_alt = t;
+            done = n32;
+        }
+    }
+    if (rc == LLZ_OK && wave_form && !f->float32_ok && f->d_cw64 && n_fast >= 2048) {
+        const int n32 = n_fast - n_fast % 2048;
+        rc = llzs_iir_cascade_wave32_f64(d_in, d_out, f->d_cw64, f->d_pd64w, f->d_pl64w, f->d_state, f->d_state_alt,
+                                         f->channels, n32, frame_len, frame_len, f->stages, f->warm_chunks, f->in_gain64,
                                          f->stream);
         if (rc == LLZ_OK) {
             double *t = f->d_state; f->d_state = f->d_state_alt; f->d_state_alt = t;

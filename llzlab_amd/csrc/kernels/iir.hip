@@ -1056,6 +1056,185 @@ k_iir_cascade_wave_pf64(const float *__restrict__ in, float *__restrict__ out,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_iir_cascade_wave_pf64w: the double cascade with 32 samples per lane and the b0 gains folded out -- what
+// k_iir_cascade_wave_pk32 does for float32, without the packing (v_fma_f64 already is the two-slot instruction).  Per sample
+// and section: 2 (feed-forward, b' = b / b0) + 2 (zero-state recurrence, end state only) + 2 (recurrence from the true start
+// state) FMAs and 28 / 32 of the lane scan, against 3 + 2 + 2 and 28 / 16 in k_iir_cascade_wave_pf64: 6.9 instead of 8.75.
+// Register budget for two waves per SIMD: the run is 64 registers, so only the four coefficients are fetched a section
+// ahead (two SGPR sets); the scan's uniform powers (SGPRs) and the lane's powers (LDS, one compact copy per section as in
+// pk32) are requested when the section starts and first used ~130 FMAs later.
+// Tables: cw [S][8] = b1', b2', a1, a2, xfac, yfac, 0, 0;  pd [S][16] = P^(2^d), d < 4, P = A^32, row major;
+// plc [S][448] = P^lane (64 x 4), P^(i+1) i < 16, P^(i+1) i < 32.
+typedef double d8v __attribute__((ext_vector_type(8)));
+template <int S>
+__global__ void __launch_bounds__(256, 2)
+k_iir_cascade_wave_pf64w(const float *__restrict__ in, float *__restrict__ out, const double *__restrict__ cw,
+                         const double *__restrict__ pd, const double *__restrict__ plc,
+                         const double *__restrict__ state_in, double *__restrict__ state, int nchunks_total, long in_pitch,
+                         long out_pitch, int segs, int seg_chunks, int warm, long items, double in_gain)
+{
+    constexpr int RUN = 32, CHUNK = 64 * RUN;
+    __shared__ __attribute__((aligned(16))) double s_pl[S * 448];
+    __shared__ __attribute__((aligned(16))) float s_turn[4][CHUNK + CHUNK / 8];
+    for (int e = threadIdx.x; e < S * 448; e += 256) s_pl[e] = plc[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+    if (item >= items) return;
+    const int c = (int)(item / segs), seg = (int)(item - (long)c * segs);
+    const int skip = seg > 0 ? warm : 0;
+    const int chunk0 = seg * seg_chunks - skip;
+    const int nchunks = min(nchunks_total, (seg + 1) * seg_chunks) - chunk0;
+
+    double su1[S], su2[S], sy1[S], sy2[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        su1[s] = su2[s] = sy1[s] = sy2[s] = 0;
+        if (seg == 0) {
+            const double *st = state_in + ((size_t)c * S + s) * 4;
+            const double xf = cw[s * 8 + 4], yf = cw[s * 8 + 5];
+            su1[s] = st[0] * xf; su2[s] = st[1] * xf; sy1[s] = st[2] * yf; sy2[s] = st[3] * yf;
+        }
+    }
+    const float *row = in + (size_t)c * in_pitch + (size_t)chunk0 * CHUNK + 4 * lane;
+    float *orow = out + (size_t)c * out_pitch + (size_t)chunk0 * CHUNK + 4 * lane;
+    float *turn = s_turn[threadIdx.x >> 6];
+    float *t_lin = turn + 4 * lane + 4 * (lane >> 3);       // + 288 q: float 256 q + 4 lane at pitch 36 per 32
+    float *t_own = turn + 36 * lane;                        // + 4 j: the lane's own run
+    float4 pre[8];
+    if (nchunks > 0) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(row + 256 * q)); pre[q] = make_float4(t.x, t.y, t.z, t.w); }
+    }
+    d4v cA, cB;                     // b1', b2', a1, a2 of the current / next section
+    d8v pw0, pw1;                   // the current section's P^1, P^2 and P^4, P^8
+    d2v tl[6];                      // rows of P^lane, P^(lane%16+1), P^(lane%32+1)
+    double u[RUN];
+    u[0] = u[RUN - 1] = 0.0;
+#define LLZ_PFW_TIE asm volatile("" : "+v"(u[0]), "+v"(u[RUN - 1]))
+#define LLZ_PFW_FETCH_C(SEC, CX)                                                                                     \
+    {                                                                                                                \
+        asm volatile("s_load_dwordx8 %0, %1, %2" : "=&s"(CX) : "s"(cw), "n"((SEC) * 64) : "memory");                  \
+        LLZ_PFW_TIE;                                                                                                 \
+    }
+#define LLZ_PFW_FETCH_P(SEC)                                                                                         \
+    {                                                                                                                \
+        const double *ts = s_pl + (SEC) * 448;                                                                       \
+        tl[0] = *(lds_cv_d2v *)(ts + 4 * lane); tl[1] = *(lds_cv_d2v *)(ts + 4 * lane + 2);                          \
+        tl[2] = *(lds_cv_d2v *)(ts + 256 + 4 * (lane & 15)); tl[3] = *(lds_cv_d2v *)(ts + 256 + 4 * (lane & 15) + 2); \
+        tl[4] = *(lds_cv_d2v *)(ts + 320 + 4 * (lane & 31)); tl[5] = *(lds_cv_d2v *)(ts + 320 + 4 * (lane & 31) + 2); \
+        asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4"                                       \
+                     : "=&s"(pw0), "=&s"(pw1) : "s"(pd), "n"((SEC) * 128), "n"((SEC) * 128 + 64) : "memory");         \
+    }
+#define LLZ_PFW_WAIT(CX)                                                                                             \
+    {                                                                                                                \
+        LLZ_PFW_TIE;                                                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(CX));                                                             \
+    }
+    LLZ_PFW_FETCH_C(0, cA)
+    for (int chunk = 0; chunk < nchunks; chunk++) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) *reinterpret_cast<float4 *>(t_lin + 288 * q) = pre[q];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 8; q++) pre[q] = *reinterpret_cast<const float4 *>(t_own + 4 * q);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            u[4 * q] = in_gain * (double)pre[q].x; u[4 * q + 1] = in_gain * (double)pre[q].y;
+            u[4 * q + 2] = in_gain * (double)pre[q].z; u[4 * q + 3] = in_gain * (double)pre[q].w;
+        }
+        if (chunk + 1 < nchunks) {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                { const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(row + (size_t)(chunk + 1) * CHUNK + 256 * q)); pre[q] = make_float4(t.x, t.y, t.z, t.w); }
+        }
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            d4v &cc = (s & 1) ? cB : cA;
+            if ((s & 1) == 0) {
+                LLZ_PFW_WAIT(cA);
+                if (s + 1 < S) LLZ_PFW_FETCH_C(s + 1, cB)
+            } else {
+                LLZ_PFW_WAIT(cB);
+                LLZ_PFW_FETCH_C((s + 1 < S ? s + 1 : 0), cA)
+            }
+            LLZ_PFW_FETCH_P(s)
+            const double b1 = cc[0], b2 = cc[1], a1 = cc[2], a2 = cc[3];
+            double um1 = dpp_<DPP_WAVE_SHR1, 0xF>(u[RUN - 1]), um2 = dpp_<DPP_WAVE_SHR1, 0xF>(u[RUN - 2]);
+            if (lane == 0) { um1 = su1[s]; um2 = su2[s]; }
+            su1[s] = lane63_(u[RUN - 1]); su2[s] = lane63_(u[RUN - 2]);
+            double z1 = 0.0, z2 = 0.0;
+            {   // feed-forward part in place and, behind it, the run from the zero state (only its end state is kept)
+                double p1 = um1, p2 = um2;
+#pragma unroll
+                for (int k = 0; k < RUN; k++) {
+                    const double x = u[k];
+                    const double w = fma_(b2, p2, fma_(b1, p1, x));
+                    u[k] = w;
+                    p2 = p1; p1 = x;
+                    const double y = fma_(-a1, z1, fma_(-a2, z2, w));
+                    z2 = z1; z1 = y;
+                }
+            }
+            LLZ_PFW_TIE;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pw0), "+s"(pw1));     // the section's powers (requested ~130 FMAs ago)
+#define LLZ_SCAN_STEP(CTRL, MASK, M00, M01, M10, M11)                                                                \
+            {                                                                                                        \
+                const double q1 = dpp_<CTRL, MASK>(z1), q2 = dpp_<CTRL, MASK>(z2);                                   \
+                z1 = fma_(M00, q1, fma_(M01, q2, z1));                                                               \
+                z2 = fma_(M10, q1, fma_(M11, q2, z2));                                                               \
+            }
+            LLZ_SCAN_STEP(DPP_ROW_SHR + 1, 0xF, pw0[0], pw0[1], pw0[2], pw0[3])
+            LLZ_SCAN_STEP(DPP_ROW_SHR + 2, 0xF, pw0[4], pw0[5], pw0[6], pw0[7])
+            LLZ_SCAN_STEP(DPP_ROW_SHR + 4, 0xF, pw1[0], pw1[1], pw1[2], pw1[3])
+            LLZ_SCAN_STEP(DPP_ROW_SHR + 8, 0xF, pw1[4], pw1[5], pw1[6], pw1[7])
+            LLZ_SCAN_STEP(DPP_BCAST15, 0xA, tl[2].x, tl[2].y, tl[3].x, tl[3].y)
+            LLZ_SCAN_STEP(DPP_BCAST31, 0xC, tl[4].x, tl[4].y, tl[5].x, tl[5].y)
+#undef LLZ_SCAN_STEP
+            const double e1 = dpp_<DPP_WAVE_SHR1, 0xF>(z1), e2 = dpp_<DPP_WAVE_SHR1, 0xF>(z2);
+            double y1 = fma_(tl[0].x, sy1[s], fma_(tl[0].y, sy2[s], e1));
+            double y2 = fma_(tl[1].x, sy1[s], fma_(tl[1].y, sy2[s], e2));
+#pragma unroll
+            for (int k = 0; k < RUN; k++) {
+                const double y = fma_(-a1, y1, fma_(-a2, y2, u[k]));
+                u[k] = y;
+                y2 = y1; y1 = y;
+            }
+            sy1[s] = lane63_(y1); sy2[s] = lane63_(y2);
+            if ((s & 1) == 0 && s + 1 == S) LLZ_PFW_FETCH_C(0, cA)   // odd S: set A is free only now (once per chunk)
+        }
+        if (chunk >= skip) {
+            float *dst = orow + (size_t)chunk * CHUNK;
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                *reinterpret_cast<float4 *>(t_own + 4 * q) = make_float4((float)u[4 * q], (float)u[4 * q + 1], (float)u[4 * q + 2], (float)u[4 * q + 3]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const f4v v = *reinterpret_cast<const f4v *>(t_lin + 288 * q);
+                __builtin_nontemporal_store(v, reinterpret_cast<f4v *>(dst + 256 * q));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // read out before the next chunk is written in
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // nothing in flight when the wave ends
+#undef LLZ_PFW_FETCH_C
+#undef LLZ_PFW_FETCH_P
+#undef LLZ_PFW_TIE
+#undef LLZ_PFW_WAIT
+    if (lane == 0 && seg == segs - 1) {
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            double *st = state + ((size_t)c * S + s) * 4;
+            const double xf = cw[s * 8 + 4], yf = cw[s * 8 + 5];
+            st[0] = su1[s] / xf; st[1] = su2[s] / xf; st[2] = sy1[s] / yf; st[3] = sy2[s] / yf;
+        }
+    }
+}
+
 } // namespace
 
 extern "C" int llzs_iir_df1_f64(const double *in, double *out, const double *a, const double *b, double *xs,
@@ -1333,5 +1512,62 @@ extern "C" int llzs_iir_cascade_wave32_f32(const float *in, float *out, const fl
     }
 #undef LLZ_PK32_LAUNCH
     LLZ_LAUNCH_CHECK("k_iir_cascade_wave_pk32");
+    return LLZ_OK;
+}
+
+// the double cascade with 32 samples per lane and b0 folded out (k_iir_cascade_wave_pf64w): n a multiple of 2048, rows
+// 16-byte aligned, 1..8 sections; cw [S][8], pd [S][16], plc [S][448] as described at the kernel; in_gain = the product of
+// the b0's
+extern "C" int llzs_iir_cascade_wave32_f64(const float *in, float *out, const double *cw, const double *pd,
+                                           const double *plc, const double *state_in, double *state, int channels, int n,
+                                           long in_pitch, long out_pitch, int stages, int warm_chunks, double in_gain,
+                                           void *stream)
+{
+    if (!in || !out || !cw || !pd || !plc || !state || !state_in || state == state_in || channels <= 0 || n <= 0 ||
+        (n % 2048) || stages < 1 || stages > 8 || warm_chunks < 1 || in_pitch < n || out_pitch < n || (in_pitch & 3) ||
+        (out_pitch & 3) || (reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) {
+        llzs_set_error("iir_cascade_wave32_f64: bad arguments");
+        return LLZ_ERR_ARG;
+    }
+    static const void *const tab[8] = {
+        (const void *)k_iir_cascade_wave_pf64w<1>, (const void *)k_iir_cascade_wave_pf64w<2>, (const void *)k_iir_cascade_wave_pf64w<3>,
+        (const void *)k_iir_cascade_wave_pf64w<4>, (const void *)k_iir_cascade_wave_pf64w<5>, (const void *)k_iir_cascade_wave_pf64w<6>,
+        (const void *)k_iir_cascade_wave_pf64w<7>, (const void *)k_iir_cascade_wave_pf64w<8>};
+    const void *kfn = tab[stages - 1];
+    int blocks_per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kfn, 256, 0) != hipSuccess || blocks_per_cu < 1) {
+        (void)hipGetLastError();
+        blocks_per_cu = 2;
+    }
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+        (void)hipGetLastError();
+        cus = 256;
+    }
+    const long slots = 4L * blocks_per_cu * cus;
+    const int nchunks = n / 2048, warm = (warm_chunks + 1) / 2;
+    int segs = 1;
+    for (int rounds = 3; rounds >= 1; rounds--) {
+        segs = (int)((rounds * slots + channels / 2) / channels);
+        if (segs < 1) segs = 1;
+        if (segs > 64) segs = 64;
+        if (rounds == 1 || nchunks / segs >= 32) break;
+    }
+    while (segs > 1 && nchunks / segs < 8 * warm) segs--;
+    if (const int v = llzs_tune(LLZS_TUNE_IIR_SEGS); v >= 1 && v <= 64) segs = v;
+    const int seg_chunks = (nchunks + segs - 1) / segs;
+    segs = (nchunks + seg_chunks - 1) / seg_chunks;
+    const long items = (long)channels * segs;
+    const dim3 grid((unsigned)((items + 3) / 4));
+#define LLZ_PFW_LAUNCH(S)                                                                                            \
+    hipLaunchKernelGGL((k_iir_cascade_wave_pf64w<S>), grid, dim3(256), 0, as_stream(stream), in, out, cw, pd, plc,      \
+                       state_in, state, nchunks, in_pitch, out_pitch, segs, seg_chunks, warm, items, in_gain)
+    switch (stages) {
+    case 1: LLZ_PFW_LAUNCH(1); break; case 2: LLZ_PFW_LAUNCH(2); break; case 3: LLZ_PFW_LAUNCH(3); break;
+    case 4: LLZ_PFW_LAUNCH(4); break; case 5: LLZ_PFW_LAUNCH(5); break; case 6: LLZ_PFW_LAUNCH(6); break;
+    case 7: LLZ_PFW_LAUNCH(7); break; default: LLZ_PFW_LAUNCH(8); break;
+    }
+#undef LLZ_PFW_LAUNCH
+    LLZ_LAUNCH_CHECK("k_iir_cascade_wave_pf64w");
     return LLZ_OK;
 }

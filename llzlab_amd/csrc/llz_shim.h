@@ -157,6 +157,11 @@ int llzs_iir_cascade_wave_f32(const float *in, float *out, const float *coef32, 
 int llzs_iir_cascade_wave32_f32(const float *in, float *out, const float *pd32, const float *pl32, const float *ph32,
                                 const double *state_in, double *state_out, int channels, int n, long in_pitch,
                                 long out_pitch, int stages, int warm_chunks, float in_gain, void *stream);
+/* the same in double for cascades float32 arithmetic is not good enough for (k_iir_cascade_wave_pf64w): cw [S][8] = b1/b0,
+ * b2/b0, a1, a2, xfac, yfac, 0, 0; pd [S][16]; plc [S][448] (powers of A^32, see the kernel) */
+int llzs_iir_cascade_wave32_f64(const float *in, float *out, const double *cw, const double *pd, const double *plc,
+                                const double *state_in, double *state, int channels, int n, long in_pitch, long out_pitch,
+                                int stages, int warm_chunks, double in_gain, void *stream);
 /* the same in double from the pipelined kernel's tables; at most 8 sections */
 int llzs_iir_cascade_wave_f64(const float *in, float *out, const double *coef, const double *pd, const double *pl,
                               const double *state_in, double *state_out, int channels, int n, long in_pitch, long out_pitch, int stages,

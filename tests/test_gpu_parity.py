@@ -589,6 +589,38 @@ def test_iir_cascade_wave_distinct_sections(dev, oracle, stages):
         assert err <= TOL * max(1.0, scale) and err / scale <= TOL, (stages, channels, err, scale)
 
 
+@pytest.mark.parametrize("stages", [1, 3, 4, 7, 8])
+def test_iir_cascade_wave_double_distinct_sections(dev, oracle, stages):
+    """high-Q sections, every one different (radius, angle, zeros, gain): the double kernel with 32 samples per lane and the
+    b0 gains folded out (k_iir_cascade_wave_pf64w) fetches coefficients a section ahead into alternating register sets and
+    keeps its states scaled by the gains still to come; frames of whole 2048-sample chunks + one 1024-sample chunk + a ragged
+    tail (three kernels share the state), two calls, many channels and few (segments along time)"""
+    rows = []
+    for k in range(stages):
+        r, th = 0.99 - 0.004 * k, 0.25 + 0.31 * k
+        a1, a2 = -2 * r * np.cos(th), r * r
+        b = np.array([1.0, 0.3 - 0.2 * k, 0.1 * k]) * (1 + a1 + a2) * (0.7 + 0.2 * k)
+        rows.append(np.concatenate([b, [1.0, a1, a2]]))
+    coef = np.array(rows)
+    for channels, n in ((2048, 2048 * 40 + 1024 + 40), (24, 2048 * 600 + 1024)):
+        f = filters.IirCascadeMC(channels, coef)
+        assert f.precision == 64
+        sel = [0, channels // 2 + 1, channels - 1]
+        xs, ys = [], []
+        for call in range(2):
+            x = torch.empty(channels, n, dtype=torch.float32, device=dev)
+            filters.synth_f32(x, seed=170 + call + stages)
+            y = torch.empty_like(x)
+            f.filter(x, y)
+            xs.append(x[sel].cpu().numpy())
+            ys.append(y[sel].cpu().numpy())
+        f.close()
+        ref = oracle.iir_cascade_batch_f32(np.concatenate(xs, axis=1), coef)
+        got = np.concatenate(ys, axis=1).astype(np.float64)
+        err, scale = float(np.sqrt(np.mean((got - ref) ** 2))), float(np.sqrt(np.mean(ref ** 2)))
+        assert err <= TOL * max(1.0, scale) and err / scale <= TOL, (stages, channels, err, scale)
+
+
 def test_iir_cascade_few_channels_split_along_time(dev, oracle):
     """few channels and a long frame: the pipelined kernel splits each channel into time segments that start a measured
     warm-up early from the zero state (the cascade's memory, probed at init); the result must still match the sequential
