@@ -142,6 +142,160 @@ k_resample_mfma_f32(const float *__restrict__ in, float *__restrict__ out, const
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_resample_mfma_pt_f32: the same product with the roles turned round -- a wave owns a PHASE tile and keeps its A operands
+// (the tile's taps, KS registers) for the whole launch, and sweeps the period tiles of the spans its workgroup walks.  In
+// the form above every wave re-reads the whole tap table (40 KB at 147:160) through the vector memory path for each 16
+// periods, and load -> wait -> compute -> store run in sequence.  Here a workgroup = ceil(L / 16) waves (4..16; more phase
+// tiles than waves: the RELOAD instantiation, a wave takes several tiles in turn and re-reads A once per tile and span)
+// walking consecutive spans of 16 PT periods of one channel:
+//   1. a span's input is REQUESTED one span ahead into 16 registers per thread and written to the LDS image when its turn
+//      comes.  Image = one column per period holding the period's whole window (M + 4 KS samples: the first 4 KS samples of a
+//      period are stored a second time behind the previous period's M), column stride = 2 mod 32: a B operand is then
+//      column base + immediate offset -- one address register for the KS reads of a tile, all issued back to back;
+//   2. wave (tile t) x period tile p: KS LDS reads + KS MFMAs, D written to an LDS image of the OUTPUT in memory order
+//      (period-major rows of L floats, odd row stride: the 16 columns of a D write spread over the banks);
+//   3. the whole workgroup streams the output image out: 16 PT x L consecutive floats, one dword per lane (a wave
+//      instruction = 256 contiguous, 256-byte aligned bytes).
+// Measured by knocking phases out (147:160, 256 ch): moving the data alone 0.35 ms, the products alone 0.85 ms against 0.27 ms
+// of matrix-pipe busy time -- the pipe idles while a workgroup moves data, and two workgroups per CU do not interleave well
+// enough.  A form with specialised waves (10 multiplying + 6 data waves, one workgroup per CU, both images double-buffered,
+// one barrier per span) was built and measured at 1.57 ms against 0.90 ms for this one; it was dropped.
+struct rp_shape {
+    int L, M, Q, ntiles;
+    int pt;              // period tiles per span
+    int cstride;         // floats per column of the input image: M + 4 KS + pad, = 2 mod 32
+    int ostride;         // floats per row of the output image (L | 1)
+    int img;             // floats of the input image: 16 pt cstride
+    unsigned m_magic;    // ceil(2^32 / M)
+    unsigned l_magic;    // ceil(2^32 / L)
+    long spans;          // spans of a channel: ceil(periods / (16 pt))
+    int spans_per_wg;    // consecutive spans a workgroup walks
+};
+
+template <int KS, bool RELOAD>
+__global__ void __launch_bounds__(1024, KS <= 16 ? 5 : 4)
+k_resample_mfma_pt_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
+                       const float *__restrict__ atab /* [ntiles][KS][64] */, const int *__restrict__ c0tab /* [ntiles] */,
+                       long n_in, long n_out, long in_pitch, long out_pitch, rp_shape rp)
+{
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    const int tid = threadIdx.x, lane = tid & 63, waves = blockDim.x >> 6, threads = (int)blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const int c = blockIdx.y;
+    const int periods = 16 * rp.pt;
+    const int H = rp.Q - 1;
+    const int count = periods * rp.M + 4 * KS;                      // input samples a span touches (<= 16 per thread)
+    const float *row = in + (size_t)c * in_pitch;
+    const float *hrow = hist ? hist + (size_t)c * H : nullptr;
+    float *obase = out + (size_t)c * out_pitch;
+    float av[KS];
+    if (!RELOAD && wave < rp.ntiles) {
+        const float *ap = atab + ((size_t)wave * KS) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KS; s++) av[s] = ap[s * 64];
+    }
+    float v[16];
+    auto request = [&](long m0s) {
+        const long first = m0s * rp.M - H;                          // input index of span element 0
+        const float *bp = row + first;                              // wave-uniform: a load is base_j + lane offset
+        if (first >= 0 && first + count <= n_in) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const float *bj = bp + j * threads;
+                v[j] = 0.f;
+                if (j * threads + tid < count) v[j] = __builtin_nontemporal_load(&bj[tid]);
+            }
+        } else {
+            // the channel's first span (history in front) and its last (zeros behind): p in [lo, hi) is inside the frame
+            const int lo = first < 0 ? (int)-first : 0;
+            const long room = n_in - first;
+            const int hi = room < (long)count ? (int)(room < 0 ? 0 : room) : count;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int p = j * threads + tid;
+                v[j] = 0.f;
+                if (p >= lo && p < hi) v[j] = bp[p];
+                else if (p < lo && hrow && p >= lo - H) v[j] = hrow[H - lo + p];
+            }
+        }
+    };
+    float *oimg = xs + rp.img;
+    const int opad = rp.ostride - rp.L;
+    const long span0 = (long)blockIdx.x * rp.spans_per_wg;
+    const long span1 = min(span0 + rp.spans_per_wg, rp.spans);
+    if (span0 < span1) request(span0 * periods);
+    for (long sp = span0; sp < span1; sp++) {
+        const long m0 = sp * periods;
+        // (the previous span's products are done: every thread passed the barrier behind them)
+        // The image positions do not depend on the span; left to itself the compiler keeps all 32 of them (and their
+        // conditions) live across the whole walk and spills them -- recomputed per span from a value it cannot see through.
+        int tid_now = tid;
+        asm volatile("" : "+v"(tid_now));
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int p = j * threads + tid_now;
+            const int q = (int)__umulhi((unsigned)p, rp.m_magic), r = p - q * rp.M;
+            if (p < count) {
+                if (q < periods) xs[q * rp.cstride + r] = v[j];
+                if (r < 4 * KS && q > 0) xs[(q - 1) * rp.cstride + rp.M + r] = v[j];
+            }
+        }
+        if (sp + 1 < span1) request(m0 + periods);
+        __syncthreads();
+        for (int t = wave; t < rp.ntiles; t += waves) {
+            if (RELOAD) {
+                const float *ap = atab + ((size_t)t * KS) * 64 + lane;
+#pragma unroll
+                for (int s = 0; s < KS; s++) av[s] = ap[s * 64];
+            }
+            const float *bp = xs + n * rp.cstride + c0tab[t] + kq;   // + 16 p cstride + 4 s
+            const int f0 = 16 * t + 4 * kq;                          // the lane's first phase of the tile
+            float *op = oimg + n * rp.ostride + f0;                  // D[4 kq + j][n] = output (phase f0 + j, period 16 p + n)
+#pragma unroll 1
+            for (int p = 0; p < rp.pt; p++) {
+                float bv[KS];
+#pragma unroll
+                for (int s = 0; s < KS; s++) bv[s] = bp[4 * s];
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+                if (f0 + 3 < rp.L) { op[0] = acc[0]; op[1] = acc[1]; op[2] = acc[2]; op[3] = acc[3]; }
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) if (f0 + j < rp.L) op[j] = acc[j];
+                }
+                bp += 16 * rp.cstride;
+                op += 16 * rp.ostride;
+            }
+        }
+        __syncthreads();
+        // stream the output image out in memory order
+        float *orow = obase + m0 * rp.L;
+        const long left = n_out - m0 * rp.L;
+        const int total = (int)(left < (long)periods * rp.L ? left : (long)periods * rp.L);
+        // four outputs in flight per thread (an LDS read answered before the next is asked for costs its latency each time)
+        for (int e = tid; e < total; e += 4 * threads) {
+            float w[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int eu = e + u * threads;
+                const int r = (int)__umulhi((unsigned)eu, rp.l_magic);
+                w[u] = eu < total ? oimg[eu + opad * r] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int eu = e + u * threads;
+                if (eu < total) __builtin_nontemporal_store(w[u], &orow[eu]);
+            }
+        }
+        // (the next span's image is written by threads that have passed the barrier above: nobody reads xs any more; the
+        //  output image is next written after the next span's first barrier)
+    }
+}
+
 } // namespace
 
 extern "C" int llzs_resample_mfma_f32_ksteps(int L, int M, int Q)
@@ -165,11 +319,12 @@ static int rm_waves(int M)
     return w < 1 ? 1 : (w > RM_MAX_WAVES ? RM_MAX_WAVES : w);
 }
 
-static size_t rm_image_floats(int M, int Q, int waves, int kst)
+static size_t rm_image_floats_n(int M, int Q, int periods, int kst)
 {
-    const size_t span = (size_t)16 * waves * M + (Q - 1) + 4 * kst;
+    const size_t span = (size_t)periods * M + (Q - 1) + 4 * kst;
     return span + (size_t)rm_pad(M) * (span / M) + 8;
 }
+static size_t rm_image_floats(int M, int Q, int waves, int kst) { return rm_image_floats_n(M, Q, 16 * waves, kst); }
 
 extern "C" int llzs_resample_mfma_f32_table_steps(int L, int M, int Q)
 {
@@ -199,7 +354,63 @@ extern "C" int llzs_resample_mfma_f32(const float *in, float *out, const float *
         llzs_set_error("resample_mfma_f32: bad arguments (channels=%d L=%d M=%d Q=%d)", channels, L, M, Q);
         return LLZ_ERR_ARG;
     }
-    const int waves = rm_waves(M), kst = llzs_resample_mfma_f32_table_steps(L, M, Q);
+    const int kst = llzs_resample_mfma_f32_table_steps(L, M, Q);
+    if (llzs_tune(LLZS_TUNE_RS_MFMA_FORM) != 1) {
+        // a wave per phase tile (k_resample_mfma_pt_f32): the span is as many period tiles (at most 4) as keep the input and
+        // output images of a workgroup under ~78 KB (two workgroups share a CU) and its samples within 16 per thread
+        rp_shape rp;
+        rp.L = L; rp.M = M; rp.Q = Q;
+        rp.ntiles = (L + 15) / 16;
+        rp.ostride = L | 1;
+        rp.cstride = M + 4 * kst;
+        rp.cstride += ((2 - rp.cstride) % 32 + 32) % 32;
+        const int waves_min = rp.ntiles < 4 ? 4 : (rp.ntiles > 16 ? 16 : rp.ntiles);
+        int waves = waves_min, pt = 4;
+        size_t lds = 0;
+        bool ok = false;
+        for (; pt >= 1; pt--) {
+            rp.img = 16 * pt * rp.cstride;
+            lds = ((size_t)rp.img + (size_t)16 * pt * rp.ostride) * sizeof(float);
+            const long count = (long)16 * pt * M + 4 * kst;
+            waves = waves_min;
+            while (waves < 16 && count > 16L * 64 * waves) waves++;
+            ok = lds <= 78 * 1024 && count <= 16L * 64 * waves;
+            if (ok) break;
+        }
+        if (ok) {
+            rp.pt = pt;
+            rp.m_magic = (unsigned)((0x100000000ull + (unsigned)M - 1) / (unsigned)M);
+            rp.l_magic = (unsigned)((0x100000000ull + (unsigned)L - 1) / (unsigned)L);
+            const long periods = (n_out + L - 1) / L;
+            rp.spans = (periods + 16 * pt - 1) / (16 * pt);
+            // consecutive spans per workgroup: ~6 rounds of 512 resident workgroups over the launch, at least 4 spans where
+            // the channel has them (the first span of a walk waits for memory with nothing to do)
+            long spw = (rp.spans * channels) / (512 * 6);
+            if (spw < 4) spw = 4;
+            if (spw > rp.spans) spw = rp.spans;
+            rp.spans_per_wg = (int)spw;
+            const dim3 grid((unsigned)((rp.spans + spw - 1) / spw), (unsigned)channels), block(64 * waves);
+            const bool reload = rp.ntiles > waves;
+#define RP_GO2(K, R)                                                                                                 \
+    do {                                                                                                             \
+        if (lds > 64 * 1024)                                                                                         \
+            LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resample_mfma_pt_f32<K, R>),          \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
+        hipLaunchKernelGGL((k_resample_mfma_pt_f32<K, R>), grid, block, lds, as_stream(stream), in, out, hist, atab, \
+                           c0tab, n_in, n_out, in_pitch, out_pitch, rp);                                             \
+    } while (0)
+#define RP_GO(K) do { if (reload) RP_GO2(K, true); else RP_GO2(K, false); } while (0)
+            if (kst == 8) RP_GO(8);
+            else if (kst == 16) RP_GO(16);
+            else if (kst == 24) RP_GO(24);
+            else RP_GO(32);
+#undef RP_GO
+#undef RP_GO2
+            LLZ_LAUNCH_CHECK("k_resample_mfma_pt_f32");
+            return LLZ_OK;
+        }
+    }
+    const int waves = rm_waves(M);
     rm_shape sh;
     sh.L = L; sh.M = M; sh.Q = Q;
     sh.ntiles = (L + 15) / 16;

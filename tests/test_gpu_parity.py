@@ -379,6 +379,34 @@ def test_resample_mc_f32_small_ratios_streaming(dev, oracle, L, M):
     assert err <= TOL and err / float(np.sqrt(np.mean(ref ** 2))) <= 3e-5, (L, M, err)
 
 
+@pytest.mark.parametrize("form", ["phase-tile waves", "period-tile waves"])
+@pytest.mark.parametrize("L,M", [(147, 160), (160, 147), (441, 320), (320, 441), (20, 147)])
+def test_resample_mc_f32_matrix_core_streaming(dev, oracle, L, M, form):
+    """large L and M on the fp32 matrix cores (resample_mfma.hip): a wave per phase tile walking spans of periods (441 and 320
+    phases: more phase tiles than waves, taps reloaded per tile) and the first form with a wave per period tile; streamed in
+    calls of uneven length -- one period, a few spans, a length that ends inside a span -- so that the history in front of a
+    call, the walk's first and last span and the ragged tail are all in use; against the oracle on the whole signal"""
+    ch = 3
+    lens = [200 * M, M, 1037 * M, 49 * M]                               # a call takes whole periods of M inputs
+    x = oracle.synth_f32(ch, sum(lens), seed=L + M)
+    with capi.tuned(rs_mfma_form=1 if form == "period-tile waves" else -1):
+        r = filters.ResampleMC(ch, L, M, 1.0, po.BLACKMAN, filters.PCM_F32)
+        outs, o = [], 0
+        for n_in in lens:
+            n_out = r.out_len(n_in)
+            assert n_out == n_in // M * L
+            xd = torch.from_numpy(np.ascontiguousarray(x[:, o:o + n_in])).to(dev)
+            yd = torch.empty(ch, n_out, dtype=torch.float32, device=dev)
+            r.process(xd, yd)
+            outs.append(yd.cpu().numpy())
+            o += n_in
+        r.close()
+    got = np.concatenate(outs, axis=1).astype(np.float64)
+    ref = oracle.rs_batch_f32(x, L, M, 1.0, po.BLACKMAN)[:, :got.shape[1]]
+    err = float(np.sqrt(np.mean((got - ref) ** 2)))
+    assert err <= TOL and err / float(np.sqrt(np.mean(ref ** 2))) <= 3e-5, (L, M, form, err)
+
+
 def test_resample_mc_f32_integer_input_matches_int16_reference(dev, oracle):
     """integer-valued float input: trunc(clamp(float path)) equals the bit-exact int16 path except within ~1e-2
     of an integer boundary (float accumulate), SURVEY.md H3"""
