@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sweep the IIR cascade's time-segment count (LLZ_IIR_SEGS) on config 4's shape: python tools/iir_segs.py [channels] [n]"""
+"""Sweep the IIR cascade's time-segment count (llz_hip_tune("iir_segs", n)) on config 4's shape: python tools/iir_segs.py [channels] [n]"""
 import os
 import sys
 
@@ -25,8 +25,7 @@ if os.environ.get("HIGHQ"):
     row = [0.01, 0.0, -0.01, 1.0, -2 * 0.99 * np.cos(0.3), 0.99 ** 2]
 q = filters.IirCascadeMC(ch, np.tile(np.array(row), (8, 1)), stream=stream)
 for segs in [0] + [int(v) for v in os.environ.get("SEGS", "3,6,8,9,12,18,24,48,64").split(",") if int(v) > 0]:
-    if segs:
-        os.environ["LLZ_IIR_SEGS"] = str(segs)
+    capi.tune("iir_segs", segs if segs else -1)
     for _ in range(max(3, 40 * 1024 // ch)):                            # clocks settle over tens of milliseconds
         q.filter(x, y)
     torch.cuda.synchronize()
