@@ -482,6 +482,118 @@ k_acf2048_f32(const float *__restrict__ x, float *__restrict__ r, int frames, in
     }
 }
 
+// FFT autocorrelation for fft_len = 4096 (frames of 1025..2048 samples): the real-input scheme of k_acf2048_f32 one size up --
+// both 4096-point transforms are ONE 2048-point complex transform each, and that transform runs on a WHOLE WAVE as in
+// fir_ols.hip (k_fir_ols2k_chain_f32): one radix-2 step splits it over the two half-waves, each of which runs the 1024-point
+// machinery.  z[m] = x[2m] + j x[2m+1], m < 2048, and the frame is at most 2048 samples, so z[m] = 0 for m >= 1024:
+//   forward (decimation in frequency):  Z[2k']   = FFT_1024( z[m] )            -> lower half-wave
+//                                       Z[2k'+1] = FFT_1024( z[m] W_2048^m )   -> upper half-wave          (m < 1024)
+//   a bin's mirror Z[2048 - k] has the parity of k, so it sits in the SAME half-wave: index (1024 - k') mod 1024 among the
+//   even bins, 1023 - k' among the odd ones -- one LDS round trip per plane, as in k_acf2048_f32;
+//   X[k] = Xe + W_4096^k Xo, power, symmetric spectrum and G[k] as there (4096 for 2048, 2048 for 1024);
+//   inverse (decimation in time):  g[m], g[m + 1024] = S'[m] +- W_2048^-m D'[m],  S' / D' = IFFT_1024 of G's even / odd bins;
+//   r[2m] = Re g[m], r[2m + 1] = Im g[m].
+// Lane (half h, l5) owns the rows of parity h of the 64 x 32 sample block (row 2p + h, p < 32) at column l5: rows p and p + 16
+// are 1024 samples apart, so the butterflies of both radix-2 steps are in-lane and one v_permlane32_swap per register pair
+// sorts sums / differences to the lower / upper half-wave.
+__global__ void __launch_bounds__(256, 2)
+k_acf4096_f32(const float *__restrict__ x, float *__restrict__ r, int frames, int n, int p,
+              const float *__restrict__ cs /* 4096 cos, then 4096 sin of 2 pi i / 4096 */)
+{
+    __shared__ float2 s_tw[1024];                                  // W_1024^(a*b), [a][b]
+    __shared__ float2 s_w2[1024];                                  // W_2048^m, m < 1024
+    __shared__ float2 s_w4[2048];                                  // W_4096^k, k < 2048
+    __shared__ float bufs[8][OLS_XBUF];
+    const int tid = threadIdx.x, l5 = tid & 31, half = (tid >> 5) & 1;
+    for (int i = tid; i < 1024; i += 256) {
+        const int m = (4 * (i >> 5) * (i & 31)) & 4095;
+        s_tw[i] = make_float2(cs[m], -cs[4096 + m]);
+        s_w2[i] = make_float2(cs[2 * i], -cs[4096 + 2 * i]);
+        s_w4[i] = make_float2(cs[i], -cs[4096 + i]);
+        s_w4[1024 + i] = make_float2(cs[1024 + i], -cs[4096 + 1024 + i]);
+    }
+    __syncthreads();
+    const long t = (long)blockIdx.x * 4 + (tid >> 6);              // a wave per frame
+    if (t >= frames) return;
+    const float *g = x + t * n;
+    float *buf = bufs[tid >> 5];
+    const int rowoff = 32 * half + l5;
+    // ---- this lane's rows of z (m = 64 q + rowoff < 1024; the upper half of z is padding) and the radix-2 step down
+    cf w[32];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int i0 = 2 * (64 * q + rowoff);
+        cf sm = {i0 < n ? g[i0] : 0.f, i0 + 1 < n ? g[i0 + 1] : 0.f};
+        const float2 tw = s_w2[64 * q + rowoff];
+        cf df = cmul<false>(sm, cf{tw.x, tw.y});
+        swap32(sm.x, df.x);
+        swap32(sm.y, df.y);
+        w[2 * q] = sm;                                             // lower: z rows 2q, 2q+1; upper: the twiddled copies
+        w[2 * q + 1] = df;
+    }
+    fft32<false>(w);
+    transpose_twiddle<false>(w, buf, s_tw, l5);
+    fft32<false>(w);                                               // w[q] = Z[2 k' + half], k' = l5 + 32 brev5(q)
+    // ---- mirrored bins: even bins k' -> (1024 - k') mod 1024: lane (32 - l5) & 31, column 31 - j (lane 0: (32 - j) & 31);
+    //      odd bins k' -> 1023 - k': lane 31 - l5, column 31 - j
+    const int lm = half ? 31 - l5 : (32 - l5) & 31;
+    const bool wrap = !half && l5 == 0;
+    float mx[32];
+#pragma unroll
+    for (int q = 0; q < 32; q++) buf[xaddr(brev5(q), l5)] = w[q].x;
+    OLS_WAVE_SYNC();
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+        const int j = brev5(q);
+        mx[q] = buf[wrap ? xaddr((32 - j) & 31, 0) : xaddr(31 - j, lm)];
+    }
+    OLS_WAVE_SYNC();
+#pragma unroll
+    for (int q = 0; q < 32; q++) buf[xaddr(brev5(q), l5)] = w[q].y;
+    OLS_WAVE_SYNC();
+    const float sc = 1.0f / (4.0f * 4096.0f);                      // the two halvings of (Xe, Xo) and llz_ifft's 1/N
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+        const int j = brev5(q);
+        const int k = 2 * (l5 + 32 * j) + half;                    // this lane's bin, k < 2048
+        const float my = buf[wrap ? xaddr((32 - j) & 31, 0) : xaddr(31 - j, lm)];
+        const float2 tw = s_w4[k];                                 // (cos, -sin) of 2 pi k / 4096
+        const cf xe = {w[q].x + mx[q], w[q].y - my};               // 2 Xe
+        const cf xo = {w[q].y + my, mx[q] - w[q].x};               // 2 Xo
+        const cf T = cmul<false>(xo, cf{tw.x, tw.y});
+        const cf a = cadd(xe, T), b = csub(xe, T);
+        float sk = __builtin_fmaf(a.x, a.x, a.y * a.y) * sc, sm = __builtin_fmaf(b.x, b.x, b.y * b.y) * sc;
+        if (k >= n) sk = 0.f;
+        if (2048 - k >= n) sm = 0.f;
+        if (k == 0) { sk *= 2.f; sm = 0.f; }                       // S[0] = 2 P[0]; the mirror of bin 0 is bin 2048: unused
+        const float dk = sk - sm;
+        w[q] = cf{__builtin_fmaf(tw.y, dk, sk + sm), tw.x * dk};   // (S + Sm) + j conj(W^k) dk
+    }
+    OLS_WAVE_SYNC();
+    // ---- inverse transforms of the even / odd bins, then the radix-2 step up
+    cf u[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) u[j] = w[brev5(j)];               // bin order -> natural order: register renaming
+    fft32<true>(u);
+    transpose_twiddle<true>(u, buf, s_tw, l5);
+    fft32<true>(u);                                                // u[q] = S' / D' [32 brev5(q) + l5]
+    float *rr = r + t * (p + 1);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        cf P = u[brev5(2 * q)], Q = u[brev5(2 * q + 1)];
+        swap32(P.x, Q.x);
+        swap32(P.y, Q.y);                                          // lane (half, l5): P = S', Q = D' at m = 64 q + rowoff
+        const float2 tw = s_w2[64 * q + rowoff];
+        Q = cmul<true>(Q, cf{tw.x, tw.y});
+        const cf lo = cadd(P, Q), hi = csub(P, Q);
+        const int m = 64 * q + rowoff;
+        if (2 * m <= p) rr[2 * m] = lo.x;
+        if (2 * m + 1 <= p) rr[2 * m + 1] = lo.y;
+        if (2 * (m + 1024) <= p) rr[2 * (m + 1024)] = hi.x;
+        if (2 * (m + 1024) + 1 <= p) rr[2 * (m + 1024) + 1] = hi.y;
+    }
+}
+
 // FFT autocorrelation for fft_len = 1024 (frames of 257..512 samples): the two transforms of llz_corr.c:155-177 as they
 // stand (complex, zero imaginary parts) on the half-wave machinery -- twice the arithmetic of the real-input form above,
 // but a half size of 512 = 2 x 16^2 has no single-group register transform with the mirrored bins in reach, and even so
@@ -1587,6 +1699,12 @@ extern "C" int llzs_acf_fused_f32(const float *x, float *r, int frames, int n, i
         hipLaunchKernelGGL(k_acf2048_f32, dim3((unsigned)((frames + 7) / 8)), dim3(256), 0, as_stream(stream), x, r,
                            frames, n, p, cs);
         LLZ_LAUNCH_CHECK("k_acf2048_f32");
+        return LLZ_OK;
+    }
+    if (size == 4096 && llzs_tune(LLZS_TUNE_FFT_GENERIC) < 1) {              // one complex 2048-point transform on a whole wave
+        hipLaunchKernelGGL(k_acf4096_f32, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, as_stream(stream), x, r,
+                           frames, n, p, cs);
+        LLZ_LAUNCH_CHECK("k_acf4096_f32");
         return LLZ_OK;
     }
     const int passes = (log2n + 3) / 4;

@@ -175,4 +175,13 @@ __device__ __forceinline__ void transpose_twiddle(cf (&v)[32], float *buf, const
     transpose_twiddle<INV>(v, buf, tw, l5, l5);
 }
 
+// x's upper half-wave <-> y's lower half-wave (the radix-2 step that splits a transform over the two half-waves of a wave:
+// fir_ols.hip k_fir_ols2k_chain_f32, fft.hip k_acf4096_f32)
+__device__ __forceinline__ void swap32(float &x, float &y)
+{
+    const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(p[0]);
+    y = __uint_as_float(p[1]);
+}
+
 } // namespace

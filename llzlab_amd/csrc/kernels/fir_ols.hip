@@ -307,13 +307,6 @@ k_fir_ols_chain_f32(const float *__restrict__ in, float *__restrict__ out, const
 // Template parameter O = the overlap: 512 samples (16 rows, up to 513 taps, 1536 new samples per block) or 1024 (32 rows,
 // up to 1025 taps, 1024 new samples per block).
 
-__device__ __forceinline__ void swap32(float &x, float &y)          // x's upper half-wave <-> y's lower half-wave
-{
-    const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-    x = __uint_as_float(p[0]);
-    y = __uint_as_float(p[1]);
-}
-
 template <int O>
 __global__ void __launch_bounds__(OLS_THREADS, 2)
 k_fir_ols2k_chain_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,

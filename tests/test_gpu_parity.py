@@ -728,7 +728,11 @@ def test_autocorr_mc_direct_vs_oracle(dev, oracle, frames, n, p):
                                         # fft_len 128 and 512 on the E = 8 / 16 lane groups (k_acf_sq_f32)
                                         (50, 64, 20), (40, 200, 33), (300, 256, 16), (9, 130, 255), (5, 33, 3), (70, 255, 500),
                                         # fft_len 1024 (k_acf1024_f32): pruned (p < 32) and full inverse
-                                        (100, 512, 16), (13, 300, 31), (6, 257, 32), (9, 480, 1000)])
+                                        (100, 512, 16), (13, 300, 31), (6, 257, 32), (9, 480, 1000),
+                                        # fft_len 4096 = one complex 2048-point transform on a whole wave (k_acf4096_f32): odd
+                                        # and even lengths, lags into the second half of the inverse, a partial last workgroup
+                                        (5, 1025, 16), (9, 2000, 63), (4, 1500, 64), (3, 2047, 3000), (130, 1800, 4095),
+                                        (2, 2048, 2049), (6, 1026, 0)])
 def test_autocorr_fast_mc_vs_oracle(dev, oracle, frames, n, p):
     if frames > 1000:
         x = np.tile(oracle.synth_f32(8, n, seed=3), (frames // 8, 1))

@@ -133,7 +133,8 @@ if "fft" in which:
         del z, q
 
 if "corr" in which:
-    for (frames, n, p) in ((1 << 18, 1024, 16), (1 << 18, 1024, 64), (1 << 19, 512, 16), (1 << 20, 256, 16), (4096, 1 << 18, 32)):
+    for (frames, n, p) in ((1 << 18, 1024, 16), (1 << 18, 1024, 64), (1 << 19, 512, 16), (1 << 20, 256, 16), (1 << 17, 2048, 16),
+                           (1 << 17, 2048, 255), (4096, 1 << 18, 32)):
         x = torch.rand(frames, n, dtype=torch.float32, device=dev) * 2 - 1
         r = torch.empty(frames, p + 1, dtype=torch.float32, device=dev)
         ms = timeit(lambda: filters.autocorr_mc(x, r, p, stream=stream), 3)
@@ -144,6 +145,10 @@ if "corr" in which:
             ms = timeit(lambda: f.run(x, r, p), 3)
             gb = 4.0 * frames * n / ms / 1e6
             print(f"autocorr fft    {frames} x {n}, p={p}: {ms:.3f} ms  {frames * n / ms / 1e3:.0f} Msamples/s  {gb:.0f} GB/s ({gb / 80:.1f} %)")
+            if n == 2048:
+                with capi.tuned(fft_generic=1):
+                    ms = timeit(lambda: f.run(x, r, p), 3)
+                print(f"autocorr fft    {frames} x {n}, p={p} (staged passes): {ms:.3f} ms")
             f.close()
         del x, r
 
