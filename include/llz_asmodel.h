@@ -59,6 +59,18 @@ int           llz_stft_mc_set_stream(unsigned long handle, void *stream);
 int           llz_stft_mc_analysis(unsigned long handle, const float *x, float *re, float *im, int frames);
 int           llz_stft_mc_synthesis(unsigned long handle, const float *re, const float *im, float *x, int frames);
 
+/* Windowed MDCT frames with 50 % overlap in batch: the float32 multi-channel form of llz_analysis_mdct / llz_synthesis_mdct
+ * above (reference llz_asmodel.c:313-463: MDCT_FFT4 of length 2*frame_len on w[i]*xbuf[i]; synthesis w[i]*imdct[i] overlap-
+ * added).  One handle serves both directions and keeps per channel the previous input frame (analysis) and the overlap-add
+ * tail (synthesis), so consecutive calls continue the streams; analysis followed by synthesis returns the input delayed by
+ * one frame.  frame_len a power of two in 128..4096.  x: planar [channels][frames*frame_len]; X: [channels][frames]
+ * [frame_len].  Pointers may be device or host memory (x and X distinct).  Return frames or < 0. */
+unsigned long llz_mdct_frames_mc_init(int channels, int frame_len, mdct_win_t win_type);
+void          llz_mdct_frames_mc_uninit(unsigned long handle);
+int           llz_mdct_frames_mc_set_stream(unsigned long handle, void *stream);
+int           llz_mdct_frames_mc_analysis(unsigned long handle, const float *x, float *X, int frames);
+int           llz_mdct_frames_mc_synthesis(unsigned long handle, const float *X, float *x, int frames);
+
 #ifdef __cplusplus
 }
 #endif

@@ -396,3 +396,137 @@ int llz_stft_mc_synthesis(unsigned long handle, const float *re, const float *im
     if (rc == LLZ_OK && dx != x) rc = llzs_d2h(x, dx, sizeof(float) * (size_t)f->channels * n, f->stream);
     return rc == LLZ_OK ? frames : rc;
 }
+
+/* ---- Part 2b: windowed MDCT frames (time-domain alias cancellation) in batch, float32 ---- */
+/* The batch form of llz_analysis_mdct / llz_synthesis_mdct (llz_asmodel.c:313-463): per channel, analysis keeps the previous
+ * frame and synthesis the overlap-add tail, so consecutive calls continue the streams.  On the register MDCT kernels
+ * (k_mdct_reg_f32<..., FRAMES>): the window is applied as the transform reads / writes, frames are taken straight from the
+ * planar signal at a hop of frame_len (nothing is expanded in memory). */
+#define LLZ_TAG_AMDM 0x4c5a4d4d
+
+typedef struct {
+    int tag, channels, frame_len, mdct_len;
+    float *d_w, *d_tc, *d_ts, *d_cs;
+    float *d_prev[2], *d_tail[2];       /* analysis: the previous frame; synthesis: the overlap-add tail; [channels][frame_len] */
+    int cur_prev, cur_tail;
+    llz_stage_t st_x, st_X;
+    void *stream;
+} amdm_t;
+
+static void amdm_destroy(amdm_t *f)
+{
+    if (!f) return;
+    llzs_free(f->d_w); llzs_free(f->d_tc); llzs_free(f->d_ts); llzs_free(f->d_cs);
+    llzs_free(f->d_prev[0]); llzs_free(f->d_prev[1]); llzs_free(f->d_tail[0]); llzs_free(f->d_tail[1]);
+    llz_stage_release(&f->st_x); llz_stage_release(&f->st_X);
+    f->tag = 0;
+    free(f);
+}
+
+unsigned long llz_mdct_frames_mc_init(int channels, int frame_len, mdct_win_t win_type)
+{
+    if (channels < 1 || frame_len < 128 || frame_len > 4096 || (frame_len & (frame_len - 1)) ||
+        (win_type != MDCT_SINE && win_type != MDCT_KBD)) {
+        llzs_set_error("llz_mdct_frames_mc_init: channels %d frame_len %d (a power of two in 128..4096) window %d",
+                       channels, frame_len, (int)win_type);
+        return LLZ_BAD_HANDLE;
+    }
+    const int N = frame_len << 1, N4 = N >> 2;
+    amdm_t *f = (amdm_t *)calloc(1, sizeof(*f));
+    double *w = (double *)malloc(sizeof(double) * (size_t)N);
+    float *tab = (float *)malloc(sizeof(float) * ((size_t)N + 4 * (size_t)N4));
+    int rc = (f && w && tab) ? LLZ_OK : LLZ_ERR_NOMEM;
+    if (rc == LLZ_OK) {
+        f->tag = LLZ_TAG_AMDM; f->channels = channels; f->frame_len = frame_len; f->mdct_len = N;
+        if (win_type == MDCT_SINE) llz_mdct_sine(w, N); else llz_mdct_kbd(w, N, 6);     /* llz_asmodel.c:327-334 */
+        float *tw = tab + N;
+        for (int i = 0; i < N; i++) tab[i] = (float)w[i];
+        for (int k = 0; k < N4; k++) {
+            tw[k] = (float)cos(-2 * M_PI * (k + 0.125) / N);              /* llz_mdct.c:459-462 */
+            tw[N4 + k] = (float)sin(-2 * M_PI * (k + 0.125) / N);
+            const double ang = (double)(2 * M_PI * k) / N4;               /* llz_fft.c:222-229 for size N/4 */
+            tw[2 * N4 + k] = (float)cos(ang);
+            tw[3 * N4 + k] = (float)sin(ang);
+        }
+        const size_t keep = sizeof(float) * (size_t)channels * (size_t)frame_len;
+        f->d_w = (float *)llzs_malloc(sizeof(float) * (size_t)N);
+        f->d_tc = (float *)llzs_malloc(sizeof(float) * (size_t)N4);
+        f->d_ts = (float *)llzs_malloc(sizeof(float) * (size_t)N4);
+        f->d_cs = (float *)llzs_malloc(sizeof(float) * 2 * (size_t)N4);
+        for (int k = 0; k < 2; k++) {
+            f->d_prev[k] = (float *)llzs_malloc(keep);
+            f->d_tail[k] = (float *)llzs_malloc(keep);
+        }
+        if (!f->d_w || !f->d_tc || !f->d_ts || !f->d_cs || !f->d_prev[0] || !f->d_prev[1] || !f->d_tail[0] || !f->d_tail[1])
+            rc = LLZ_ERR_NOMEM;
+        if (rc == LLZ_OK) rc = llzs_h2d(f->d_w, tab, sizeof(float) * (size_t)N, NULL);
+        if (rc == LLZ_OK) rc = llzs_h2d(f->d_tc, tw, sizeof(float) * (size_t)N4, NULL);
+        if (rc == LLZ_OK) rc = llzs_h2d(f->d_ts, tw + N4, sizeof(float) * (size_t)N4, NULL);
+        if (rc == LLZ_OK) rc = llzs_h2d(f->d_cs, tw + 2 * N4, sizeof(float) * 2 * (size_t)N4, NULL);
+        for (int k = 0; k < 2 && rc == LLZ_OK; k++) {
+            rc = llzs_memset(f->d_prev[k], 0, keep, NULL);
+            if (rc == LLZ_OK) rc = llzs_memset(f->d_tail[k], 0, keep, NULL);
+        }
+        if (rc == LLZ_OK) rc = llzs_sync(NULL);
+    }
+    free(w); free(tab);
+    if (rc != LLZ_OK) {
+        if (f && f->tag) amdm_destroy(f); else free(f);
+        return LLZ_BAD_HANDLE;
+    }
+    return (unsigned long)f;
+}
+
+void llz_mdct_frames_mc_uninit(unsigned long handle)
+{
+    if (LLZ_HANDLE_OK(handle, amdm_t, LLZ_TAG_AMDM)) {
+        llzs_sync(((amdm_t *)handle)->stream);
+        amdm_destroy((amdm_t *)handle);
+    }
+}
+
+int llz_mdct_frames_mc_set_stream(unsigned long handle, void *stream)
+{
+    if (!LLZ_HANDLE_OK(handle, amdm_t, LLZ_TAG_AMDM)) return LLZ_ERR_ARG;
+    ((amdm_t *)handle)->stream = stream;
+    return LLZ_OK;
+}
+
+static int amdm_run(unsigned long handle, const float *in, float *out, int frames, int inverse, const char *who)
+{
+    if (!LLZ_HANDLE_OK(handle, amdm_t, LLZ_TAG_AMDM) || !in || !out || frames < 1 || in == out) {
+        llzs_set_error("%s: bad handle or arguments", who);
+        return LLZ_ERR_ARG;
+    }
+    amdm_t *f = (amdm_t *)handle;
+    const size_t bytes = sizeof(float) * (size_t)f->channels * (size_t)frames * (size_t)f->frame_len;   /* both sides */
+    const float *d_in = in;
+    float *d_out = out;
+    int rc = LLZ_OK;
+    if (!llzs_is_device_ptr(in)) {
+        d_in = (const float *)llz_stage_reserve(inverse ? &f->st_X : &f->st_x, bytes);
+        rc = d_in ? llzs_h2d((void *)d_in, in, bytes, f->stream) : LLZ_ERR_NOMEM;
+    }
+    if (rc == LLZ_OK && !llzs_is_device_ptr(out)) {
+        d_out = (float *)llz_stage_reserve(inverse ? &f->st_x : &f->st_X, bytes);
+        if (!d_out) rc = LLZ_ERR_NOMEM;
+    }
+    float **st = inverse ? f->d_tail : f->d_prev;
+    int *cur = inverse ? &f->cur_tail : &f->cur_prev;
+    if (rc == LLZ_OK)
+        rc = llzs_mdct4_frames_f32(d_in, d_out, f->channels, frames, f->mdct_len, f->d_tc, f->d_ts, f->d_cs, f->d_w, st[*cur],
+                                   st[*cur ^ 1], inverse, f->stream);
+    if (rc == LLZ_OK) *cur ^= 1;
+    if (rc == LLZ_OK && d_out != out) rc = llzs_d2h(out, d_out, bytes, f->stream);
+    return rc == LLZ_OK ? frames : rc;
+}
+
+int llz_mdct_frames_mc_analysis(unsigned long handle, const float *x, float *X, int frames)
+{
+    return amdm_run(handle, x, X, frames, 0, "llz_mdct_frames_mc_analysis");
+}
+
+int llz_mdct_frames_mc_synthesis(unsigned long handle, const float *X, float *x, int frames)
+{
+    return amdm_run(handle, X, x, frames, 1, "llz_mdct_frames_mc_synthesis");
+}

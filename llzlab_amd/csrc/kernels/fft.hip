@@ -1279,11 +1279,29 @@ k_acf_sq_f32(const float *__restrict__ x, float *__restrict__ r, int frames, int
 // tc/ts: cos and sin of -2 pi (k + 1/8) / N, k < N/4 (llz_mdct.c:459-462).  Both directions use the FORWARD transform.
 // (N = 8192 forward needs 300 VGPRs: two waves per SIMD are forced there, the little that does not fit is spilled --
 //  0.94 -> 0.51 ms; the inverse at 344 loses with the same treatment, 0.53 -> 0.57 ms, and keeps one wave)
-template <int E, bool TWO, bool INVERSE>
+// FRAMES: the windowed 50 %-overlap frames of llz_asmodel.c:313-463 in batch form (time-domain alias cancellation).  A block
+// is (channel c, frame f) of a planar signal [channels][frames F], F = N/2:
+//   forward: the transform's input is w[i] xbuf[i], xbuf = the previous frame followed by frame f = the signal from
+//            (f-1) F on (frame 0: its first half is the handle's state, the last frame of the previous call); the block of the
+//            last frame leaves that frame in state_out;
+//   inverse: w[j] y[j] is ADDED to the signal from f F on (llz_asmodel.c:451-452).  Two launches: the even frames store
+//            (their ranges [f F, (f+2) F) tile the signal; frame 0 adds the previous call's tail), then the odd frames add to
+//            what is there; the last frame's second half is the new tail (state_out).  A sum of two terms does not depend on
+//            their order, so the result is that of the reference's sequential overlap-add.
+struct mdct_fr {
+    const float *win;          // [N]
+    const float *state_in;     // [channels][F]
+    float *state_out;          // [channels][F], not the same buffer
+    int frames;                // frames per channel in this call
+    int first, step;           // this launch: frames first, first + step, ...
+    int per_channel;           // how many of them per channel
+};
+
+template <int E, bool TWO, bool INVERSE, bool FRAMES>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((E == 32 && TWO && !INVERSE) ? 2 : 1)))
 k_mdct_reg_f32(const float *__restrict__ in, float *__restrict__ out, int count, const float *__restrict__ tc,
                const float *__restrict__ ts, const float2 *__restrict__ tw2d, const float2 *__restrict__ tw1,
-               float sqrt_cof)
+               float sqrt_cof, mdct_fr fr)
 {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1292,8 +1310,27 @@ k_mdct_reg_f32(const float *__restrict__ in, float *__restrict__ out, int count,
     const int tid = threadIdx.x, grp = tid / E, lg = tid % E;
     const long t = (long)blockIdx.x * GROUPS + grp;
     if (t >= count) return;                                        // whole groups leave together: no barrier below
-    const float *x = in + t * (INVERSE ? N2 : N);
-    float *y = out + t * (INVERSE ? N : N2);
+    const float *x;
+    float *y;
+    int fc = 0, ff = 0;                                            // FRAMES: channel and frame of this block
+    if constexpr (FRAMES) {
+        fc = (int)(t / fr.per_channel);
+        ff = fr.first + fr.step * (int)(t - (long)fc * fr.per_channel);
+        const size_t sig = (size_t)fc * fr.frames * N2;            // the channel's signal: frames * F samples, F = N2
+        if (!INVERSE) {
+            x = in + sig + (long)(ff - 1) * N2;                    // xbuf[i] = x[i] (frame 0: i < F comes from the state)
+            y = out + (sig + (size_t)ff * N2);                     // coefficients [channels][frames][F]
+        } else {
+            x = in + (sig + (size_t)ff * N2);
+            y = out + sig + (size_t)ff * N2;                       // y[j], j < 2F: the signal from f F on
+        }
+    } else {
+        x = in + t * (INVERSE ? N2 : N);
+        y = out + t * (INVERSE ? N : N2);
+    }
+    const float *st_in = FRAMES ? fr.state_in + (size_t)fc * N2 : nullptr;
+    float *st_out = FRAMES ? fr.state_out + (size_t)fc * N2 : nullptr;
+    const bool last = FRAMES && ff == fr.frames - 1;
     float *buf = bufs[grp];
     // The point k and its mirror N/4-1-k share their rows pairwise: x[2k] goes to k, x[2k+1] to the mirror, and so on.
     // The mirror of (lane lg, register j) is (lane E-1-lg, register E-1-j) -- in bin order (lane E-1-lg, register q^(E-1))
@@ -1303,7 +1340,15 @@ k_mdct_reg_f32(const float *__restrict__ in, float *__restrict__ out, int count,
     };
     // rot[i] = -x[i + 3N/4] (i < N/4), x[i - N/4] otherwise (llz_mdct.c:279-283); pairs never straddle N/4
     auto rot2 = [&](int i) {
-        const f32x2 v = *reinterpret_cast<const f32x2 *>(i < N4 ? x + i + 3 * N4 : x + i - N4);
+        const int idx = i < N4 ? i + 3 * N4 : i - N4;
+        f32x2 v;
+        if constexpr (FRAMES && !INVERSE) {
+            v = *reinterpret_cast<const f32x2 *>((ff == 0 && idx < N2) ? st_in + idx : x + idx);
+            if (last && idx >= N2) *reinterpret_cast<f32x2 *>(st_out + idx - N2) = v;      // the next call's previous frame
+            v *= *reinterpret_cast<const f32x2 *>(fr.win + idx);
+        } else {
+            v = *reinterpret_cast<const f32x2 *>(x + idx);
+        }
         return i < N4 ? -v : v;
     };
     // z[k] = 0.5 (re + j im) (c + j s), (c, s) = cos, sin of -2 pi (k + 1/8) / N
@@ -1363,13 +1408,27 @@ k_mdct_reg_f32(const float *__restrict__ in, float *__restrict__ out, int count,
         return cf{v.x * c - v.y * sn, v.x * sn + v.y * c};
     };
     // rot[ri], rot[ri+1] = (v0, v1) -> x (llz_mdct.c:331-352): x[i] = rot[N/4 + i] cof (i < 3N/4), -rot[i - 3N/4] cof else
+    // FRAMES: windowed, then stored / added into the signal or left as the new overlap-add tail (see mdct_fr)
+    auto put = [&](int j, auto v) {
+        typedef decltype(v) vec;
+        if constexpr (FRAMES && INVERSE) {
+            v *= *reinterpret_cast<const vec *>(fr.win + j);
+            if (j >= N2 && last) {
+                *reinterpret_cast<vec *>(st_out + j - N2) = v;
+                return;
+            }
+            if (fr.first) v += *reinterpret_cast<const vec *>(y + j);                    // odd frames: add to the even frames' stores
+            else if (ff == 0 && j < N2) v += *reinterpret_cast<const vec *>(st_in + j);   // the previous call's tail
+        }
+        *reinterpret_cast<vec *>(y + j) = v;
+    };
     auto unrot2 = [&](int ri, float v0, float v1) {
-        if (ri >= N4) *reinterpret_cast<f32x2 *>(y + ri - N4) = (f32x2){v0 * sqrt_cof, v1 * sqrt_cof};
-        else *reinterpret_cast<f32x2 *>(y + ri + 3 * N4) = (f32x2){-v0 * sqrt_cof, -v1 * sqrt_cof};
+        if (ri >= N4) put(ri - N4, (f32x2){v0 * sqrt_cof, v1 * sqrt_cof});
+        else put(ri + 3 * N4, (f32x2){-v0 * sqrt_cof, -v1 * sqrt_cof});
     };
     auto unrot4 = [&](int ri, float v0, float v1, float v2, float v3) {
-        if (ri >= N4) *reinterpret_cast<f32x4 *>(y + ri - N4) = (f32x4){v0, v1, v2, v3} * sqrt_cof;
-        else *reinterpret_cast<f32x4 *>(y + ri + 3 * N4) = (f32x4){v0, v1, v2, v3} * -sqrt_cof;
+        if (ri >= N4) put(ri - N4, (f32x4){v0, v1, v2, v3} * sqrt_cof);
+        else put(ri + 3 * N4, (f32x4){v0, v1, v2, v3} * -sqrt_cof);
     };
 #pragma unroll
     for (int q = 0; q < E; q++) {
@@ -1568,8 +1627,8 @@ extern "C" int llzs_fft_f32(float *data, int count, int size, const float *cs, i
 
 // MDCT frames on the register transforms (see k_mdct_reg_f32).  N in {256, 512, 1024, 2048, 4096, 8192}; cs: the FFT
 // table of size N/4 the twiddle tables are derived from once per device and size.  Returns LLZ_ERR_RANGE for other N.
-extern "C" int llzs_mdct4_reg_f32(const float *in, float *out, int count, int N, const float *tc, const float *ts,
-                                  const float *cs, int inverse, void *stream)
+static int mdct_reg_launch(const float *in, float *out, int count, int N, const float *tc, const float *ts,
+                           const float *cs, int inverse, void *stream, const mdct_fr *frp)
 {
     int E = 0, two = 0;
     switch (N) {
@@ -1606,9 +1665,14 @@ extern "C" int llzs_mdct4_reg_f32(const float *in, float *out, int count, int N,
     guard.unlock();
     const unsigned blocks = (unsigned)((count + (256 / E) - 1) / (256 / E));
     const float sqrt_cof = (float)(1.0 / sqrt((double)N));
+    const mdct_fr fr = frp ? *frp : mdct_fr{};
 #define LLZ_MDCT_LAUNCH(EE, TT, II)                                                                                  \
-    hipLaunchKernelGGL((k_mdct_reg_f32<EE, TT, II>), dim3(blocks), dim3(256), 0, as_stream(stream), in, out, count, tc,  \
-                       ts, tw2d, tw1, sqrt_cof)
+    do {                                                                                                             \
+        if (frp) hipLaunchKernelGGL((k_mdct_reg_f32<EE, TT, II, true>), dim3(blocks), dim3(256), 0, as_stream(stream), in, \
+                                    out, count, tc, ts, tw2d, tw1, sqrt_cof, fr);                                    \
+        else hipLaunchKernelGGL((k_mdct_reg_f32<EE, TT, II, false>), dim3(blocks), dim3(256), 0, as_stream(stream), in, \
+                                out, count, tc, ts, tw2d, tw1, sqrt_cof, fr);                                        \
+    } while (0)
 #define LLZ_MDCT_PICK(EE)                                                                                            \
     do {                                                                                                             \
         if (two) { if (inverse) LLZ_MDCT_LAUNCH(EE, true, true); else LLZ_MDCT_LAUNCH(EE, true, false); }            \
@@ -1621,6 +1685,38 @@ extern "C" int llzs_mdct4_reg_f32(const float *in, float *out, int count, int N,
 #undef LLZ_MDCT_LAUNCH
     LLZ_LAUNCH_CHECK("k_mdct_reg_f32");
     return LLZ_OK;
+}
+
+extern "C" int llzs_mdct4_reg_f32(const float *in, float *out, int count, int N, const float *tc, const float *ts,
+                                  const float *cs, int inverse, void *stream)
+{
+    return mdct_reg_launch(in, out, count, N, tc, ts, cs, inverse, stream, nullptr);
+}
+
+// Windowed 50 %-overlap MDCT frames in batch (k_mdct_reg_f32<..., FRAMES>): analysis x [channels][frames F] -> X
+// [channels][frames][F], synthesis the other way with overlap-add; F = N/2, win [N], state_in / state_out [channels][F]
+// (analysis: the previous frame; synthesis: the overlap-add tail), two different buffers.
+extern "C" int llzs_mdct4_frames_f32(const float *in, float *out, int channels, int frames, int N, const float *tc,
+                                     const float *ts, const float *cs, const float *win, const float *state_in,
+                                     float *state_out, int inverse, void *stream)
+{
+    if (!win || !state_in || !state_out || state_in == state_out || channels < 1 || frames < 1) {
+        llzs_set_error("mdct4_frames_f32: bad arguments");
+        return LLZ_ERR_ARG;
+    }
+    mdct_fr fr;
+    fr.win = win; fr.state_in = state_in; fr.state_out = state_out; fr.frames = frames;
+    if (!inverse) {
+        fr.first = 0; fr.step = 1; fr.per_channel = frames;
+        return mdct_reg_launch(in, out, channels * frames, N, tc, ts, cs, 0, stream, &fr);
+    }
+    fr.first = 0; fr.step = 2; fr.per_channel = (frames + 1) / 2;
+    int rc = mdct_reg_launch(in, out, channels * fr.per_channel, N, tc, ts, cs, 1, stream, &fr);
+    if (rc == LLZ_OK && frames > 1) {
+        fr.first = 1; fr.per_channel = frames / 2;
+        rc = mdct_reg_launch(in, out, channels * fr.per_channel, N, tc, ts, cs, 1, stream, &fr);
+    }
+    return rc;
 }
 
 extern "C" int llzs_fft_f64(double *data, int size, const double *cs, int inverse, void *stream)

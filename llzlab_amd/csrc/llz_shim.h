@@ -249,6 +249,12 @@ int llzs_mdct4_f32(const float *in, float *out, int count, int N, const float *t
 /* the same on the register transforms for N in {256, 512, 1024, 2048, 4096, 8192}; LLZ_ERR_RANGE for other N */
 int llzs_mdct4_reg_f32(const float *in, float *out, int count, int N, const float *tc, const float *ts, const float *cs,
                        int inverse, void *stream);
+/* windowed 50 %-overlap MDCT frames in batch on the same kernels (N in {256 .. 8192}, F = N/2): analysis x [channels][frames F]
+ * -> X [channels][frames][F]; synthesis the other way with overlap-add.  win [N]; state_in / state_out [channels][F]
+ * (analysis: the previous frame; synthesis: the overlap-add tail), two different buffers */
+int llzs_mdct4_frames_f32(const float *in, float *out, int channels, int frames, int N, const float *tc, const float *ts,
+                          const float *cs, const float *win, const float *state_in, float *state_out, int inverse,
+                          void *stream);
 
 /* ---- PCM ingest / egress ---- */
 int llzs_pcm_deinterleave_i16_f32(const short *in, float *out, int channels, long n, float scale, void *stream);

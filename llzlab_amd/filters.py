@@ -536,6 +536,38 @@ class StftMC:
     __del__ = close
 
 
+class MdctFramesMC:
+    """llz_mdct_frames_mc_*: windowed 50 %-overlap MDCT frames (the batch form of llz_analysis_mdct / llz_synthesis_mdct);
+    x [channels, frames*frame_len] float32, X [channels, frames, frame_len]; the handle carries both streams' state."""
+
+    def __init__(self, channels, frame_len, win=capi.MDCT_SINE, stream=None):
+        self._L = capi.lib()
+        self.handle = check_handle(self._L.llz_mdct_frames_mc_init(channels, frame_len, win), "llz_mdct_frames_mc_init")
+        self.channels, self.frame_len = channels, frame_len
+        if stream is not None:
+            check(self._L.llz_mdct_frames_mc_set_stream(self.handle, _stream_ptr(stream)), "set_stream")
+
+    def _frames(self, x, X):
+        _typed(x, "float32", self.channels * X.shape[1] * self.frame_len, "x")
+        _typed(X, "float32", self.channels * X.shape[1] * self.frame_len, "X")
+        return X.shape[1]
+
+    def analysis(self, x, X):
+        check(self._L.llz_mdct_frames_mc_analysis(self.handle, _ptr(x), _ptr(X), self._frames(x, X)), "llz_mdct_frames_mc_analysis")
+        return X
+
+    def synthesis(self, X, x):
+        check(self._L.llz_mdct_frames_mc_synthesis(self.handle, _ptr(X), _ptr(x), self._frames(x, X)), "llz_mdct_frames_mc_synthesis")
+        return x
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            self._L.llz_mdct_frames_mc_uninit(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
 # ------------------------------------------------------------------------------------------ MDCT
 def mdct_window(win, n, alpha=6.0):
     w = np.zeros(n)

@@ -942,6 +942,43 @@ def test_mdct_batch_vs_oracle(dev, oracle, n, count):
     m.close()
 
 
+@pytest.mark.parametrize("frame_len,win,channels,calls", [(128, 0, 5, (7, 1, 4)), (256, 1, 3, (1, 1, 6)), (512, 0, 70, (5, 2)),
+                                                          (1024, 1, 2, (9,)), (2048, 0, 3, (3, 4)), (4096, 1, 2, (2, 3))])
+def test_mdct_frames_mc_vs_oracle(dev, oracle, frame_len, win, channels, calls):
+    """windowed 50 %-overlap MDCT frames in batch (llz_mdct_frames_mc_*, the register MDCT kernels with the window and the hop
+    fused in): analysis and synthesis streamed over several calls of even, odd and single frame counts (the previous frame /
+    the overlap-add tail carried by the handle; even and odd frames of the synthesis are separate launches), all six
+    transform sizes, both windows; against the oracle's sequential handles per channel, and the TDAC property on every
+    channel: the output is the input delayed by one frame"""
+    F = frame_len
+    total = sum(calls)
+    x = oracle.synth_f32(channels, total * F, seed=F + channels)
+    m = filters.MdctFramesMC(channels, F, win)
+    Xs, ys, o = [], [], 0
+    for frames in calls:
+        xd = torch.from_numpy(np.ascontiguousarray(x[:, o * F:(o + frames) * F])).to(dev)
+        Xd = torch.empty(channels, frames, F, dtype=torch.float32, device=dev)
+        yd = torch.empty(channels, frames * F, dtype=torch.float32, device=dev)
+        m.analysis(xd, Xd)
+        m.synthesis(Xd, yd)
+        Xs.append(Xd.cpu().numpy()); ys.append(yd.cpu().numpy())
+        o += frames
+    X, y = np.concatenate(Xs, axis=1), np.concatenate(ys, axis=1)
+    for c in sorted({0, channels // 2, channels - 1}):
+        Xr, yr = oracle.mdct_frames(F, win, x[c].astype(np.float64))
+        assert np.sqrt(np.mean((X[c] - Xr) ** 2)) <= TOL * max(1.0, np.sqrt(np.mean(Xr ** 2))), (F, c)
+        assert np.sqrt(np.mean((y[c] - yr) ** 2)) <= TOL, (F, c)
+    assert np.abs(y[:, F:] - x[:, :-F]).max() <= 2e-5 and np.abs(y[:, :F]).max() <= 2e-5
+    # host buffers through the staging path: a second handle, one call
+    m2 = filters.MdctFramesMC(channels, F, win)
+    Xh = np.zeros((channels, total, F), dtype=np.float32)
+    m2.analysis(np.ascontiguousarray(x), Xh)
+    assert np.array_equal(Xh, X)
+    m.close(); m2.close()
+    with pytest.raises(capi.LlzError):
+        filters.MdctFramesMC(2, 96, 0)
+
+
 # ------------------------------------------------------------------------------------------------ overlap-save, 2048 points
 @pytest.mark.parametrize("taps_n,channels,n", [(258, 3, 5000), (513, 5, 1536 * 4 + 1), (1025, 2, 1024 * 7), (300, 9, 700),
                                                (1025, 70, 1024 * 40 + 3), (2, 3, 4096), (513, 6, 3072 * 20 + 77),

@@ -194,3 +194,15 @@ if "mdct" in which:
               f"inverse {ms_i:.3f} ms {gb / ms_i / 1e6:.0f} GB/s")
         q.close()
         del x, X
+    # windowed 50 %-overlap frames in batch: 4 B in + 4 B out per sample either way
+    for F, ch, frames in ((128, 1024, 2048), (1024, 1024, 256), (4096, 256, 256)):
+        x = torch.rand(ch, frames * F, dtype=torch.float32, device=dev) * 2 - 1
+        X = torch.empty(ch, frames, F, dtype=torch.float32, device=dev)
+        q = filters.MdctFramesMC(ch, F, capi.MDCT_SINE, stream=stream)
+        ms_a = timeit(lambda: q.analysis(x, X), 5)
+        ms_s = timeit(lambda: q.synthesis(X, x), 5)
+        gb = 8 * ch * frames * F
+        print(f"mdct frames F={F} {ch}ch x {frames}: analysis {ms_a:.3f} ms {gb / ms_a / 1e6:.0f} GB/s ({gb / ms_a / 1e6 / 80:.1f} %), "
+              f"synthesis {ms_s:.3f} ms {gb / ms_s / 1e6:.0f} GB/s ({gb / ms_s / 1e6 / 80:.1f} %)")
+        q.close()
+        del x, X
