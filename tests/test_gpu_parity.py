@@ -1095,6 +1095,97 @@ def test_fir_ols_headline_shape_full_length(dev, oracle):
     f.close()
 
 
+@pytest.mark.parametrize("name,row,prec", [("config 4 low-pass section", [0.2066, 0.4131, 0.2066, 1.0, -0.3695, 0.1958], 32),
+                                           ("0.99-radius set", [0.01, 0.0, -0.01, 1.0, -2 * 0.99 * np.cos(0.3), 0.99 ** 2], 64)])
+def test_iir_config4_full_size(dev, oracle, name, row, prec):
+    """BASELINE config 4 at its full size through the handle's own dispatch: 1024 channels x 2^20 samples x 8 sections, both
+    coefficient sets the bench times (packed float32 with 32 samples per lane; double with 32 samples per lane, b0 folded).
+    Six spread channels over their FULL length against the double oracle, every channel over its first 8 Ki samples, and a
+    second call of a ragged length (state handed from the 2048-sample kernels to the 1024-sample and per-channel ones)"""
+    channels, n = 1024, 1 << 20
+    coef = np.tile(np.array(row), (8, 1))
+    x = torch.empty(channels, n, dtype=torch.float32, device=dev)
+    filters.synth_f32(x, seed=0x44)
+    y = torch.empty_like(x)
+    f = filters.IirCascadeMC(channels, coef)
+    assert f.precision == prec
+    f.filter(x, y)
+    torch.cuda.synchronize()
+    sel = [0, 1, 333, 512, 1022, 1023]
+    n2 = 1024 * 3 + 77
+    x2 = torch.empty(channels, n2, dtype=torch.float32, device=dev)
+    filters.synth_f32(x2, seed=0x45)
+    y2 = torch.empty_like(x2)
+    f.filter(x2, y2)
+    f.close()
+    xs = np.concatenate([x[sel].cpu().numpy(), x2[sel].cpu().numpy()], axis=1)
+    ref = oracle.iir_cascade_batch_f32(xs, coef)
+    got = np.concatenate([y[sel].cpu().numpy(), y2[sel].cpu().numpy()], axis=1).astype(np.float64)
+    err, scale = float(np.sqrt(np.mean((got - ref) ** 2))), float(np.sqrt(np.mean(ref ** 2)))
+    assert err <= TOL * max(1.0, scale) and err / scale <= TOL, (name, err, scale)
+    m = 8192
+    ref = oracle.iir_cascade_batch_f32(x[:, :m].cpu().numpy(), coef)
+    got = y[:, :m].cpu().numpy().astype(np.float64)
+    err, scale = float(np.sqrt(np.mean((got - ref) ** 2))), float(np.sqrt(np.mean(ref ** 2)))
+    assert err <= TOL * max(1.0, scale) and err / scale <= TOL, (name, "all channels", err, scale)
+
+
+def test_resample_config5_full_size_i16_bit_exact(dev, oracle):
+    """BASELINE config 5 at its full size in the reference's own sample format: 8192 channels x 4 Mi int16 samples, 1:3,
+    through the handle's own dispatch (integer screen on the matrix cores + exact recompute).  Six spread channels over their
+    FULL length and every channel over its first 12 Ki inputs, bit for bit against the oracle; a checksum of the whole output
+    must not change when the same frame is processed by a second handle on the all-double kernel for a spread subset"""
+    channels, n_in, M = 8192, 1536 * 2730, 3                            # whole frames of the reference (1536 samples), ~4 Mi
+    x = torch.empty(channels, n_in, dtype=torch.int16, device=dev)
+    filters.synth_i16(x, seed=0x55)
+    r = filters.ResampleMC(channels, 1, M, 1.0, po.BLACKMAN, filters.PCM_I16)
+    n_out = r.out_len(n_in)
+    y = torch.empty(channels, n_out, dtype=torch.int16, device=dev)
+    r.process(x, y)
+    torch.cuda.synchronize()
+    r.close()
+    sel = [0, 1, 2047, 4096, 8190, 8191]
+    ref = oracle.rs_batch_i16(x[sel].cpu().numpy(), 1, M, 1.0, po.BLACKMAN)
+    assert np.array_equal(y[sel].cpu().numpy(), ref), "config 5 int16: six channels, full length"
+    m_in = 3 * 4096
+    ref = oracle.rs_batch_i16(x[:, :m_in].cpu().numpy(), 1, M, 1.0, po.BLACKMAN)
+    assert np.array_equal(y[:, :m_in // M].cpu().numpy(), ref), "config 5 int16: all channels x 4 Ki outputs"
+    # the all-double kernel on 64 spread channels, whole length: same bits
+    sub = list(range(0, channels, 128))
+    xs = x[sub].contiguous()
+    with capi.tuned(rs_i16_path=1):
+        r2 = filters.ResampleMC(len(sub), 1, M, 1.0, po.BLACKMAN, filters.PCM_I16)
+        y2 = torch.empty(len(sub), n_out, dtype=torch.int16, device=dev)
+        r2.process(xs, y2)
+        r2.close()
+    assert torch.equal(y2, y[sub])
+
+
+def test_resample_config5_full_size_f32(dev, oracle):
+    """BASELINE config 5 at its full size, float32: 8192 channels x ~4 Mi samples, 1:3 on the matrix cores (split bf16).  Four
+    spread channels over their FULL length and every channel over its first 12 Ki inputs against the oracle (double
+    accumulate over the float-rounded taps)"""
+    channels, n_in, M = 8192, 1536 * 2730, 3
+    x = torch.empty(channels, n_in, dtype=torch.float32, device=dev)
+    filters.synth_f32(x, seed=0x56)
+    r = filters.ResampleMC(channels, 1, M, 1.0, po.BLACKMAN, filters.PCM_F32)
+    n_out = r.out_len(n_in)
+    y = torch.empty(channels, n_out, dtype=torch.float32, device=dev)
+    r.process(x, y)
+    torch.cuda.synchronize()
+    r.close()
+    sel = [0, 2049, 6000, 8191]
+    ref = oracle.rs_batch_f32(x[sel].cpu().numpy(), 1, M, 1.0, po.BLACKMAN)
+    got = y[sel].cpu().numpy().astype(np.float64)
+    err = float(np.sqrt(np.mean((got - ref) ** 2)))
+    assert err <= TOL and err / float(np.sqrt(np.mean(ref ** 2))) <= 3e-5, err
+    m_in = 3 * 4096
+    ref = oracle.rs_batch_f32(x[:, :m_in].cpu().numpy(), 1, M, 1.0, po.BLACKMAN)
+    got = y[:, :m_in // M].cpu().numpy().astype(np.float64)
+    err = float(np.sqrt(np.mean((got - ref) ** 2)))
+    assert err <= TOL and err / float(np.sqrt(np.mean(ref ** 2))) <= 3e-5, err
+
+
 def test_iir_wave_first_version_kernels(dev, oracle):
     """llz_hip_tune("iir_unpacked", 1) keeps the first wave-autonomous kernels (no one-section-ahead fetch, no packed
     arithmetic) for A/B runs; they stay checked here"""
