@@ -663,6 +663,7 @@ extern "C" int llzs_fir_ols_f32(const float *in, float *out, const float *hist, 
             if (cost < best * 0.999) { best = cost; seg_len = sl; }
         }
     }
+    if (const int v = llzs_tune(LLZS_TUNE_OLS_SEG_LEN); v >= 1 && v <= 1024) seg_len = v;
     G.seg_len = seg_len;
     G.segs_per_channel = (G.jobs_per_channel + seg_len - 1) / seg_len;
     G.total_segs = (long)G.segs_per_channel * channels;

@@ -46,6 +46,7 @@ enum {
     LLZS_TUNE_IIR_WAVE_MIN_ITEMS,   /* crossover (channel, segment) item count of the wave form */
     LLZS_TUNE_SHARD_RCCL,           /* 1: sharded handles broadcast their tables through RCCL even on a single device */
     LLZS_TUNE_RS_MFMA_FORM,         /* 1: matrix-core L/M resampler with a wave per PERIOD tile (first form) */
+    LLZS_TUNE_OLS_SEG_LEN,          /* jobs per segment of the 1024-point overlap-save walk (1..16) */
     LLZS_TUNE_COUNT
 };
 int llzs_tune(int id);                                   /* current override or -1 */
