@@ -74,6 +74,18 @@ int main(void)
     CHECK(llz_iir_cascade_mc(h, fx, fy, 1) == 1);
     llz_iir_cascade_mc_uninit(h);
     CHECK(llz_iir_cascade_mc_init(5, 0, &coef[0][0]) == BAD);
+    {   /* eight high-Q sections: double arithmetic with the folded-gain tables of the 32-sample kernel; a zero b0: no folding */
+        double hq[8][6];
+        for (int s = 0; s < 8; s++) { hq[s][0] = 0.01; hq[s][1] = 0; hq[s][2] = -0.01; hq[s][3] = 1; hq[s][4] = -1.89 + 0.01 * s; hq[s][5] = 0.9801; }
+        h = llz_iir_cascade_mc_init(4, 8, &hq[0][0]); CHECK(h != BAD);
+        CHECK(llz_iir_cascade_mc_precision(h) == 64);
+        CHECK(llz_iir_cascade_mc(h, fx, fy, 4096 + 1024 + 7) == 4096 + 1024 + 7);
+        llz_iir_cascade_mc_uninit(h);
+        hq[3][0] = 0.0;
+        h = llz_iir_cascade_mc_init(4, 8, &hq[0][0]); CHECK(h != BAD);
+        CHECK(llz_iir_cascade_mc(h, fx, fy, 2048) == 2048);
+        llz_iir_cascade_mc_uninit(h);
+    }
     /* resamplers: the reference's three and the batch forms (int16 screen tables, matrix-core band tables) */
     h = llz_resample_filter_init(147, 160, 1.0, BLACKMAN); CHECK(h != BAD);
     int nb = llz_get_resample_framelen_bytes(h), ob = 0;
@@ -136,6 +148,13 @@ int main(void)
     h = llz_mdct_batch_init(1024); CHECK(h != BAD); CHECK(llz_mdct_batch(h, fx, fy, 4) >= 0 && llz_imdct_batch(h, fy, fx, 4) >= 0);
     llz_mdct_batch_uninit(h);
     CHECK(llz_mdct_batch_init(100) == BAD);
+    /* windowed MDCT frames in batch: both directions, two calls (state buffers swap), refused shapes */
+    h = llz_mdct_frames_mc_init(3, 128, MDCT_KBD); CHECK(h != BAD);
+    CHECK(llz_mdct_frames_mc_analysis(h, fx, fy, 5) == 5 && llz_mdct_frames_mc_synthesis(h, fy, fx, 5) == 5);
+    CHECK(llz_mdct_frames_mc_analysis(h, fx, fy, 1) == 1 && llz_mdct_frames_mc_synthesis(h, fy, fx, 1) == 1);
+    CHECK(llz_mdct_frames_mc_analysis(h, fx, fx, 1) < 0 && llz_mdct_frames_mc_analysis(h, fx, fy, 0) < 0);
+    llz_mdct_frames_mc_uninit(h);
+    CHECK(llz_mdct_frames_mc_init(3, 96, MDCT_SINE) == BAD && llz_mdct_frames_mc_init(0, 128, MDCT_SINE) == BAD);
     /* PCM, WAV */
     CHECK(llz_pcm_deinterleave_i16_f32(sx, fx, 6, 100, 1.0f / 32768, NULL) == 0);
     CHECK(llz_pcm_interleave_f32_i16(fx, sx, 6, 100, 32768.f, NULL) == 0);
