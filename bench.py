@@ -128,19 +128,20 @@ def main():
     dev = torch.device("cuda", dev_index)
     capi.check(capi.lib().llz_hip_set_device(dev_index), "llz_hip_set_device")
     comm_dev = dev if args.dist_backend == "nccl" else None       # where the tiny setup collectives live
+    cpu_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the coefficient tables travel over RCCL (backend nccl, device tensors); the timing barrier and the max-reduce of the
+        # step time are host-side bookkeeping on a gloo group, which is also where a table goes should RCCL refuse to come up
+        # (reported in the line as "table_broadcast")
+        dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
         if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
+            cpu_group = dist.new_group(backend="gloo")
+            shard.use_cpu_group(cpu_group)
 
     def barrier():
         if world > 1:
-            if args.dist_backend == "nccl":
-                dist.barrier(device_ids=[dev_index])
-            else:
-                dist.barrier()
+            dist.barrier(group=cpu_group)
 
     channels, n = args.channels, args.samples
     # rank 0 designs the tap set (host C: llz_fir_lpf_cof(257, 0.1, KAISER)); everyone else receives it over RCCL
@@ -280,7 +281,7 @@ def main():
             "metric": "Msamples/s/GPU (float32 FIR 257-tap, 4096 ch) + achieved HBM GB/s vs peak",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "table_broadcast": shard.transport() if world > 1 else "single process",
             "config": {"workload": f"{channels}-ch float32 FIR, {FLT_LEN} taps (llz_fir_lpf_cof 0.1 KAISER), "
                                    f"{n} samples/ch per GPU, {algo_name}, channels sharded over {world} GPU(s)",
                        "channels_per_gpu": channels, "samples_per_channel": n, "taps": FLT_LEN,

@@ -6,6 +6,41 @@ gloo in the CPU tests.  There is no steady-state collective.
 """
 import numpy as np
 
+# how the setup collectives travelled in this process: "rccl" (device tensors over the nccl backend), "gloo" (host tensors), and
+# the reason if the device path was given up (one failure switches every later call to the host group)
+_state = {"cpu_group": None, "device_ok": True, "used": [], "error": None}
+
+
+def use_cpu_group(group):
+    """A gloo process group for the timing barrier / max-reduce and as the fallback of the table broadcasts."""
+    _state["cpu_group"] = group
+
+
+def transport():
+    """e.g. "rccl", "gloo", or "gloo (rccl failed: ...)" -- for the bench line"""
+    used = "+".join(dict.fromkeys(_state["used"])) or "none"
+    return used + (f" (rccl failed: {_state['error']})" if _state["error"] else "")
+
+
+def _device_collective(t, device, fn):
+    """run fn(tensor) on a device copy of t over the default (nccl) group; on failure fall back to the host group for good"""
+    import torch
+
+    if device is not None and _state["device_ok"]:
+        try:
+            d = t.to(device)
+            fn(d, None)
+            torch.cuda.synchronize()
+            _state["used"].append("rccl")
+            return d.cpu()
+        except Exception as e:  # noqa: BLE001  (communicator creation or the collective itself)
+            _state["device_ok"] = False
+            _state["error"] = str(e).splitlines()[0][:160]
+    h = t.clone()
+    fn(h, _state["cpu_group"] if device is not None else None)
+    _state["used"].append("gloo")
+    return h
+
 
 def channel_range(total_channels, rank, world_size):
     """Contiguous slice [lo, hi) of the channel axis owned by `rank` (remainder spread over the first ranks)."""
@@ -30,10 +65,7 @@ def broadcast_table(table, src=0, device=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return arr
     t = torch.from_numpy(arr.copy())
-    if device is not None:
-        t = t.to(device)
-    dist.broadcast(t, src=src)
-    return t.cpu().numpy()
+    return _device_collective(t, device, lambda x, g: dist.broadcast(x, src=src, group=g)).numpy()
 
 
 def broadcast_shape(shape, src=0, device=None, ndim=2):
@@ -45,10 +77,8 @@ def broadcast_shape(shape, src=0, device=None, ndim=2):
         return tuple(int(v) for v in shape)
     vals = list(shape) + [0] * (ndim - len(shape))
     t = torch.tensor(vals, dtype=torch.int64)
-    if device is not None:
-        t = t.to(device)
-    dist.broadcast(t, src=src)
-    return tuple(int(v) for v in t.cpu().tolist())
+    t = _device_collective(t, device, lambda x, g: dist.broadcast(x, src=src, group=g))
+    return tuple(int(v) for v in t.tolist())
 
 
 def max_over_ranks(value, device=None):
@@ -59,7 +89,8 @@ def max_over_ranks(value, device=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64)
-    if device is not None:
-        t = t.to(device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if _state["cpu_group"] is not None:                      # timing bookkeeping stays on the host group
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_state["cpu_group"])
+        return float(t.item())
+    t = _device_collective(t, device, lambda x, g: dist.all_reduce(x, op=dist.ReduceOp.MAX, group=g))
     return float(t.item())

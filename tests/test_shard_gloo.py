@@ -38,6 +38,14 @@ def _worker(rank, world, port, q):
         gotm = shard.broadcast_table(mat)
         t = shard.max_over_ranks(1.0 + rank)
         lo, hi = shard.channel_range(8192, rank, world)
+        # the bench's layout: a host-side gloo group for the bookkeeping, device tensors for the tables; here the device path
+        # must fail on every rank (no GPU in this process) and the table still arrives, over the host group, with the failure
+        # reported
+        if not __import__("torch").cuda.is_available():
+            shard.use_cpu_group(dist.new_group(backend="gloo"))
+            again = shard.broadcast_table(taps, device="cuda:0")
+            assert again.tobytes() == got.tobytes() and "rccl failed" in shard.transport(), shard.transport()
+            assert shard.max_over_ranks(5.0 - rank, device="cuda:0") == 5.0
         q.put((rank, got.tobytes(), shape, float(gotm.sum()), t, lo, hi))
     finally:
         dist.destroy_process_group()
