@@ -383,11 +383,16 @@ extern "C" int llzs_resample_mfma_f32(const float *in, float *out, const float *
             rp.l_magic = (unsigned)((0x100000000ull + (unsigned)L - 1) / (unsigned)L);
             const long periods = (n_out + L - 1) / L;
             rp.spans = (periods + 16 * pt - 1) / (16 * pt);
-            // consecutive spans per workgroup: ~6 rounds of 512 resident workgroups over the launch, at least 4 spans where
-            // the channel has them (the first span of a walk waits for memory with nothing to do)
-            long spw = (rp.spans * channels) / (512 * 6);
-            if (spw < 4) spw = 4;
-            if (spw > rp.spans) spw = rp.spans;
+            // consecutive spans per workgroup: the walk length that minimises rounds x (length + 1) over the 512 resident
+            // workgroups (two per CU) -- a walk's first span waits for memory with nothing to do, and a last round that is
+            // half empty costs as much as a full one (147:160, 256 channels: 14 spans per walk made 6.5 rounds)
+            long spw = rp.spans < 4 ? rp.spans : 4;
+            double best = 1e300;
+            for (long c = spw; c <= rp.spans; c++) {
+                const long wgs = ((rp.spans + c - 1) / c) * (long)channels;
+                const double cost = (double)((wgs + 511) / 512) * (double)(c + 1);
+                if (cost < best * 0.999) { best = cost; spw = c; }
+            }
             rp.spans_per_wg = (int)spw;
             const dim3 grid((unsigned)((rp.spans + spw - 1) / spw), (unsigned)channels), block(64 * waves);
             const bool reload = rp.ntiles > waves;
