@@ -1,4 +1,7 @@
-// fir_ols.hip -- K4: overlap-save FIR (up to 257 taps) with a 1024-point complex FFT that never leaves the CU.
+// fir_ols.hip -- K4 / K4b: overlap-save FIR with register FFTs that never leave the CU.
+//   k_fir_ols_chain_f32      up to 257 taps   1024-point transforms, a half-wave per job (described first, below)
+//   k_fir_ols2k_chain_f32<O> up to 1025 taps  2048-point transforms, a whole wave per job (one radix-2 step over the half-waves)
+//   k_fir_ols4k_f32<O>       up to 3073 taps  4096-point transforms, a whole wave per job (two radix-2 steps)
 //
 // New functionality relative to the reference (llz_fir.c is time-domain only); its end-to-end
 // oracle is the time-domain llz_fir_filter (llz_fir.c:547-584), its FFT stage follows the sign/scale
