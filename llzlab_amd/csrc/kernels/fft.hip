@@ -1307,7 +1307,14 @@ k_mdct_reg_f32(const float *__restrict__ in, float *__restrict__ out, int count,
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int H = E * E, N4 = TWO ? 2 * H : H, N = 4 * N4, N2 = N / 2, GROUPS = 256 / E, PITCH = E + 1;
     __shared__ float bufs[GROUPS][E * PITCH];
+    // FRAMES: the window in LDS, one copy for the workgroup's frames (through the vector memory path it was one load per
+    // signal load)
+    __shared__ __attribute__((aligned(16))) float s_win[FRAMES ? N : 4];
     const int tid = threadIdx.x, grp = tid / E, lg = tid % E;
+    if constexpr (FRAMES) {
+        for (int i = 4 * tid; i < N; i += 4 * 256) *reinterpret_cast<f32x4 *>(s_win + i) = *reinterpret_cast<const f32x4 *>(fr.win + i);
+        __syncthreads();
+    }
     const long t = (long)blockIdx.x * GROUPS + grp;
     if (t >= count) return;                                        // whole groups leave together: no barrier below
     const float *x;
@@ -1339,17 +1346,23 @@ k_mdct_reg_f32(const float *__restrict__ in, float *__restrict__ out, int count,
         return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), ((E - 1) << 10) | 0x1F));   // lane ^ (E-1)
     };
     // rot[i] = -x[i + 3N/4] (i < N/4), x[i - N/4] otherwise (llz_mdct.c:279-283); pairs never straddle N/4
-    auto rot2 = [&](int i) {
-        const int idx = i < N4 ? i + 3 * N4 : i - N4;
+    // (ib = the part of i that does not depend on the lane, a multiple of 2E: which quarter i falls in is decided on it, at
+    //  compile time after unrolling -- every access is then base + lane offset + constant)
+    const float *xlo = x;                                          // FRAMES forward: where xbuf[0 .. F) lives
+    if constexpr (FRAMES && !INVERSE) xlo = ff == 0 ? st_in : x;
+    auto rot2 = [&](int ib, int lane2) {
+        const bool neg = ib < N4;
+        const int idx = (neg ? ib + 3 * N4 : ib - N4) + lane2;
+        const bool hi_half = neg || ib >= 3 * N4;                  // idx >= N/2
         f32x2 v;
         if constexpr (FRAMES && !INVERSE) {
-            v = *reinterpret_cast<const f32x2 *>((ff == 0 && idx < N2) ? st_in + idx : x + idx);
-            if (last && idx >= N2) *reinterpret_cast<f32x2 *>(st_out + idx - N2) = v;      // the next call's previous frame
-            v *= *reinterpret_cast<const f32x2 *>(fr.win + idx);
+            v = *reinterpret_cast<const f32x2 *>((hi_half ? x : xlo) + idx);
+            if (hi_half && last) *reinterpret_cast<f32x2 *>(st_out + idx - N2) = v;       // the next call's previous frame
+            v *= *reinterpret_cast<const f32x2 *>(s_win + idx);
         } else {
             v = *reinterpret_cast<const f32x2 *>(x + idx);
         }
-        return i < N4 ? -v : v;
+        return neg ? -v : v;
     };
     // z[k] = 0.5 (re + j im) (c + j s), (c, s) = cos, sin of -2 pi (k + 1/8) / N
     auto pre = [&](int k, float re, float im) {
@@ -1366,14 +1379,14 @@ k_mdct_reg_f32(const float *__restrict__ in, float *__restrict__ out, int count,
         if (!INVERSE) {
             // own: r0 = rot[2k], r3 = rot[N/2+2k];  from the mirror: r2 = rot[2k+1] (= rot[N/2-1-2k']), r1 = rot[N/2+2k+1]
             if (!TWO) {
-                const f32x2 Aa = rot2(2 * ka), Ba = rot2(N2 + 2 * ka), Ab = rot2(2 * kb), Bb = rot2(N2 + 2 * kb);
+                const f32x2 Aa = rot2(2 * E * j, 2 * lg), Ba = rot2(N2 + 2 * E * j, 2 * lg), Ab = rot2(2 * E * jm, 2 * lg), Bb = rot2(N2 + 2 * E * jm, 2 * lg);
                 const float r2a = mir(Ab.y), r1a = mir(Bb.y), r2b = mir(Aa.y), r1b = mir(Ba.y);
                 s[j] = pre(ka, Aa.x - r1a, r2a - Ba.x);
                 s[jm] = pre(kb, Ab.x - r1b, r2b - Bb.x);
             } else {
-                const f32x2 Aa = rot2(2 * ka), Ba = rot2(N2 + 2 * ka), Ab = rot2(2 * kb), Bb = rot2(N2 + 2 * kb);
-                const f32x2 Ca = rot2(2 * (ka + H)), Da = rot2(N2 + 2 * (ka + H));
-                const f32x2 Cb = rot2(2 * (kb + H)), Db = rot2(N2 + 2 * (kb + H));
+                const f32x2 Aa = rot2(2 * E * j, 2 * lg), Ba = rot2(N2 + 2 * E * j, 2 * lg), Ab = rot2(2 * E * jm, 2 * lg), Bb = rot2(N2 + 2 * E * jm, 2 * lg);
+                const f32x2 Ca = rot2(2 * E * j + 2 * H, 2 * lg), Da = rot2(N2 + 2 * E * j + 2 * H, 2 * lg);
+                const f32x2 Cb = rot2(2 * E * jm + 2 * H, 2 * lg), Db = rot2(N2 + 2 * E * jm + 2 * H, 2 * lg);
                 // a-point ka <- mirror lane's b-point kb + H (its register jm = our j's partner): C/D of index b
                 const cf a0 = pre(ka, Aa.x - mir(Db.y), mir(Cb.y) - Ba.x);
                 const cf b0 = pre(ka + H, Ca.x - mir(Bb.y), mir(Ab.y) - Da.x);
@@ -1409,26 +1422,34 @@ k_mdct_reg_f32(const float *__restrict__ in, float *__restrict__ out, int count,
     };
     // rot[ri], rot[ri+1] = (v0, v1) -> x (llz_mdct.c:331-352): x[i] = rot[N/4 + i] cof (i < 3N/4), -rot[i - 3N/4] cof else
     // FRAMES: windowed, then stored / added into the signal or left as the new overlap-add tail (see mdct_fr)
-    auto put = [&](int j, auto v) {
+    // (jb / rb = the lane-independent part of the index, a multiple of 2E: which half / quarter it falls in is decided on it
+    //  at compile time, as in rot2)
+    float *ylo = y;                                                 // FRAMES inverse: second half of the last frame -> tail
+    auto put = [&](int jb, int lane_off, auto v) {
         typedef decltype(v) vec;
+        const int j = jb + lane_off;
         if constexpr (FRAMES && INVERSE) {
-            v *= *reinterpret_cast<const vec *>(fr.win + j);
-            if (j >= N2 && last) {
-                *reinterpret_cast<vec *>(st_out + j - N2) = v;
-                return;
+            v *= *reinterpret_cast<const vec *>(s_win + j);
+            if (jb >= N2) {
+                if (last) {
+                    *reinterpret_cast<vec *>(st_out + j - N2) = v;
+                    return;
+                }
+                if (fr.first) v += *reinterpret_cast<const vec *>(y + j);                // odd frames: add to the even frames' stores
+            } else {
+                if (fr.first) v += *reinterpret_cast<const vec *>(y + j);
+                else if (ff == 0) v += *reinterpret_cast<const vec *>(st_in + j);         // the previous call's tail
             }
-            if (fr.first) v += *reinterpret_cast<const vec *>(y + j);                    // odd frames: add to the even frames' stores
-            else if (ff == 0 && j < N2) v += *reinterpret_cast<const vec *>(st_in + j);   // the previous call's tail
         }
-        *reinterpret_cast<vec *>(y + j) = v;
+        *reinterpret_cast<vec *>(ylo + j) = v;
     };
-    auto unrot2 = [&](int ri, float v0, float v1) {
-        if (ri >= N4) put(ri - N4, (f32x2){v0 * sqrt_cof, v1 * sqrt_cof});
-        else put(ri + 3 * N4, (f32x2){-v0 * sqrt_cof, -v1 * sqrt_cof});
+    auto unrot2 = [&](int rb, int lane_off, float v0, float v1) {
+        if (rb >= N4) put(rb - N4, lane_off, (f32x2){v0 * sqrt_cof, v1 * sqrt_cof});
+        else put(rb + 3 * N4, lane_off, (f32x2){-v0 * sqrt_cof, -v1 * sqrt_cof});
     };
-    auto unrot4 = [&](int ri, float v0, float v1, float v2, float v3) {
-        if (ri >= N4) put(ri - N4, (f32x4){v0, v1, v2, v3} * sqrt_cof);
-        else put(ri + 3 * N4, (f32x4){v0, v1, v2, v3} * -sqrt_cof);
+    auto unrot4 = [&](int rb, int lane_off, float v0, float v1, float v2, float v3) {
+        if (rb >= N4) put(rb - N4, lane_off, (f32x4){v0, v1, v2, v3} * sqrt_cof);
+        else put(rb + 3 * N4, lane_off, (f32x4){v0, v1, v2, v3} * -sqrt_cof);
     };
 #pragma unroll
     for (int q = 0; q < E; q++) {
@@ -1455,18 +1476,20 @@ k_mdct_reg_f32(const float *__restrict__ in, float *__restrict__ out, int count,
             if (!TWO) {
                 const cf pa = post(kq, s[q]), pb = post(km, s[qm]);
                 const float ia = mir(pb.y), ra = mir(pb.x), ib = mir(pa.y), rb = mir(pa.x);
-                unrot2(2 * kq, g * pa.x, -g * ia);
-                unrot2(N2 + 2 * kq, g * pa.y, -g * ra);
-                unrot2(2 * km, g * pb.x, -g * ib);
-                unrot2(N2 + 2 * km, g * pb.y, -g * rb);
+                const int bq = 2 * E * brevE<E>(q), bm = 2 * E * brevE<E>(qm);    // constants after unrolling
+                unrot2(bq, 2 * lg, g * pa.x, -g * ia);
+                unrot2(N2 + bq, 2 * lg, g * pa.y, -g * ra);
+                unrot2(bm, 2 * lg, g * pb.x, -g * ib);
+                unrot2(N2 + bm, 2 * lg, g * pb.y, -g * rb);
             } else {
                 const cf sa = post(2 * kq, s[q]), da = post(2 * kq + 1, d[q]), sb = post(2 * km, s[qm]), db = post(2 * km + 1, d[qm]);
                 const float dbi = mir(db.y), dbr = mir(db.x), sbi = mir(sb.y), sbr = mir(sb.x);
                 const float dai = mir(da.y), dar = mir(da.x), sai = mir(sa.y), sar = mir(sa.x);
-                unrot4(4 * kq, g * sa.x, -g * dbi, g * da.x, -g * sbi);
-                unrot4(N2 + 4 * kq, g * sa.y, -g * dbr, g * da.y, -g * sbr);
-                unrot4(4 * km, g * sb.x, -g * dai, g * db.x, -g * sai);
-                unrot4(N2 + 4 * km, g * sb.y, -g * dar, g * db.y, -g * sar);
+                const int bq = 4 * E * brevE<E>(q), bm = 4 * E * brevE<E>(qm);
+                unrot4(bq, 4 * lg, g * sa.x, -g * dbi, g * da.x, -g * sbi);
+                unrot4(N2 + bq, 4 * lg, g * sa.y, -g * dbr, g * da.y, -g * sbr);
+                unrot4(bm, 4 * lg, g * sb.x, -g * dai, g * db.x, -g * sai);
+                unrot4(N2 + bm, 4 * lg, g * sb.y, -g * dar, g * db.y, -g * sar);
             }
         }
     }
