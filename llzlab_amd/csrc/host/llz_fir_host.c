@@ -326,7 +326,8 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
         if (flt_len <= 32) algo = LLZ_FIR_ALGO_TIME;
         else if (flt_len <= LLZS_OLS_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE;
         /* whole-wave overlap-save (4096 ch x 2^20): 2048 points with 512 of overlap 7.8 ms up to 513 taps (10.6 ms with 1024
-         * of overlap); 4096 points 8.0 / 8.3 / 11.3 / 19.5 ms with 512 / 1024 / 2048 / 3072 of overlap */
+         * of overlap); 4096 points 8.0 / 7.9 / 8.3 / 9.6 / 11.3 / 14.7 / 19.5 ms with 512 / 768 / 1024 / 1536 / 2048 / 2560 /
+         * 3072 of overlap */
         else if (flt_len <= 513) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_2048;
         else if (flt_len <= LLZS_OLS4K_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_4096;
         else algo = llzs_fir_mfma_f32_fits(flt_len, 1) ? LLZ_FIR_ALGO_TIME_MFMA : LLZ_FIR_ALGO_TIME;

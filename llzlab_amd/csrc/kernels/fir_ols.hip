@@ -511,7 +511,8 @@ __device__ __forceinline__ void ols2k_core(cf (&v)[32], cf (&y)[32], float *buf,
     }
 }
 
-// O = overlap (512: up to 513 taps, 1024: up to 1025, 2048: up to 2049, 3072: up to 3073); a job is two blocks = 2 (4096 - O) new samples.
+// O = overlap, a multiple of 64 that holds flt_len - 1 samples (512, 768, 1024, 1536, 2048, 2560, 3072); a job is two blocks =
+// 2 (4096 - O) new samples.
 // Lane position i (0..63) of a block is sample 64 i + rowoff; positions below O / 64 are overlap.
 template <int O>
 __global__ void __launch_bounds__(O4K_THREADS, 2)
@@ -781,11 +782,14 @@ extern "C" int llzs_fir_ols4k_f32(const float *in, float *out, const float *hist
         llzs_set_error("fir_ols4k_f32: bad arguments (flt_len=%d, 2..%d)", flt_len, LLZS_OLS4K_MAX_TAPS);
         return LLZ_ERR_ARG;
     }
-    if (flt_len <= 513)
-        return ols4k_launch<512>(in, out, hist, hfreq4, twid, tw2k, tw4k, channels, n, in_pitch, out_pitch, flt_len, stream);
-    if (flt_len <= 1025)
-        return ols4k_launch<1024>(in, out, hist, hfreq4, twid, tw2k, tw4k, channels, n, in_pitch, out_pitch, flt_len, stream);
-    if (flt_len <= 2049)
-        return ols4k_launch<2048>(in, out, hist, hfreq4, twid, tw2k, tw4k, channels, n, in_pitch, out_pitch, flt_len, stream);
-    return ols4k_launch<3072>(in, out, hist, hfreq4, twid, tw2k, tw4k, channels, n, in_pitch, out_pitch, flt_len, stream);
+    // the smallest overlap of the ladder that holds flt_len - 1 samples: a block yields 4096 - O outputs
+#define LLZ_OLS4K_GO(O) return ols4k_launch<O>(in, out, hist, hfreq4, twid, tw2k, tw4k, channels, n, in_pitch, out_pitch, flt_len, stream)
+    if (flt_len <= 513) LLZ_OLS4K_GO(512);
+    if (flt_len <= 769) LLZ_OLS4K_GO(768);
+    if (flt_len <= 1025) LLZ_OLS4K_GO(1024);
+    if (flt_len <= 1537) LLZ_OLS4K_GO(1536);
+    if (flt_len <= 2049) LLZ_OLS4K_GO(2048);
+    if (flt_len <= 2561) LLZ_OLS4K_GO(2560);
+    LLZ_OLS4K_GO(3072);
+#undef LLZ_OLS4K_GO
 }

@@ -1015,7 +1015,10 @@ def test_fir_ols2048_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
 @pytest.mark.parametrize("taps_n,channels,n", [(1026, 3, 9000), (2049, 2, 2048 * 5 + 1), (3073, 2, 1024 * 9), (1500, 40, 1024 * 30 + 3),
                                                (2, 3, 8192), (400, 5, 1000), (2049, 7, 4096 * 19 + 77), (2000, 300, 4096 * 3),
                                                (2050, 3, 4096 * 4), (1025, 4, 6144 * 3 + 5), (700, 33, 6144 * 11), (513, 6, 7168 * 5 + 77),
-                                               (2600, 5, 2048 * 9 + 31), (3073, 130, 2048 * 6)])
+                                               (2600, 5, 2048 * 9 + 31), (3073, 130, 2048 * 6),
+                                               # the in-between overlaps of the ladder: 768, 1536, 2560
+                                               (769, 4, 6656 * 3 + 17), (600, 40, 6656 * 5), (1537, 3, 5120 * 4 + 9), (1100, 50, 5120 * 6),
+                                               (2561, 2, 3072 * 7 + 100), (2100, 33, 3072 * 8)])
 def test_fir_ols4096_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
     """filters of up to 3073 taps on the 4096-point overlap-save (k_fir_ols4k_f32, a whole wave per pair of blocks; overlap
     512 / 1024 / 2048 / 3072 by tap count): two frames, ragged lengths, blocks that end past the frame, and the automatic
