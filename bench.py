@@ -232,7 +232,16 @@ def main():
 
     # long filters on the same batch (weak scaling like the headline): 513 taps on the 2048-point overlap-save, 1025 and
     # 2049 taps on the 4096-point one (the library's own choice) -- under 'also', never part of `value`
-    if not args.no_also and fir_algo == 2:
+    def guarded(label, fn):
+        """the 'also' configs must not cost the headline line: a failure is reported under its label instead"""
+        try:
+            return fn()
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"bench.py: also/{label} failed: {e}\n")
+            return {label: {"error": str(e).splitlines()[0][:200]}}
+
+    def long_fir():
+        res = {}
         for long_taps in (513, 1025, 2049):
             lt = filters.fir_design("lpf", long_taps, 0.1, 0.0, filters.KAISER)
             lf = filters.FirFilterMC(channels, n, lt, stream=stream)
@@ -246,21 +255,26 @@ def main():
             L.llz_hip_timer_stop(tm, sptr)
             lms = shard.max_over_ranks(L.llz_hip_timer_ms(tm) / 3, device=comm_dev)
             L.llz_hip_timer_free(tm)
-            also[f"fir_{long_taps}taps_{channels}ch_per_gpu"] = {
+            res[f"fir_{long_taps}taps_{channels}ch_per_gpu"] = {
                 "Msamples_s": channels * n * world / lms / 1e3, "GBs_per_gpu": BYTES_PER_SAMPLE * channels * n / lms / 1e6,
                 "hbm_frac_per_gpu": BYTES_PER_SAMPLE * channels * n / lms / 1e6 / HBM_PEAK_GBS, "ms": lms,
                 "channels_per_gpu": channels, "scaling": "weak",
                 "algorithm": {4: "overlap-save-2048", 5: "overlap-save-4096"}.get(lf.algo, str(lf.algo))}
             lf.close()
+        return res
+
+    if not args.no_also and fir_algo == 2:
+        also.update(guarded("long_fir", long_fir))
 
     # release the FIR batch before the other configs allocate theirs
     fir.close()
     del x, y
     torch.cuda.empty_cache()
     if not args.no_also:
-        also.update(sharded_configs(torch, filters, capi, shard, dev, comm_dev, stream, rank, world, barrier))
+        also.update(guarded("sharded_configs",
+                            lambda: sharded_configs(torch, filters, capi, shard, dev, comm_dev, stream, rank, world, barrier)))
     if not args.no_also and world == 1:
-        also.update(extra_paths(torch, filters, capi, dev, stream))
+        also.update(guarded("extra_paths", lambda: extra_paths(torch, filters, capi, dev, stream)))
 
     if rank == 0:
         achieved = BYTES_PER_SAMPLE * channels * n / (kern_ms * 1e-3) / 1e9      # GB/s, algorithmic bytes
