@@ -98,7 +98,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=25)
     ap.add_argument("--channels", type=int, default=CHANNELS, help="channels per GPU (weak scaling)")
     ap.add_argument("--samples", type=int, default=N_SAMPLES)
     ap.add_argument("--algo", type=int, default=0, help="0 auto (overlap-save), 1 time domain, 2 overlap-save, 3 time domain on the matrix cores, 4 / 5 overlap-save with\n"
