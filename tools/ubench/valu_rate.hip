@@ -144,6 +144,42 @@ __global__ void __launch_bounds__(256) k(float *out, int iters)
                 asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a6) : "v"(c));
                 asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a7) : "v"(c));
             }
+        } else if (MODE == 13) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a0) : "s"(c), "v"(e));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a1) : "s"(c), "v"(e));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a2) : "s"(c), "v"(e));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a3) : "s"(c), "v"(e));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a4) : "s"(c), "v"(e));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a5) : "s"(c), "v"(e));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a6) : "s"(c), "v"(e));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a7) : "s"(c), "v"(e));
+            }
+        } else if (MODE == 14) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p0) : "s"(c2), "v"(e2));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p1) : "s"(c2), "v"(e2));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p2) : "s"(c2), "v"(e2));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p3) : "s"(c2), "v"(e2));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p4) : "s"(c2), "v"(e2));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p5) : "s"(c2), "v"(e2));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p6) : "s"(c2), "v"(e2));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p7) : "s"(c2), "v"(e2));
+            }
+        } else if (MODE == 15) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p0) : "v"(c2), "v"(e2));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p1) : "v"(c2), "v"(e2));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p2) : "v"(c2), "v"(e2));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p3) : "v"(c2), "v"(e2));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p4) : "v"(c2), "v"(e2));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p5) : "v"(c2), "v"(e2));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p6) : "v"(c2), "v"(e2));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(p7) : "v"(c2), "v"(e2));
+            }
         } else if (MODE == 5) {
             // complex multiply p *= c2 on the packed pipe: t = (p.x c.x, p.x c.y); p = (-p.y c.y + t.x, p.y c.x + t.y)
 #pragma unroll
@@ -224,6 +260,9 @@ int main()
         run<10>("v_mul_f32", w, d);
         run<11>("v_pk_mul_f32", w, d);
         run<12>("v_fma_f32 2rd", w, d);
+        run<13>("v_fmac s,v", w, d);
+        run<14>("v_pk_fma s.xx,v", w, d);
+        run<15>("v_pk_fma v.xx,v", w, d);
     }
     return 0;
 }
