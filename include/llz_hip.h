@@ -35,7 +35,8 @@ void *llz_hip_malloc(size_t bytes);            /* device memory, NULL on failure
 void  llz_hip_free(void *dev_ptr);
 int   llz_hip_upload(void *dev_dst, const void *host_src, size_t bytes);
 int   llz_hip_download(void *host_dst, const void *dev_src, size_t bytes);
-int   llz_hip_is_device_ptr(const void *p);    /* 1 device, 0 host */
+int   llz_hip_is_device_ptr(const void *p);    /* 1: memory of the CURRENT device; 0: host memory; LLZ_ERR_ARG: memory of
+                                                * another GPU (every batch call refuses such a buffer the same way) */
 
 /* counter-hash PCM written straight into device memory, planar [channels][stride]:
  *   u = fmix32(seed ^ (chan0+c)*0x9E3779B9 ^ n*0x85EBCA6B)

@@ -235,6 +235,10 @@ def lib():
     sig("llz_mdct_fixed_uninit", None, ul)
     sig("llz_mdct_fixed", None, ul, ip, ip)
     sig("llz_imdct_fixed", None, ul, ip, ip)
+    sig("llz_mdct_fixed_batch", i, ul, vp, vp, i)
+    sig("llz_imdct_fixed_batch", i, ul, vp, vp, i)
+    sig("llz_mdct_fixed_set_stream", i, ul, vp)
+    sig("llz_mdct_fixed_len", i, ul)
     # llz_shard.h
     pp = C.POINTER(C.c_void_p)
     sig("llz_shard_range", i, i, i, i, ip, ip)

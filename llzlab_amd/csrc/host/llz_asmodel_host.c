@@ -6,7 +6,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include "../../../include/llz_asmodel.h"
-#include "../../../include/llz_fft.h"
 #include "../../../include/llz_mdct.h"
 #include "llz_host.h"
 
@@ -32,22 +31,42 @@ static int asm_window(double *w, int n, win_t win_type)
     }
 }
 
-/* ---- Part 1: reference symbols ---- */
+/* ---- Part 1: the reference's symbols, one channel, one frame per call ----
+ * A handle keeps its running frame buffer, the window and the scratch spectrum in DEVICE memory.  A call copies the new
+ * samples (or the two spectrum planes) in, runs framing kernel -> exact-order transform -> framing kernel on the device
+ * (kernels/frames_f64.hip, kernels/fft.hip), and copies the result out; nothing is computed on the host. */
 
 typedef struct {
-    int tag, frame_len, fft_len;
-    double *x_buf, *fft_buf, *window;
-    unsigned long h_fft;
-    double magic;
+    int tag, device, hop, size, bins;       /* hop = frame_len, size = fft_len, bins = size/2 + 1 */
+    double out_scale;                       /* the reference's empirical 0.812 at 3/4 overlap, 1 at 1/2 */
+    double *d_window, *d_fft_cs;
+    double *d_run[2];                       /* analysis: the last `size` input samples; synthesis: the overlap-add sums */
+    int cur;
+    double *d_spectrum;                     /* size interleaved complex points */
+    double *d_io;                           /* hop samples, or the two planes of bins values */
 } asm1_t;
 
 static void asm1_destroy(asm1_t *f)
 {
     if (!f) return;
-    if (f->h_fft && f->h_fft != LLZ_BAD_HANDLE) llz_fft_uninit(f->h_fft);
-    free(f->x_buf); free(f->fft_buf); free(f->window);
+    llzs_free(f->d_window); llzs_free(f->d_fft_cs); llzs_free(f->d_run[0]); llzs_free(f->d_run[1]);
+    llzs_free(f->d_spectrum); llzs_free(f->d_io);
     f->tag = 0;
     free(f);
+}
+
+static double *upload_f64(const double *host, size_t count)
+{
+    double *dev = (double *)llzs_malloc(sizeof(double) * count);
+    if (dev && llzs_h2d(dev, host, sizeof(double) * count, NULL) != LLZ_OK) { llzs_free(dev); dev = NULL; }
+    return dev;
+}
+
+static double *zeros_f64(size_t count)
+{
+    double *dev = (double *)llzs_malloc(sizeof(double) * count);
+    if (dev && llzs_memset(dev, 0, sizeof(double) * count, NULL) != LLZ_OK) { llzs_free(dev); dev = NULL; }
+    return dev;
 }
 
 static unsigned long asm1_init(int overlap_hint, int frame_len, win_t win_type, const char *who)
@@ -60,18 +79,40 @@ static unsigned long asm1_init(int overlap_hint, int frame_len, win_t win_type, 
         return LLZ_BAD_HANDLE;
     }
     asm1_t *f = (asm1_t *)calloc(1, sizeof(*f));
-    if (!f) return LLZ_BAD_HANDLE;
-    f->tag = LLZ_TAG_ASM1; f->frame_len = frame_len; f->fft_len = fft_len; f->magic = magic;
-    f->x_buf = (double *)calloc((size_t)fft_len, sizeof(double));
-    f->fft_buf = (double *)calloc(2 * (size_t)fft_len, sizeof(double));
-    f->window = (double *)calloc((size_t)fft_len, sizeof(double));
-    f->h_fft = llz_fft_init(fft_len);
-    if (!f->x_buf || !f->fft_buf || !f->window || f->h_fft == LLZ_BAD_HANDLE || !asm_window(f->window, fft_len, win_type)) {
-        if (f->window) llzs_set_error("%s: unknown window %d or FFT handle failed", who, (int)win_type);
-        asm1_destroy(f);
+    double *w = (double *)malloc(sizeof(double) * (size_t)fft_len);
+    int ok = f && w;
+    if (ok && !asm_window(w, fft_len, win_type)) {
+        llzs_set_error("%s: unknown window %d", who, (int)win_type);
+        ok = 0;
+    }
+    if (ok) {
+        f->tag = LLZ_TAG_ASM1; f->device = llzs_device_get();
+        f->hop = frame_len; f->size = fft_len; f->bins = (fft_len >> 1) + 1; f->out_scale = magic;
+        f->d_window = upload_f64(w, (size_t)fft_len);
+        f->d_fft_cs = llz_host_fft_table_f64(fft_len);
+        f->d_run[0] = zeros_f64((size_t)fft_len);
+        f->d_run[1] = zeros_f64((size_t)fft_len);
+        f->d_spectrum = zeros_f64(2 * (size_t)fft_len);
+        f->d_io = zeros_f64(2 * (size_t)f->bins > (size_t)frame_len ? 2 * (size_t)f->bins : (size_t)frame_len);
+        ok = f->device >= 0 && f->d_window && f->d_fft_cs && f->d_run[0] && f->d_run[1] && f->d_spectrum && f->d_io &&
+             llzs_sync(NULL) == LLZ_OK;
+    }
+    free(w);
+    if (!ok) {
+        if (f && f->tag) asm1_destroy(f); else free(f);
         return LLZ_BAD_HANDLE;
     }
     return (unsigned long)f;
+}
+
+static void asm1_uninit(unsigned long handle)
+{
+    if (!LLZ_HANDLE_OK(handle, asm1_t, LLZ_TAG_ASM1)) return;
+    asm1_t *f = (asm1_t *)handle;
+    const int prev = llzs_device_enter(f->device);
+    llzs_sync(NULL);
+    asm1_destroy(f);
+    llzs_device_leave(prev);
 }
 
 unsigned long llz_analysis_fft_init(int overlap_hint, int frame_len, win_t win_type)
@@ -84,16 +125,10 @@ unsigned long llz_synthesis_fft_init(int overlap_hint, int frame_len, win_t win_
     return asm1_init(overlap_hint, frame_len, win_type, "llz_synthesis_fft_init");
 }
 
-void llz_analysis_fft_uninit(unsigned long handle)
-{
-    if (LLZ_HANDLE_OK(handle, asm1_t, LLZ_TAG_ASM1)) asm1_destroy((asm1_t *)handle);
-}
+void llz_analysis_fft_uninit(unsigned long handle) { asm1_uninit(handle); }
+void llz_synthesis_fft_uninit(unsigned long handle) { asm1_uninit(handle); }
 
-void llz_synthesis_fft_uninit(unsigned long handle)
-{
-    if (LLZ_HANDLE_OK(handle, asm1_t, LLZ_TAG_ASM1)) asm1_destroy((asm1_t *)handle);
-}
-
+/* reference llz_asmodel.c:177-203: slide the input buffer by one frame, window, forward transform, bins 0..N/2 */
 void llz_analysis_fft(unsigned long handle, double *x, double *re, double *im)
 {
     if (!LLZ_HANDLE_OK(handle, asm1_t, LLZ_TAG_ASM1) || !x || !re || !im) {
@@ -101,21 +136,21 @@ void llz_analysis_fft(unsigned long handle, double *x, double *re, double *im)
         return;                                                     /* void in the reference ABI */
     }
     asm1_t *f = (asm1_t *)handle;
-    const int F = f->frame_len, N = f->fft_len;
-    /* llz_asmodel.c:188-204, statement for statement; the transform is the product's llz_fft (GPU, exact order) */
-    for (int i = 0; i < N - F; i++) f->x_buf[i] = f->x_buf[i + F];
-    for (int i = 0; i < F; i++) f->x_buf[i + N - F] = x[i];
-    for (int i = 0; i < N; i++) {
-        f->fft_buf[i + i] = f->x_buf[i] * f->window[i];
-        f->fft_buf[i + i + 1] = 0;
-    }
-    llz_fft(f->h_fft, f->fft_buf);
-    for (int i = 0; i < (N >> 1) + 1; i++) {
-        re[i] = f->fft_buf[i + i];
-        im[i] = f->fft_buf[i + i + 1];
-    }
+    const size_t plane = sizeof(double) * (size_t)f->bins;
+    const int prev = llzs_device_enter(f->device);
+    int rc = llzs_h2d(f->d_io, x, sizeof(double) * (size_t)f->hop, NULL);
+    if (rc == LLZ_OK)
+        rc = llzs_frame_slide_window_f64(f->d_io, f->d_run[f->cur], f->d_run[f->cur ^ 1], f->d_window, f->d_spectrum,
+                                         f->size, f->hop, 1, NULL);
+    if (rc == LLZ_OK) f->cur ^= 1;
+    if (rc == LLZ_OK) rc = llzs_fft_f64(f->d_spectrum, f->size, f->d_fft_cs, 0, NULL);
+    if (rc == LLZ_OK) rc = llzs_spectrum_split_f64(f->d_spectrum, f->d_io, f->bins, NULL);
+    if (rc == LLZ_OK) rc = llzs_d2h(re, f->d_io, plane, NULL);
+    if (rc == LLZ_OK) rc = llzs_d2h(im, f->d_io + f->bins, plane, NULL);
+    llzs_device_leave(prev);
 }
 
+/* reference llz_asmodel.c:274-309: conjugate-mirror the half spectrum, inverse transform, window, overlap-add, emit */
 void llz_synthesis_fft(unsigned long handle, double *re, double *im, double *x)
 {
     if (!LLZ_HANDLE_OK(handle, asm1_t, LLZ_TAG_ASM1) || !x || !re || !im) {
@@ -123,41 +158,39 @@ void llz_synthesis_fft(unsigned long handle, double *re, double *im, double *x)
         return;
     }
     asm1_t *f = (asm1_t *)handle;
-    const int F = f->frame_len, N = f->fft_len;
-    /* llz_asmodel.c:279-304 */
-    for (int i = 0; i < (N >> 1) + 1; i++) {
-        f->fft_buf[i + i] = re[i];
-        f->fft_buf[i + i + 1] = im[i];
-    }
-    for (int i = 0, j = (N >> 1) - 1; i < (N >> 1) - 1; i++, j--) {
-        f->fft_buf[N + 2 + 2 * i] = re[j];
-        f->fft_buf[N + 2 + 2 * i + 1] = -im[j];
-    }
-    llz_ifft(f->h_fft, f->fft_buf);
-    for (int i = 0; i < N; i++) {
-        const double t = f->fft_buf[i + i] * f->window[i];          /* rounded product, then rounded add */
-        f->x_buf[i] = f->x_buf[i] + t;
-    }
-    for (int i = 0; i < F; i++) x[i] = f->magic * f->x_buf[i];
-    for (int i = 0; i < N - F; i++) f->x_buf[i] = f->x_buf[i + F];
-    for (int i = 0; i < F; i++) f->x_buf[i + N - F] = 0;
+    const size_t plane = sizeof(double) * (size_t)f->bins;
+    const int prev = llzs_device_enter(f->device);
+    int rc = llzs_h2d(f->d_io, re, plane, NULL);
+    if (rc == LLZ_OK) rc = llzs_h2d(f->d_io + f->bins, im, plane, NULL);
+    if (rc == LLZ_OK) rc = llzs_spectrum_mirror_f64(f->d_io, f->d_spectrum, f->size, NULL);
+    if (rc == LLZ_OK) rc = llzs_fft_f64(f->d_spectrum, f->size, f->d_fft_cs, 1, NULL);
+    if (rc == LLZ_OK)
+        rc = llzs_frame_overlap_add_f64(f->d_spectrum, 2, f->d_window, f->d_run[f->cur], f->d_run[f->cur ^ 1], f->d_io,
+                                        f->size, f->hop, f->out_scale, NULL);
+    if (rc == LLZ_OK) f->cur ^= 1;
+    if (rc == LLZ_OK) rc = llzs_d2h(x, f->d_io, sizeof(double) * (size_t)f->hop, NULL);
+    llzs_device_leave(prev);
 }
 
-/* ---- Part 1b: MDCT frames (llz_asmodel.c:313-463) ---- */
+/* ---- Part 1b: MDCT frames with 50 % overlap (llz_asmodel.c:313-463), same scheme around the device MDCT ---- */
 
 #define LLZ_TAG_ASMD 0x4c5a5344
 
 typedef struct {
-    int tag, frame_len, mdct_len;
-    double *x_buf, *mdct_buf, *window;
-    unsigned long h_mdct;
+    int tag, device, hop, size;             /* hop = frame_len, size = mdct_len = 2 hop */
+    double *d_window;
+    double *d_run[2];                       /* analysis: the last two frames; synthesis: the overlap-add sums */
+    int cur;
+    double *d_frame, *d_coef, *d_io;        /* size windowed samples, hop coefficients, hop samples in / out */
+    unsigned long mdct;                     /* llz_mdct_init(MDCT_FFT4, size): the N/4-point form, llz_asmodel.c:323 */
 } asmd_t;
 
 static void asmd_destroy(asmd_t *f)
 {
     if (!f) return;
-    if (f->h_mdct && f->h_mdct != LLZ_BAD_HANDLE) llz_mdct_uninit(f->h_mdct);
-    free(f->x_buf); free(f->mdct_buf); free(f->window);
+    if (f->mdct && f->mdct != LLZ_BAD_HANDLE) llz_mdct_uninit(f->mdct);
+    llzs_free(f->d_window); llzs_free(f->d_run[0]); llzs_free(f->d_run[1]);
+    llzs_free(f->d_frame); llzs_free(f->d_coef); llzs_free(f->d_io);
     f->tag = 0;
     free(f);
 }
@@ -169,20 +202,40 @@ static unsigned long asmd_init(int frame_len, mdct_win_t win_type, const char *w
         llzs_set_error("%s: frame_len %d (a power of two in 4..8192) window %d", who, frame_len, (int)win_type);
         return LLZ_BAD_HANDLE;
     }
+    const int N = frame_len << 1;
     asmd_t *f = (asmd_t *)calloc(1, sizeof(*f));
-    if (!f) return LLZ_BAD_HANDLE;
-    f->tag = LLZ_TAG_ASMD; f->frame_len = frame_len; f->mdct_len = frame_len << 1;
-    f->x_buf = (double *)calloc((size_t)f->mdct_len, sizeof(double));
-    f->mdct_buf = (double *)calloc((size_t)f->mdct_len, sizeof(double));
-    f->window = (double *)calloc((size_t)f->mdct_len, sizeof(double));
-    f->h_mdct = llz_mdct_init(MDCT_FFT4, f->mdct_len);             /* llz_asmodel.c:323 */
-    if (!f->x_buf || !f->mdct_buf || !f->window || f->h_mdct == LLZ_BAD_HANDLE) {
-        asmd_destroy(f);
+    double *w = (double *)malloc(sizeof(double) * (size_t)N);
+    int ok = f && w;
+    if (ok) {
+        f->tag = LLZ_TAG_ASMD; f->device = llzs_device_get(); f->hop = frame_len; f->size = N;
+        if (win_type == MDCT_SINE) llz_mdct_sine(w, N);
+        else llz_mdct_kbd(w, N, 6);                                  /* llz_asmodel.c:330-331 */
+        f->d_window = upload_f64(w, (size_t)N);
+        f->d_run[0] = zeros_f64((size_t)N);
+        f->d_run[1] = zeros_f64((size_t)N);
+        f->d_frame = zeros_f64((size_t)N);
+        f->d_coef = zeros_f64((size_t)frame_len);
+        f->d_io = zeros_f64((size_t)frame_len);
+        f->mdct = llz_mdct_init(MDCT_FFT4, N);
+        ok = f->device >= 0 && f->d_window && f->d_run[0] && f->d_run[1] && f->d_frame && f->d_coef && f->d_io &&
+             f->mdct != LLZ_BAD_HANDLE && llzs_sync(NULL) == LLZ_OK;
+    }
+    free(w);
+    if (!ok) {
+        if (f && f->tag) asmd_destroy(f); else free(f);
         return LLZ_BAD_HANDLE;
     }
-    if (win_type == MDCT_SINE) llz_mdct_sine(f->window, f->mdct_len);
-    else llz_mdct_kbd(f->window, f->mdct_len, 6);                   /* llz_asmodel.c:330-331 */
     return (unsigned long)f;
+}
+
+static void asmd_uninit(unsigned long handle)
+{
+    if (!LLZ_HANDLE_OK(handle, asmd_t, LLZ_TAG_ASMD)) return;
+    asmd_t *f = (asmd_t *)handle;
+    const int prev = llzs_device_enter(f->device);
+    llzs_sync(NULL);
+    asmd_destroy(f);
+    llzs_device_leave(prev);
 }
 
 unsigned long llz_analysis_mdct_init(int frame_len, mdct_win_t win_type)
@@ -195,16 +248,10 @@ unsigned long llz_synthesis_mdct_init(int frame_len, mdct_win_t win_type)
     return asmd_init(frame_len, win_type, "llz_synthesis_mdct_init");
 }
 
-void llz_analysis_mdct_uninit(unsigned long handle)
-{
-    if (LLZ_HANDLE_OK(handle, asmd_t, LLZ_TAG_ASMD)) asmd_destroy((asmd_t *)handle);
-}
+void llz_analysis_mdct_uninit(unsigned long handle) { asmd_uninit(handle); }
+void llz_synthesis_mdct_uninit(unsigned long handle) { asmd_uninit(handle); }
 
-void llz_synthesis_mdct_uninit(unsigned long handle)
-{
-    if (LLZ_HANDLE_OK(handle, asmd_t, LLZ_TAG_ASMD)) asmd_destroy((asmd_t *)handle);
-}
-
+/* reference llz_asmodel.c:365-383 */
 void llz_analysis_mdct(unsigned long handle, double *x, double *X)
 {
     if (!LLZ_HANDLE_OK(handle, asmd_t, LLZ_TAG_ASMD) || !x || !X) {
@@ -212,13 +259,19 @@ void llz_analysis_mdct(unsigned long handle, double *x, double *X)
         return;
     }
     asmd_t *f = (asmd_t *)handle;
-    const int F = f->frame_len;
-    for (int i = 0; i < F; i++) f->x_buf[i] = f->x_buf[i + F];      /* llz_asmodel.c:365-376 */
-    for (int i = 0; i < F; i++) f->x_buf[i + F] = x[i];
-    for (int i = 0; i < f->mdct_len; i++) f->mdct_buf[i] = f->x_buf[i] * f->window[i];
-    llz_mdct(f->h_mdct, f->mdct_buf, X);
+    const size_t frame = sizeof(double) * (size_t)f->hop;
+    const int prev = llzs_device_enter(f->device);
+    int rc = llzs_h2d(f->d_io, x, frame, NULL);
+    if (rc == LLZ_OK)
+        rc = llzs_frame_slide_window_f64(f->d_io, f->d_run[f->cur], f->d_run[f->cur ^ 1], f->d_window, f->d_frame,
+                                         f->size, f->hop, 0, NULL);
+    if (rc == LLZ_OK) f->cur ^= 1;
+    if (rc == LLZ_OK) rc = llz_host_mdct_on_device(f->mdct, f->d_frame, f->d_coef, 0);
+    if (rc == LLZ_OK) rc = llzs_d2h(X, f->d_coef, frame, NULL);
+    llzs_device_leave(prev);
 }
 
+/* reference llz_asmodel.c:440-462 */
 void llz_synthesis_mdct(unsigned long handle, double *X, double *x)
 {
     if (!LLZ_HANDLE_OK(handle, asmd_t, LLZ_TAG_ASMD) || !x || !X) {
@@ -226,21 +279,22 @@ void llz_synthesis_mdct(unsigned long handle, double *X, double *x)
         return;
     }
     asmd_t *f = (asmd_t *)handle;
-    const int F = f->frame_len;
-    llz_imdct(f->h_mdct, X, f->mdct_buf);                           /* llz_asmodel.c:446-461 */
-    for (int i = 0; i < f->mdct_len; i++) {
-        const double t = f->mdct_buf[i] * f->window[i];
-        f->x_buf[i] = f->x_buf[i] + t;
-    }
-    for (int i = 0; i < F; i++) x[i] = f->x_buf[i];
-    for (int i = 0; i < F; i++) f->x_buf[i] = f->x_buf[i + F];
-    for (int i = 0; i < F; i++) f->x_buf[i + F] = 0;
+    const size_t frame = sizeof(double) * (size_t)f->hop;
+    const int prev = llzs_device_enter(f->device);
+    int rc = llzs_h2d(f->d_coef, X, frame, NULL);
+    if (rc == LLZ_OK) rc = llz_host_mdct_on_device(f->mdct, f->d_coef, f->d_frame, 1);
+    if (rc == LLZ_OK)
+        rc = llzs_frame_overlap_add_f64(f->d_frame, 1, f->d_window, f->d_run[f->cur], f->d_run[f->cur ^ 1], f->d_io,
+                                        f->size, f->hop, 1.0, NULL);
+    if (rc == LLZ_OK) f->cur ^= 1;
+    if (rc == LLZ_OK) rc = llzs_d2h(x, f->d_io, frame, NULL);
+    llzs_device_leave(prev);
 }
 
 /* ---- Part 2: batch extension ---- */
 
 typedef struct {
-    int tag, channels, frame_len, fft_len, bins;
+    int tag, device, channels, frame_len, fft_len, bins;
     float magic;
     float *d_w, *d_cs;
     float *d_hist[2], *d_ola[2];        /* analysis history / synthesis overlap-add tail: [channels][fft_len-frame_len] */
@@ -277,7 +331,7 @@ unsigned long llz_stft_mc_init(int channels, int overlap_hint, int frame_len, wi
         rc = LLZ_ERR_ARG;
     }
     if (rc == LLZ_OK) {
-        f->tag = LLZ_TAG_ASMM; f->channels = channels; f->frame_len = frame_len; f->fft_len = N; f->bins = N / 2 + 1;
+        f->tag = LLZ_TAG_ASMM; f->device = llzs_device_get(); f->channels = channels; f->frame_len = frame_len; f->fft_len = N; f->bins = N / 2 + 1;
         f->magic = (float)magic;
         for (int i = 0; i < N; i++) {
             const double ang = (double)(2 * M_PI * i) / N;          /* table of llz_fft_init, llz_fft.c:222-229 */
@@ -312,8 +366,10 @@ unsigned long llz_stft_mc_init(int channels, int overlap_hint, int frame_len, wi
 void llz_stft_mc_uninit(unsigned long handle)
 {
     if (LLZ_HANDLE_OK(handle, asmm_t, LLZ_TAG_ASMM)) {
+        const int prev = llzs_device_enter(((asmm_t *)handle)->device);
         llzs_sync(((asmm_t *)handle)->stream);
         asmm_destroy((asmm_t *)handle);
+        llzs_device_leave(prev);
     }
 }
 
@@ -337,17 +393,19 @@ static int asmm_stage(asmm_t *f, const float *x, const float *re, const float *i
     const size_t sb = sizeof(float) * (size_t)f->channels * frames * f->bins;
     int rc = LLZ_OK;
     *dx = (float *)x; *dre = (float *)re; *dim = (float *)im;
-    if (!llzs_is_device_ptr(x)) {
+    const int x_dev = llzs_is_device_ptr(x), re_dev = llzs_is_device_ptr(re), im_dev = llzs_is_device_ptr(im);
+    if (x_dev < 0 || re_dev < 0 || im_dev < 0) return LLZ_ERR_ARG;
+    if (!x_dev) {
         *dx = (float *)llz_stage_reserve(&f->st_x, xb);
         if (!*dx) return LLZ_ERR_NOMEM;
         if (x_is_input) rc = llzs_h2d(*dx, x, xb, f->stream);
     }
-    if (rc == LLZ_OK && !llzs_is_device_ptr(re)) {
+    if (rc == LLZ_OK && !re_dev) {
         *dre = (float *)llz_stage_reserve(&f->st_re, sb);
         if (!*dre) return LLZ_ERR_NOMEM;
         if (!x_is_input) rc = llzs_h2d(*dre, re, sb, f->stream);
     }
-    if (rc == LLZ_OK && !llzs_is_device_ptr(im)) {
+    if (rc == LLZ_OK && !im_dev) {
         *dim = (float *)llz_stage_reserve(&f->st_im, sb);
         if (!*dim) return LLZ_ERR_NOMEM;
         if (!x_is_input) rc = llzs_h2d(*dim, im, sb, f->stream);
@@ -364,6 +422,7 @@ int llz_stft_mc_analysis(unsigned long handle, const float *x, float *re, float 
     asmm_t *f = (asmm_t *)handle;
     const long n = (long)frames * f->frame_len;
     float *dx, *dre, *dim;
+    const int prev = llzs_device_enter(f->device);
     int rc = asmm_stage(f, x, re, im, frames, 1, &dx, &dre, &dim);
     if (rc == LLZ_OK)
         rc = llzs_stft_analysis_f32(dx, f->d_hist[f->cur_hist], dre, dim, f->d_w, f->d_cs, f->channels, frames,
@@ -376,6 +435,7 @@ int llz_stft_mc_analysis(unsigned long handle, const float *x, float *re, float 
     const size_t sb = sizeof(float) * (size_t)f->channels * frames * f->bins;
     if (rc == LLZ_OK && dre != re) rc = llzs_d2h(re, dre, sb, f->stream);
     if (rc == LLZ_OK && dim != im) rc = llzs_d2h(im, dim, sb, f->stream);
+    llzs_device_leave(prev);
     return rc == LLZ_OK ? frames : rc;
 }
 
@@ -388,12 +448,14 @@ int llz_stft_mc_synthesis(unsigned long handle, const float *re, const float *im
     asmm_t *f = (asmm_t *)handle;
     const long n = (long)frames * f->frame_len;
     float *dx, *dre, *dim;
+    const int prev = llzs_device_enter(f->device);
     int rc = asmm_stage(f, x, re, im, frames, 0, &dx, &dre, &dim);
     if (rc == LLZ_OK)
         rc = llzs_stft_synthesis_f32(dre, dim, dx, f->d_ola[f->cur_ola], f->d_ola[f->cur_ola ^ 1], f->d_w, f->d_cs,
                                      f->channels, frames, f->frame_len, f->fft_len, n, f->magic, f->stream);
     if (rc == LLZ_OK) f->cur_ola ^= 1;
     if (rc == LLZ_OK && dx != x) rc = llzs_d2h(x, dx, sizeof(float) * (size_t)f->channels * n, f->stream);
+    llzs_device_leave(prev);
     return rc == LLZ_OK ? frames : rc;
 }
 
@@ -405,7 +467,7 @@ int llz_stft_mc_synthesis(unsigned long handle, const float *re, const float *im
 #define LLZ_TAG_AMDM 0x4c5a4d4d
 
 typedef struct {
-    int tag, channels, frame_len, mdct_len;
+    int tag, device, channels, frame_len, mdct_len;
     float *d_w, *d_tc, *d_ts, *d_cs;
     float *d_prev[2], *d_tail[2];       /* analysis: the previous frame; synthesis: the overlap-add tail; [channels][frame_len] */
     int cur_prev, cur_tail;
@@ -437,7 +499,7 @@ unsigned long llz_mdct_frames_mc_init(int channels, int frame_len, mdct_win_t wi
     float *tab = (float *)malloc(sizeof(float) * ((size_t)N + 4 * (size_t)N4));
     int rc = (f && w && tab) ? LLZ_OK : LLZ_ERR_NOMEM;
     if (rc == LLZ_OK) {
-        f->tag = LLZ_TAG_AMDM; f->channels = channels; f->frame_len = frame_len; f->mdct_len = N;
+        f->tag = LLZ_TAG_AMDM; f->device = llzs_device_get(); f->channels = channels; f->frame_len = frame_len; f->mdct_len = N;
         if (win_type == MDCT_SINE) llz_mdct_sine(w, N); else llz_mdct_kbd(w, N, 6);     /* llz_asmodel.c:327-334 */
         float *tw = tab + N;
         for (int i = 0; i < N; i++) tab[i] = (float)w[i];
@@ -480,8 +542,10 @@ unsigned long llz_mdct_frames_mc_init(int channels, int frame_len, mdct_win_t wi
 void llz_mdct_frames_mc_uninit(unsigned long handle)
 {
     if (LLZ_HANDLE_OK(handle, amdm_t, LLZ_TAG_AMDM)) {
+        const int prev = llzs_device_enter(((amdm_t *)handle)->device);
         llzs_sync(((amdm_t *)handle)->stream);
         amdm_destroy((amdm_t *)handle);
+        llzs_device_leave(prev);
     }
 }
 
@@ -500,14 +564,16 @@ static int amdm_run(unsigned long handle, const float *in, float *out, int frame
     }
     amdm_t *f = (amdm_t *)handle;
     const size_t bytes = sizeof(float) * (size_t)f->channels * (size_t)frames * (size_t)f->frame_len;   /* both sides */
+    const int prev = llzs_device_enter(f->device);
+    const int in_dev = llzs_is_device_ptr(in), out_dev = llzs_is_device_ptr(out);
     const float *d_in = in;
     float *d_out = out;
-    int rc = LLZ_OK;
-    if (!llzs_is_device_ptr(in)) {
+    int rc = (in_dev < 0 || out_dev < 0) ? LLZ_ERR_ARG : LLZ_OK;
+    if (rc == LLZ_OK && !in_dev) {
         d_in = (const float *)llz_stage_reserve(inverse ? &f->st_X : &f->st_x, bytes);
         rc = d_in ? llzs_h2d((void *)d_in, in, bytes, f->stream) : LLZ_ERR_NOMEM;
     }
-    if (rc == LLZ_OK && !llzs_is_device_ptr(out)) {
+    if (rc == LLZ_OK && !out_dev) {
         d_out = (float *)llz_stage_reserve(inverse ? &f->st_x : &f->st_X, bytes);
         if (!d_out) rc = LLZ_ERR_NOMEM;
     }
@@ -517,7 +583,8 @@ static int amdm_run(unsigned long handle, const float *in, float *out, int frame
         rc = llzs_mdct4_frames_f32(d_in, d_out, f->channels, frames, f->mdct_len, f->d_tc, f->d_ts, f->d_cs, f->d_w, st[*cur],
                                    st[*cur ^ 1], inverse, f->stream);
     if (rc == LLZ_OK) *cur ^= 1;
-    if (rc == LLZ_OK && d_out != out) rc = llzs_d2h(out, d_out, bytes, f->stream);
+    if (rc == LLZ_OK && !out_dev) rc = llzs_d2h(out, d_out, bytes, f->stream);
+    llzs_device_leave(prev);
     return rc == LLZ_OK ? frames : rc;
 }
 

@@ -123,6 +123,7 @@ int llz_autocorr_mc(const float *x, float *r, int frames, int n, int p, void *st
     }
     const size_t xb = sizeof(float) * (size_t)frames * n, rb = sizeof(float) * (size_t)frames * (p + 1);
     const int x_dev = llzs_is_device_ptr(x), r_dev = llzs_is_device_ptr(r);
+    if (x_dev < 0 || r_dev < 0) return LLZ_ERR_ARG;               /* device memory of a GPU that is not current */
     float *d_x = (float *)x, *d_r = r;
     int rc = LLZ_OK;
     if (!x_dev) {
@@ -141,7 +142,7 @@ int llz_autocorr_mc(const float *x, float *r, int frames, int n, int p, void *st
 }
 
 typedef struct {
-    int tag, frames, n, fft_len;
+    int tag, device, frames, n, fft_len;
     float *d_cs;            /* fft_len cos then fft_len sin */
     void *stream;
     llz_stage_t st_in, st_out;
@@ -164,7 +165,7 @@ unsigned long llz_autocorr_fast_mc_init(int frames, int n)
     }
     acfm_t *f = (acfm_t *)calloc(1, sizeof(*f));
     if (!f) return LLZ_BAD_HANDLE;
-    f->tag = LLZ_TAG_ACFM; f->frames = frames; f->n = n; f->fft_len = acf_fft_len(n);
+    f->tag = LLZ_TAG_ACFM; f->device = llzs_device_get(); f->frames = frames; f->n = n; f->fft_len = acf_fft_len(n);
     const int F = f->fft_len;
     float *cs = (float *)malloc(sizeof(float) * 2 * (size_t)F);
     int rc = cs ? LLZ_OK : LLZ_ERR_NOMEM;
@@ -188,8 +189,10 @@ unsigned long llz_autocorr_fast_mc_init(int frames, int n)
 void llz_autocorr_fast_mc_uninit(unsigned long handle)
 {
     if (LLZ_HANDLE_OK(handle, acfm_t, LLZ_TAG_ACFM)) {
+        const int prev = llzs_device_enter(((acfm_t *)handle)->device);
         llzs_sync(((acfm_t *)handle)->stream);
         acfm_destroy((acfm_t *)handle);
+        llzs_device_leave(prev);
     }
 }
 
@@ -212,11 +215,12 @@ int llz_autocorr_fast_mc(unsigned long handle, const float *x, float *r, int p)
         return LLZ_ERR_ARG;
     }
     const size_t xb = sizeof(float) * (size_t)f->frames * f->n, rb = sizeof(float) * (size_t)f->frames * (p + 1);
+    const int prev = llzs_device_enter(f->device);
     const int x_dev = llzs_is_device_ptr(x), r_dev = llzs_is_device_ptr(r);
     const float *d_x = x;
     float *d_r = r;
-    int rc = LLZ_OK;
-    if (!x_dev) {
+    int rc = (x_dev < 0 || r_dev < 0) ? LLZ_ERR_ARG : LLZ_OK;     /* a buffer of another GPU: refused, message set */
+    if (rc == LLZ_OK && !x_dev) {
         d_x = (const float *)llz_stage_reserve(&f->st_in, xb);
         rc = d_x ? llzs_h2d((void *)d_x, x, xb, f->stream) : LLZ_ERR_NOMEM;
     }
@@ -227,5 +231,6 @@ int llz_autocorr_fast_mc(unsigned long handle, const float *x, float *r, int p)
     /* pack -> FFT -> |X|^2 (first n bins) -> IFFT -> 2 Re, fused in LDS */
     if (rc == LLZ_OK) rc = llzs_acf_fused_f32(d_x, d_r, f->frames, f->n, p, f->fft_len, f->d_cs, f->stream);
     if (rc == LLZ_OK && !r_dev) rc = llzs_d2h(r, d_r, rb, f->stream);
+    llzs_device_leave(prev);
     return rc;
 }

@@ -18,10 +18,29 @@ static int is_pow2_in_range(int size, int lo, int hi)
 /* ---- double, single transform ---- */
 
 typedef struct {
-    int tag, size;
+    int tag, size, device;
     double *d_cs;       /* size cos then size sin */
     double *d_data;     /* 2*size doubles */
 } fft1_t;
+
+double *llz_host_fft_table_f64(int size)
+{
+    double *cs = (double *)malloc(sizeof(double) * 2 * (size_t)size);
+    double *dev = (double *)llzs_malloc(sizeof(double) * 2 * (size_t)size);
+    if (cs && dev) {
+        for (int i = 0; i < size; i++) {
+            const double ang = (double)(2 * M_PI * i) / size;    /* llz_fft.c:223-227 */
+            cs[i] = cos(ang);
+            cs[size + i] = sin(ang);
+        }
+        if (llzs_h2d(dev, cs, sizeof(double) * 2 * (size_t)size, NULL) != LLZ_OK) { llzs_free(dev); dev = NULL; }
+    } else {
+        llzs_free(dev);
+        dev = NULL;
+    }
+    free(cs);
+    return dev;
+}
 
 unsigned long llz_fft_init(int size)
 {
@@ -30,19 +49,11 @@ unsigned long llz_fft_init(int size)
         return LLZ_BAD_HANDLE;
     }
     fft1_t *f = (fft1_t *)calloc(1, sizeof(*f));
-    double *cs = (double *)malloc(sizeof(double) * 2 * (size_t)size);
-    if (!f || !cs) { free(f); free(cs); return LLZ_BAD_HANDLE; }
-    f->tag = LLZ_TAG_FFT1; f->size = size;
-    for (int i = 0; i < size; i++) {
-        const double ang = (double)(2 * M_PI * i) / size;        /* llz_fft.c:223-227 */
-        cs[i] = cos(ang);
-        cs[size + i] = sin(ang);
-    }
-    f->d_cs = (double *)llzs_malloc(sizeof(double) * 2 * (size_t)size);
+    if (!f) return LLZ_BAD_HANDLE;
+    f->tag = LLZ_TAG_FFT1; f->size = size; f->device = llzs_device_get();
+    f->d_cs = llz_host_fft_table_f64(size);
     f->d_data = (double *)llzs_malloc(sizeof(double) * 2 * (size_t)size);
-    const int ok = f->d_cs && f->d_data && llzs_h2d(f->d_cs, cs, sizeof(double) * 2 * (size_t)size, NULL) == LLZ_OK;
-    free(cs);
-    if (!ok) {
+    if (!f->d_cs || !f->d_data || f->device < 0) {
         llzs_free(f->d_cs); llzs_free(f->d_data); free(f);
         return LLZ_BAD_HANDLE;
     }
@@ -53,7 +64,10 @@ void llz_fft_uninit(unsigned long handle)
 {
     if (!LLZ_HANDLE_OK(handle, fft1_t, LLZ_TAG_FFT1)) return;
     fft1_t *f = (fft1_t *)handle;
+    const int prev = llzs_device_enter(f->device);
+    llzs_sync(NULL);
     llzs_free(f->d_cs); llzs_free(f->d_data);
+    llzs_device_leave(prev);
     f->tag = 0;
     free(f);
 }
@@ -66,9 +80,11 @@ static void fft1_run(unsigned long handle, double *data, int inverse)
     }
     fft1_t *f = (fft1_t *)handle;
     const size_t bytes = sizeof(double) * 2 * (size_t)f->size;
-    if (llzs_h2d(f->d_data, data, bytes, NULL) != LLZ_OK) return;
-    if (llzs_fft_f64(f->d_data, f->size, f->d_cs, inverse, NULL) != LLZ_OK) return;
-    (void)llzs_d2h(data, f->d_data, bytes, NULL);
+    const int prev = llzs_device_enter(f->device);
+    int rc = llzs_h2d(f->d_data, data, bytes, NULL);
+    if (rc == LLZ_OK) rc = llzs_fft_f64(f->d_data, f->size, f->d_cs, inverse, NULL);
+    if (rc == LLZ_OK) (void)llzs_d2h(data, f->d_data, bytes, NULL);
+    llzs_device_leave(prev);
 }
 
 void llz_fft(unsigned long handle, double *data)  { fft1_run(handle, data, 0); }
@@ -77,7 +93,7 @@ void llz_ifft(unsigned long handle, double *data) { fft1_run(handle, data, 1); }
 /* ---- float32 batch ---- */
 
 typedef struct {
-    int tag, size;
+    int tag, size, device;
     float *d_cs;
     void *stream;
     llz_stage_t st;
@@ -92,7 +108,7 @@ unsigned long llz_fft_batch_init(int size)
     fftb_t *f = (fftb_t *)calloc(1, sizeof(*f));
     float *cs = (float *)malloc(sizeof(float) * 2 * (size_t)size);
     if (!f || !cs) { free(f); free(cs); return LLZ_BAD_HANDLE; }
-    f->tag = LLZ_TAG_FFTB; f->size = size;
+    f->tag = LLZ_TAG_FFTB; f->size = size; f->device = llzs_device_get();
     for (int i = 0; i < size; i++) {
         const double ang = (double)(2 * M_PI * i) / size;
         cs[i] = (float)cos(ang);
@@ -109,9 +125,11 @@ void llz_fft_batch_uninit(unsigned long handle)
 {
     if (!LLZ_HANDLE_OK(handle, fftb_t, LLZ_TAG_FFTB)) return;
     fftb_t *f = (fftb_t *)handle;
+    const int prev = llzs_device_enter(f->device);
     llzs_sync(f->stream);
     llzs_free(f->d_cs);
     llz_stage_release(&f->st);
+    llzs_device_leave(prev);
     f->tag = 0;
     free(f);
 }
@@ -131,13 +149,18 @@ static int fftb_run(unsigned long handle, float *data, int count, int inverse)
     }
     fftb_t *f = (fftb_t *)handle;
     const size_t bytes = sizeof(float) * 2 * (size_t)f->size * (size_t)count;
-    if (llzs_is_device_ptr(data))
-        return llzs_fft_f32(data, count, f->size, f->d_cs, inverse, f->stream);
-    float *d = (float *)llz_stage_reserve(&f->st, bytes);
-    if (!d) return LLZ_ERR_NOMEM;
-    int rc = llzs_h2d(d, data, bytes, f->stream);
-    if (rc == LLZ_OK) rc = llzs_fft_f32(d, count, f->size, f->d_cs, inverse, f->stream);
-    if (rc == LLZ_OK) rc = llzs_d2h(data, d, bytes, f->stream);
+    const int prev = llzs_device_enter(f->device);
+    const int on_dev = llzs_is_device_ptr(data);
+    int rc = on_dev < 0 ? LLZ_ERR_ARG : LLZ_OK;
+    if (rc == LLZ_OK && on_dev) {
+        rc = llzs_fft_f32(data, count, f->size, f->d_cs, inverse, f->stream);
+    } else if (rc == LLZ_OK) {
+        float *d = (float *)llz_stage_reserve(&f->st, bytes);
+        rc = d ? llzs_h2d(d, data, bytes, f->stream) : LLZ_ERR_NOMEM;
+        if (rc == LLZ_OK) rc = llzs_fft_f32(d, count, f->size, f->d_cs, inverse, f->stream);
+        if (rc == LLZ_OK) rc = llzs_d2h(data, d, bytes, f->stream);
+    }
+    llzs_device_leave(prev);
     return rc;
 }
 
@@ -147,7 +170,7 @@ int llz_ifft_batch(unsigned long handle, float *data, int count) { return fftb_r
 /* ---- fixed point ---- */
 
 typedef struct {
-    int tag, size;
+    int tag, size, device;
     short *d_cs;
     void *stream;
     llz_stage_t st;
@@ -173,7 +196,7 @@ unsigned long llz_fft_fixed_init(int size)
     fftx_t *f = (fftx_t *)calloc(1, sizeof(*f));
     short *cs = (short *)malloc(sizeof(short) * 2 * (size_t)size);
     if (!f || !cs) { free(f); free(cs); return LLZ_BAD_HANDLE; }
-    f->tag = LLZ_TAG_FFTX; f->size = size;
+    f->tag = LLZ_TAG_FFTX; f->size = size; f->device = llzs_device_get();
     for (int i = 0; i < size; i++) {
         const double ang = (2 * M_PI * i) / size;                 /* llz_fft_fixed.c:243-247 */
         cs[i] = q15_round(cos(ang));
@@ -190,9 +213,11 @@ void llz_fft_fixed_uninit(unsigned long handle)
 {
     if (!LLZ_HANDLE_OK(handle, fftx_t, LLZ_TAG_FFTX)) return;
     fftx_t *f = (fftx_t *)handle;
+    const int prev = llzs_device_enter(f->device);
     llzs_sync(f->stream);
     llzs_free(f->d_cs);
     llz_stage_release(&f->st);
+    llzs_device_leave(prev);
     f->tag = 0;
     free(f);
 }
@@ -212,13 +237,18 @@ static int fftx_run(unsigned long handle, int *data, int count, int inverse)
     }
     fftx_t *f = (fftx_t *)handle;
     const size_t bytes = sizeof(int) * 2 * (size_t)f->size * (size_t)count;
-    if (llzs_is_device_ptr(data))
-        return llzs_fft_fixed(data, count, f->size, f->d_cs, inverse, f->stream);
-    int *d = (int *)llz_stage_reserve(&f->st, bytes);
-    if (!d) return LLZ_ERR_NOMEM;
-    int rc = llzs_h2d(d, data, bytes, f->stream);
-    if (rc == LLZ_OK) rc = llzs_fft_fixed(d, count, f->size, f->d_cs, inverse, f->stream);
-    if (rc == LLZ_OK) rc = llzs_d2h(data, d, bytes, f->stream);
+    const int prev = llzs_device_enter(f->device);
+    const int on_dev = llzs_is_device_ptr(data);
+    int rc = on_dev < 0 ? LLZ_ERR_ARG : LLZ_OK;
+    if (rc == LLZ_OK && on_dev) {
+        rc = llzs_fft_fixed(data, count, f->size, f->d_cs, inverse, f->stream);
+    } else if (rc == LLZ_OK) {
+        int *d = (int *)llz_stage_reserve(&f->st, bytes);
+        rc = d ? llzs_h2d(d, data, bytes, f->stream) : LLZ_ERR_NOMEM;
+        if (rc == LLZ_OK) rc = llzs_fft_fixed(d, count, f->size, f->d_cs, inverse, f->stream);
+        if (rc == LLZ_OK) rc = llzs_d2h(data, d, bytes, f->stream);
+    }
+    llzs_device_leave(prev);
     return rc;
 }
 

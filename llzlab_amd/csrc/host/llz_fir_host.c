@@ -522,6 +522,7 @@ static int firm_process(firm_t *f, const float *in, float *out, int frame_len)
     }
     const size_t bytes = sizeof(float) * (size_t)f->channels * (size_t)frame_len;
     const int in_dev = llzs_is_device_ptr(in), out_dev = llzs_is_device_ptr(out);
+    if (in_dev < 0 || out_dev < 0) return LLZ_ERR_ARG;            /* a buffer of another GPU: refused, message set */
     const float *d_in = in;
     float *d_out = out;
     int rc = LLZ_OK;
@@ -558,6 +559,7 @@ static int firm_flush(firm_t *f, float *out)
     if (keep == 0) return 0;
     const size_t bytes = sizeof(float) * (size_t)f->channels * (size_t)keep;
     const int out_dev = llzs_is_device_ptr(out);
+    if (out_dev < 0) return LLZ_ERR_ARG;
     float *d_out = out;
     if (!out_dev) {
         d_out = (float *)llz_stage_reserve(&f->st_out, bytes);

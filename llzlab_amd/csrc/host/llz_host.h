@@ -22,6 +22,16 @@ enum {
 
 #define LLZ_HANDLE_OK(h, type, tagv) ((h) != 0 && (h) != LLZ_BAD_HANDLE && ((type *)(h))->tag == (tagv))
 
+/* one frame of a llz_mdct_init() handle between two device buffers of doubles (llz_mdct_host.c; used by the frame handles
+ * of llz_asmodel_host.c): forward N samples -> N/2 coefficients, inverse the other way; d_src != d_dst */
+int llz_host_mdct_on_device(unsigned long handle, const double *d_src, double *d_dst, int inverse);
+/* cos then sin of 2 pi i / size, i < size, as llz_fft_init builds them (llz_fft.c:222-229), uploaded; NULL on failure */
+double *llz_host_fft_table_f64(int size);
+
+/* Caller buffers: llzs_is_device_ptr(p) is 1 for device memory of the CURRENT device (used in place), 0 for host memory
+ * (staged through the GPU) and LLZ_ERR_ARG, with a message, for device memory that lives on another device -- a handle
+ * binds its device before it looks at the caller's pointers, so a buffer of the wrong GPU is refused instead of faulting. */
+
 /* staging buffers for callers that hand over host memory */
 typedef struct {
     void *dev;

@@ -470,6 +470,7 @@ static int iirm_process(iirm_t *f, const float *x, float *y, int frame_len)
 {
     const size_t bytes = sizeof(float) * (size_t)f->channels * (size_t)frame_len;
     const int in_dev = llzs_is_device_ptr(x), out_dev = llzs_is_device_ptr(y);
+    if (in_dev < 0 || out_dev < 0) return LLZ_ERR_ARG;            /* a buffer of another GPU: refused, message set */
     const float *d_in = x;
     float *d_out = y;
     int rc = LLZ_OK;

@@ -1,20 +1,36 @@
 /*
  * llz_mdct_fixed_host.c -- handle layer of the fixed-point MDCT (fixed half): the reference's
- * symbols (reference libllzfilter/llz_mdct_fixed.c:116-526).  Statement order and macros are the reference's; int32
- * additions are written on unsigned operands so that the wrap-around the reference relies on is defined behaviour.
+ * symbols (reference libllzfilter/llz_mdct_fixed.h:24-28, llz_mdct_fixed.c:116-526) and their batch form.
+ *
+ * The host builds the Q15 tables (libm + the reference's rounding macro, so the table entries are the reference's to the
+ * last bit), uploads them once, and moves frames; all arithmetic on the data runs on the device (kernels/mdct_q15.hip
+ * around the bit-exact Q15 transform of kernels/fft.hip).  One handle serves one frame per call through the reference's
+ * symbols and `count` frames per call through llz_mdct_fixed_batch / llz_imdct_fixed_batch.
  */
 #include <math.h>
-#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #include "../../../include/llz_mdct_fixed.h"
-#include "../../../include/llz_fft_fixed.h"
 #include "llz_host.h"
 
 #define LLZ_TAG_MDCX 0x4c5a4d58
 
-/* LLZ_FIX15 (llz_fft_fixed.h:42-66): round half away from zero of v * 2^15, saturate to int32, clip to +-32767 */
-static short fix15(double v)
+enum { STEP_FWD_PRE = 0, STEP_FWD_POST = 1, STEP_INV_PRE = 2, STEP_INV_POST = 3 };
+
+typedef struct {
+    int tag, form, length, device;
+    int fft_size;                       /* points of the transform inside the two FFT forms */
+    int cof;                            /* Q15 1 / sqrt(length): the N/4-point form's inverse scale */
+    short *d_sum_fwd, *d_sum_inv;       /* MDCT_FIXED_ORIGIN: [N/2][N] and [N][N/2] Q15 cosine matrices */
+    short *d_step[4];                   /* FFT forms: (cos, sin) Q15 pair tables of the four twiddle steps */
+    short *d_fft_cs;                    /* fft_size cos then fft_size sin, Q15 (llz_fft_fixed.c:243-247) */
+    llz_stage_t time, bins, work;       /* device frames: count x N samples, count x N/2 coefficients, count x points */
+    void *stream;
+} mdcx_t;
+
+/* LLZ_FIX15 of the reference (llz_fft_fixed.h:42-66): v * 2^15 rounded half away from zero, saturated to int32, clipped to
+ * +-32767 */
+static short q15_of(double v)
 {
     const double t = v * (double)(1 << 15);
     const double r = (t > 0) ? floor(t + 0.5) : ceil(t - 0.5);
@@ -23,34 +39,104 @@ static short fix15(double v)
     if (q < -32767) q = -32767;
     return (short)q;
 }
-/* LLZ_FIXMUL_32X15 (llz_fft_fixed.h:67) */
-static inline int fixmul(int a, int b) { return (int)(((int64_t)a * (int64_t)b) >> 15); }
-static inline int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
-static inline int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
-static inline int wneg(int a) { return (int)(0u - (unsigned)a); }
-static inline int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
-
-typedef struct {
-    int tag, type, length;
-    unsigned long h_fft;
-    int *fft_buf, *rot;
-    short *d_cos_pos, *d_cos_inv;           /* type 0: Q15 cosine matrices on the device */
-    int *d_x, *d_y;
-    short *pre_c_pos, *pre_s_pos, *c_pos, *s_pos, *pre_c_inv, *pre_s_inv, *c_inv, *s_inv;
-    short *tw_c, *tw_s, sqrt_cof;
-} mdcx_t;
 
 static void mdcx_destroy(mdcx_t *f)
 {
     if (!f) return;
-    if (f->h_fft && f->h_fft != LLZ_BAD_HANDLE) llz_fft_fixed_uninit(f->h_fft);
-    free(f->fft_buf); free(f->rot);
-    llzs_free(f->d_cos_pos); llzs_free(f->d_cos_inv); llzs_free(f->d_x); llzs_free(f->d_y);
-    free(f->pre_c_pos); free(f->pre_s_pos); free(f->c_pos); free(f->s_pos);
-    free(f->pre_c_inv); free(f->pre_s_inv); free(f->c_inv); free(f->s_inv);
-    free(f->tw_c); free(f->tw_s);
+    llzs_free(f->d_sum_fwd); llzs_free(f->d_sum_inv);
+    for (int t = 0; t < 4; t++) {
+        int shared = 0;
+        for (int u = 0; u < t; u++) shared |= (f->d_step[u] == f->d_step[t]);
+        if (!shared) llzs_free(f->d_step[t]);
+    }
+    llzs_free(f->d_fft_cs);
+    llz_stage_release(&f->time); llz_stage_release(&f->bins); llz_stage_release(&f->work);
     f->tag = 0;
     free(f);
+}
+
+/* angle of entry k of a step's table: the reference's expressions (llz_mdct_fixed.c:335-366, :381-386) in its evaluation
+ * order -- the Q15 rounding of cos/sin of a differently rounded angle could differ in the last bit */
+static double step_angle(int form, int step, int k, int length)
+{
+    if (form == MDCT_FIXED_FFT4) return -2 * M_PI * (k + 0.125) / length;
+    const double n0 = ((double)length / 2 + 1) / 2;
+    switch (step) {
+    case STEP_FWD_PRE:  return -(M_PI * k) / length;
+    case STEP_FWD_POST: return -2 * M_PI * n0 * (k + 0.5) / length;
+    case STEP_INV_PRE:  return (2 * M_PI * k * n0) / length;
+    default:            return M_PI * (k + n0) / length;
+    }
+}
+
+static short *upload_q15(const short *host, size_t count)
+{
+    short *dev = (short *)llzs_malloc(sizeof(short) * count);
+    if (dev && llzs_h2d(dev, host, sizeof(short) * count, NULL) != LLZ_OK) { llzs_free(dev); dev = NULL; }
+    return dev;
+}
+
+static short *step_table_upload(int form, int step, int count, int length)
+{
+    short *host = (short *)malloc(sizeof(short) * 2 * (size_t)count);
+    if (!host) return NULL;
+    for (int k = 0; k < count; k++) {
+        const double ang = step_angle(form, step, k, length);
+        host[2 * k] = q15_of(cos(ang));
+        host[2 * k + 1] = q15_of(sin(ang));
+    }
+    short *dev = upload_q15(host, 2 * (size_t)count);
+    free(host);
+    return dev;
+}
+
+static int mdcx_build_sums(mdcx_t *f)
+{
+    const int N = f->length, K = N >> 1;
+    const size_t cnt = (size_t)K * N;
+    short *fwd = (short *)malloc(sizeof(short) * cnt), *inv = (short *)malloc(sizeof(short) * cnt);
+    int rc = (fwd && inv) ? LLZ_OK : LLZ_ERR_NOMEM;
+    if (rc == LLZ_OK) {
+        for (int k = 0; k < K; k++)
+            for (int n = 0; n < N; n++) {
+                const double ang = (M_PI / (2 * N)) * (2 * n + 1 + K) * (2 * k + 1);    /* llz_mdct_fixed.c:313-322 */
+                fwd[(size_t)k * N + n] = inv[(size_t)n * K + k] = q15_of(cos(ang));
+            }
+        f->d_sum_fwd = upload_q15(fwd, cnt);
+        f->d_sum_inv = upload_q15(inv, cnt);
+        if (!f->d_sum_fwd || !f->d_sum_inv) rc = LLZ_ERR_NOMEM;
+    }
+    free(fwd); free(inv);
+    return rc;
+}
+
+static int mdcx_build_fft_form(mdcx_t *f)
+{
+    const int N = f->length;
+    f->fft_size = f->form == MDCT_FIXED_FFT ? N : N >> 2;
+    if (f->form == MDCT_FIXED_FFT) {
+        f->d_step[STEP_FWD_PRE] = step_table_upload(MDCT_FIXED_FFT, STEP_FWD_PRE, N, N);
+        f->d_step[STEP_FWD_POST] = step_table_upload(MDCT_FIXED_FFT, STEP_FWD_POST, N >> 1, N);
+        f->d_step[STEP_INV_PRE] = step_table_upload(MDCT_FIXED_FFT, STEP_INV_PRE, N, N);
+        f->d_step[STEP_INV_POST] = step_table_upload(MDCT_FIXED_FFT, STEP_INV_POST, N, N);
+    } else {
+        short *t = step_table_upload(MDCT_FIXED_FFT4, 0, N >> 2, N);      /* one table serves all four steps */
+        for (int s = 0; s < 4; s++) f->d_step[s] = t;
+        f->cof = q15_of(1. / sqrt(N));                                    /* llz_mdct_fixed.c:373 */
+    }
+    for (int s = 0; s < 4; s++)
+        if (!f->d_step[s]) return LLZ_ERR_NOMEM;
+    const int F = f->fft_size;
+    short *cs = (short *)malloc(sizeof(short) * 2 * (size_t)F);
+    if (!cs) return LLZ_ERR_NOMEM;
+    for (int i = 0; i < F; i++) {
+        const double ang = (2 * M_PI * i) / F;                            /* llz_fft_fixed.c:243-247 */
+        cs[i] = q15_of(cos(ang));
+        cs[F + i] = q15_of(sin(ang));
+    }
+    f->d_fft_cs = upload_q15(cs, 2 * (size_t)F);
+    free(cs);
+    return f->d_fft_cs ? LLZ_OK : LLZ_ERR_NOMEM;
 }
 
 unsigned long llz_mdct_fixed_init(int type, int size)
@@ -59,9 +145,9 @@ unsigned long llz_mdct_fixed_init(int type, int size)
         llzs_set_error("llz_mdct_fixed_init: type %d len %d", type, size);
         return LLZ_BAD_HANDLE;
     }
-    int base = (int)(log(size) / log(2));                           /* llz_mdct_fixed.c:296-300 */
-    if ((1 << base) < size) base += 1;
-    const int length = 1 << base;
+    int log2len = (int)(log(size) / log(2));                        /* next power of two, as llz_mdct_fixed.c:296-300 */
+    if ((1 << log2len) < size) log2len += 1;
+    const int length = 1 << log2len;
     const int limit = type == MDCT_FIXED_ORIGIN ? 2048 : (type == MDCT_FIXED_FFT ? 4096 : 16384);
     if (length > limit || (type == MDCT_FIXED_FFT4 && length < 8)) {
         llzs_set_error("llz_mdct_fixed_init: length %d out of range for type %d (at most %d)", length, type, limit);
@@ -69,72 +155,9 @@ unsigned long llz_mdct_fixed_init(int type, int size)
     }
     mdcx_t *f = (mdcx_t *)calloc(1, sizeof(*f));
     if (!f) return LLZ_BAD_HANDLE;
-    f->tag = LLZ_TAG_MDCX; f->type = type; f->length = length;
-    int rc = LLZ_OK;
-    if (type == MDCT_FIXED_ORIGIN) {                                /* llz_mdct_fixed.c:307-325 */
-        const size_t cnt = (size_t)(length >> 1) * length;
-        short *pos = (short *)malloc(sizeof(short) * cnt), *inv = (short *)malloc(sizeof(short) * cnt);
-        f->d_cos_pos = (short *)llzs_malloc(sizeof(short) * cnt);
-        f->d_cos_inv = (short *)llzs_malloc(sizeof(short) * cnt);
-        f->d_x = (int *)llzs_malloc(sizeof(int) * (size_t)length);
-        f->d_y = (int *)llzs_malloc(sizeof(int) * (size_t)length);
-        if (!pos || !inv || !f->d_cos_pos || !f->d_cos_inv || !f->d_x || !f->d_y) rc = LLZ_ERR_NOMEM;
-        if (rc == LLZ_OK) {
-            for (int k = 0; k < (length >> 1); k++)
-                for (int n = 0; n < length; n++) {
-                    const double tmp = (M_PI / (2 * length)) * (2 * n + 1 + (length >> 1)) * (2 * k + 1);
-                    pos[(size_t)k * length + n] = inv[(size_t)n * (length >> 1) + k] = fix15(cos(tmp));
-                }
-            rc = llzs_h2d(f->d_cos_pos, pos, sizeof(short) * cnt, NULL);
-            if (rc == LLZ_OK) rc = llzs_h2d(f->d_cos_inv, inv, sizeof(short) * cnt, NULL);
-        }
-        free(pos); free(inv);
-    } else if (type == MDCT_FIXED_FFT) {                            /* llz_mdct_fixed.c:326-367 */
-        const double n0 = ((double)length / 2 + 1) / 2;
-        f->h_fft = llz_fft_fixed_init(length);
-        f->fft_buf = (int *)malloc(sizeof(int) * (size_t)length * 2);
-        f->pre_c_pos = (short *)malloc(sizeof(short) * (size_t)length);
-        f->pre_s_pos = (short *)malloc(sizeof(short) * (size_t)length);
-        f->c_pos = (short *)malloc(sizeof(short) * (size_t)(length >> 1));
-        f->s_pos = (short *)malloc(sizeof(short) * (size_t)(length >> 1));
-        f->pre_c_inv = (short *)malloc(sizeof(short) * (size_t)length);
-        f->pre_s_inv = (short *)malloc(sizeof(short) * (size_t)length);
-        f->c_inv = (short *)malloc(sizeof(short) * (size_t)length);
-        f->s_inv = (short *)malloc(sizeof(short) * (size_t)length);
-        if (f->h_fft == LLZ_BAD_HANDLE || !f->fft_buf || !f->pre_c_pos || !f->pre_s_pos || !f->c_pos || !f->s_pos ||
-            !f->pre_c_inv || !f->pre_s_inv || !f->c_inv || !f->s_inv) rc = LLZ_ERR_NOMEM;
-        if (rc == LLZ_OK) {
-            for (int k = 0; k < length; k++) {
-                f->pre_c_pos[k] = fix15(cos(-(M_PI * k) / length));
-                f->pre_s_pos[k] = fix15(sin(-(M_PI * k) / length));
-            }
-            for (int k = 0; k < (length >> 1); k++) {
-                f->c_pos[k] = fix15(cos(-2 * M_PI * n0 * (k + 0.5) / length));
-                f->s_pos[k] = fix15(sin(-2 * M_PI * n0 * (k + 0.5) / length));
-            }
-            for (int k = 0; k < length; k++) {
-                f->pre_c_inv[k] = fix15(cos((2 * M_PI * k * n0) / length));
-                f->pre_s_inv[k] = fix15(sin((2 * M_PI * k * n0) / length));
-            }
-            for (int k = 0; k < length; k++) {
-                f->c_inv[k] = fix15(cos(M_PI * (k + n0) / length));
-                f->s_inv[k] = fix15(sin(M_PI * (k + n0) / length));
-            }
-        }
-    } else {                                                        /* llz_mdct_fixed.c:368-387 */
-        f->h_fft = llz_fft_fixed_init(length >> 2);
-        f->fft_buf = (int *)malloc(sizeof(int) * (size_t)(length >> 1));
-        f->sqrt_cof = fix15(1. / sqrt(length));
-        f->rot = (int *)calloc((size_t)length, sizeof(int));
-        f->tw_c = (short *)malloc(sizeof(short) * (size_t)(length >> 2));
-        f->tw_s = (short *)malloc(sizeof(short) * (size_t)(length >> 2));
-        if (f->h_fft == LLZ_BAD_HANDLE || !f->fft_buf || !f->rot || !f->tw_c || !f->tw_s) rc = LLZ_ERR_NOMEM;
-        if (rc == LLZ_OK)
-            for (int k = 0; k < (length >> 2); k++) {
-                f->tw_c[k] = fix15(cos(-2 * M_PI * (k + 0.125) / length));
-                f->tw_s[k] = fix15(sin(-2 * M_PI * (k + 0.125) / length));
-            }
-    }
+    f->tag = LLZ_TAG_MDCX; f->form = type; f->length = length; f->device = llzs_device_get();
+    int rc = type == MDCT_FIXED_ORIGIN ? mdcx_build_sums(f) : mdcx_build_fft_form(f);
+    if (rc == LLZ_OK && f->device < 0) rc = LLZ_ERR_DEVICE;
     if (rc != LLZ_OK) {
         mdcx_destroy(f);
         return LLZ_BAD_HANDLE;
@@ -144,102 +167,93 @@ unsigned long llz_mdct_fixed_init(int type, int size)
 
 void llz_mdct_fixed_uninit(unsigned long handle)
 {
-    if (LLZ_HANDLE_OK(handle, mdcx_t, LLZ_TAG_MDCX)) mdcx_destroy((mdcx_t *)handle);
+    if (!LLZ_HANDLE_OK(handle, mdcx_t, LLZ_TAG_MDCX)) return;
+    mdcx_t *f = (mdcx_t *)handle;
+    const int prev = llzs_device_enter(f->device);
+    llzs_sync(f->stream);
+    mdcx_destroy(f);
+    llzs_device_leave(prev);
 }
 
-static int mdcx_sums(mdcx_t *f, const short *d_A, const int *x, int *y, int rows, int cols)
+int llz_mdct_fixed_set_stream(unsigned long handle, void *stream)
 {
-    int rc = llzs_h2d(f->d_x, x, sizeof(int) * (size_t)cols, NULL);
-    if (rc == LLZ_OK) rc = llzs_matvec_q15(d_A, f->d_x, f->d_y, rows, cols, NULL);
-    if (rc == LLZ_OK) rc = llzs_d2h(y, f->d_y, sizeof(int) * (size_t)rows, NULL);
+    if (!LLZ_HANDLE_OK(handle, mdcx_t, LLZ_TAG_MDCX)) return LLZ_ERR_ARG;
+    ((mdcx_t *)handle)->stream = stream;
+    return LLZ_OK;
+}
+
+int llz_mdct_fixed_len(unsigned long handle)
+{
+    return LLZ_HANDLE_OK(handle, mdcx_t, LLZ_TAG_MDCX) ? ((mdcx_t *)handle)->length : LLZ_ERR_ARG;
+}
+
+/* `count` frames in one direction, device buffers: d_src -> d_dst, through the handle's work buffer */
+static int mdcx_on_device(mdcx_t *f, const int *d_src, int *d_dst, int count, int inverse)
+{
+    const int N = f->length, K = N >> 1;
+    if (f->form == MDCT_FIXED_ORIGIN)                                /* llz_mdct_fixed.c:116-152 */
+        return inverse ? llzs_mdctq_sums(f->d_sum_inv, d_src, d_dst, count, N, K, N, f->stream)
+                       : llzs_mdctq_sums(f->d_sum_fwd, d_src, d_dst, count, K, N, 0, f->stream);
+    const int quarter = f->form == MDCT_FIXED_FFT4;
+    int *d_work = (int *)llz_stage_reserve(&f->work, sizeof(int) * 2 * (size_t)f->fft_size * (size_t)count);
+    if (!d_work) return LLZ_ERR_NOMEM;
+    /* the N-point form inverts with the inverse transform (llz_mdct_fixed.c:190); the N/4-point form runs the FORWARD
+     * transform in both directions (llz_mdct_fixed.c:223, :258) */
+    const int fft_inverse = inverse && !quarter;
+    int rc = llzs_mdctq_step(quarter, 0, d_src, d_work, f->d_step[inverse ? STEP_INV_PRE : STEP_FWD_PRE], count, N,
+                             inverse, f->cof, f->stream);
+    if (rc == LLZ_OK) rc = llzs_fft_fixed(d_work, count, f->fft_size, f->d_fft_cs, fft_inverse, f->stream);
+    if (rc == LLZ_OK)
+        rc = llzs_mdctq_step(quarter, 1, d_work, d_dst, f->d_step[inverse ? STEP_INV_POST : STEP_FWD_POST], count, N,
+                             inverse, f->cof, f->stream);
     return rc;
 }
 
-void llz_mdct_fixed(unsigned long handle, int *x, int *X)
+static int mdcx_run(unsigned long handle, const int *in, int *out, int count, int inverse, const char *who)
 {
-    if (!LLZ_HANDLE_OK(handle, mdcx_t, LLZ_TAG_MDCX) || !x || !X) {
-        llzs_set_error("llz_mdct_fixed: bad handle or arguments");
-        return;
+    if (!LLZ_HANDLE_OK(handle, mdcx_t, LLZ_TAG_MDCX) || !in || !out || in == out || count < 1 || count > 65535) {
+        llzs_set_error("%s: bad handle or arguments (1..65535 frames per call, out of place)", who);
+        return LLZ_ERR_ARG;
     }
     mdcx_t *f = (mdcx_t *)handle;
-    const int N = f->length, N2 = N >> 1, N4 = N >> 2;
-    if (f->type == MDCT_FIXED_ORIGIN) {                             /* llz_mdct_fixed.c:116-133 */
-        (void)mdcx_sums(f, f->d_cos_pos, x, X, N2, N);
-    } else if (f->type == MDCT_FIXED_FFT) {                         /* llz_mdct_fixed.c:155-172 */
-        for (int k = 0; k < N; k++) {
-            f->fft_buf[k + k] = fixmul(x[k], f->pre_c_pos[k]);
-            f->fft_buf[k + k + 1] = fixmul(x[k], f->pre_s_pos[k]);
-        }
-        llz_fft_fixed(f->h_fft, f->fft_buf);
-        for (int k = 0; k < N2; k++)
-            X[k] = wsub(fixmul(f->fft_buf[k + k], f->c_pos[k]), fixmul(f->fft_buf[k + k + 1], f->s_pos[k]));
-    } else {                                                        /* llz_mdct_fixed.c:197-233 */
-        int *rot = f->rot;
-        memset(rot, 0, sizeof(int) * (size_t)f->length);
-        for (int k = 0; k < N4; k++) rot[k] = wneg(x[k + 3 * N4]);
-        for (int k = N4; k < N; k++) rot[k] = x[k - N4];
-        for (int k = 0; k < N4; k++) {
-            const int re = wsub(rot[2 * k], rot[N - 1 - 2 * k]);
-            const int im = wsub(rot[N2 - 1 - 2 * k], rot[N2 + 2 * k]);
-            f->fft_buf[k + k] = wsub(fixmul(re, f->tw_c[k]), fixmul(im, f->tw_s[k])) >> 1;
-            f->fft_buf[k + k + 1] = wadd(fixmul(re, f->tw_s[k]), fixmul(im, f->tw_c[k])) >> 1;
-        }
-        llz_fft_fixed(f->h_fft, f->fft_buf);
-        for (int k = 0; k < N4; k++) {
-            const int re = f->fft_buf[k + k], im = f->fft_buf[k + k + 1];
-            X[2 * k] = wmul(2, wsub(fixmul(re, f->tw_c[k]), fixmul(im, f->tw_s[k])));
-            X[N2 - 1 - 2 * k] = wmul(-2, wadd(fixmul(re, f->tw_s[k]), fixmul(im, f->tw_c[k])));
-        }
+    const int prev = llzs_device_enter(f->device);
+    const size_t full = sizeof(int) * (size_t)count * (size_t)f->length, half = full / 2;
+    const size_t ib = inverse ? half : full, ob = inverse ? full : half;
+    const int in_dev = llzs_is_device_ptr(in), out_dev = llzs_is_device_ptr(out);
+    const int *d_in = in;
+    int *d_out = out;
+    int rc = (in_dev < 0 || out_dev < 0) ? LLZ_ERR_ARG : LLZ_OK;
+    if (rc == LLZ_OK && !in_dev) {
+        d_in = (const int *)llz_stage_reserve(inverse ? &f->bins : &f->time, ib);
+        rc = d_in ? llzs_h2d((void *)d_in, in, ib, f->stream) : LLZ_ERR_NOMEM;
     }
+    if (rc == LLZ_OK && !out_dev) {
+        d_out = (int *)llz_stage_reserve(inverse ? &f->time : &f->bins, ob);
+        if (!d_out) rc = LLZ_ERR_NOMEM;
+    }
+    if (rc == LLZ_OK) rc = mdcx_on_device(f, d_in, d_out, count, inverse);
+    if (rc == LLZ_OK && !out_dev) rc = llzs_d2h(out, d_out, ob, f->stream);
+    llzs_device_leave(prev);
+    return rc == LLZ_OK ? count : rc;
+}
+
+int llz_mdct_fixed_batch(unsigned long handle, const int *x, int *X, int count)
+{
+    return mdcx_run(handle, x, X, count, 0, "llz_mdct_fixed_batch");
+}
+
+int llz_imdct_fixed_batch(unsigned long handle, const int *X, int *x, int count)
+{
+    return mdcx_run(handle, X, x, count, 1, "llz_imdct_fixed_batch");
+}
+
+/* the reference's symbols: one frame on host buffers (void in the reference ABI: errors are left in llz_hip_last_error) */
+void llz_mdct_fixed(unsigned long handle, int *x, int *X)
+{
+    (void)mdcx_run(handle, x, X, 1, 0, "llz_mdct_fixed");
 }
 
 void llz_imdct_fixed(unsigned long handle, int *X, int *x)
 {
-    if (!LLZ_HANDLE_OK(handle, mdcx_t, LLZ_TAG_MDCX) || !x || !X) {
-        llzs_set_error("llz_imdct_fixed: bad handle or arguments");
-        return;
-    }
-    mdcx_t *f = (mdcx_t *)handle;
-    const int N = f->length, N2 = N >> 1, N4 = N >> 2;
-    if (f->type == MDCT_FIXED_ORIGIN) {                             /* llz_mdct_fixed.c:135-152 */
-        if (mdcx_sums(f, f->d_cos_inv, X, x, N, N2) == LLZ_OK)
-            for (int n = 0; n < N; n++) x[n] = wmul(x[n], 4) / N;
-    } else if (f->type == MDCT_FIXED_FFT) {                         /* llz_mdct_fixed.c:174-195 */
-        for (int k = 0; k < N2; k++) {
-            f->fft_buf[k + k] = fixmul(X[k], f->pre_c_inv[k]);
-            f->fft_buf[k + k + 1] = fixmul(X[k], f->pre_s_inv[k]);
-        }
-        for (int k = N2, i = N2 - 1; k < N; k++, i--) {
-            f->fft_buf[k + k] = fixmul(wneg(X[i]), f->pre_c_inv[k]);
-            f->fft_buf[k + k + 1] = fixmul(wneg(X[i]), f->pre_s_inv[k]);
-        }
-        llz_ifft_fixed(f->h_fft, f->fft_buf);
-        for (int k = 0; k < N; k++)
-            x[k] = (int)((unsigned)wsub(fixmul(f->fft_buf[k + k], f->c_inv[k]),
-                                        fixmul(f->fft_buf[k + k + 1], f->s_inv[k])) << 1);
-    } else {                                                        /* llz_mdct_fixed.c:235-283 */
-        int *rot = f->rot;
-        const short cof = f->sqrt_cof;
-        memset(rot, 0, sizeof(int) * (size_t)f->length);
-        for (int k = 0; k < N4; k++) {
-            const int re = X[2 * k], im = X[N2 - 1 - 2 * k];
-            f->fft_buf[k + k] = wsub(fixmul(re, f->tw_c[k]), fixmul(im, f->tw_s[k])) >> 1;
-            f->fft_buf[k + k + 1] = wadd(fixmul(re, f->tw_s[k]), fixmul(im, f->tw_c[k])) >> 1;
-        }
-        llz_fft_fixed(f->h_fft, f->fft_buf);
-        for (int k = 0; k < N4; k++) {
-            const int re = f->fft_buf[k + k], im = f->fft_buf[k + k + 1];
-            int tmp = wsub(fixmul(re, f->tw_c[k]), fixmul(im, f->tw_s[k]));
-            f->fft_buf[k + k] = wmul(8, fixmul(tmp, cof));
-            tmp = wadd(fixmul(re, f->tw_s[k]), fixmul(im, f->tw_c[k]));
-            f->fft_buf[k + k + 1] = wmul(8, fixmul(tmp, cof));
-        }
-        for (int k = 0; k < N4; k++) {
-            rot[2 * k] = f->fft_buf[k + k];
-            rot[N2 + 2 * k] = f->fft_buf[k + k + 1];
-        }
-        for (int k = 1; k < N; k += 2) rot[k] = wneg(rot[N - 1 - k]);
-        for (int k = 0; k < 3 * N4; k++) x[k] = fixmul(rot[N4 + k], cof);
-        for (int k = 3 * N4; k < N; k++) x[k] = fixmul(wneg(rot[k - 3 * N4]), cof);
-    }
+    (void)mdcx_run(handle, X, x, 1, 1, "llz_imdct_fixed");
 }

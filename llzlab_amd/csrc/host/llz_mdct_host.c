@@ -67,7 +67,7 @@ int llz_mdct_kbd(double *w, int N, double alpha)
 enum { ROT_FWD_PRE = 0, ROT_FWD_POST = 1, ROT_INV_PRE = 2, ROT_INV_POST = 3 };
 
 typedef struct {
-    int tag, form, length;          /* form: MDCT_ORIGIN (defining sums), MDCT_FFT (N-point), MDCT_FFT4 (N/4-point) */
+    int tag, form, length, device;  /* form: MDCT_ORIGIN (defining sums), MDCT_FFT (N-point), MDCT_FFT4 (N/4-point) */
     int fft_size;                   /* points of the transform inside the FFT forms */
     double norm;                    /* 1 / sqrt(length): the N/4-point form's inverse scale */
     double *d_sum_fwd, *d_sum_inv;  /* MDCT_ORIGIN: [N/2][N] and [N][N/2] cosine kernels */
@@ -193,7 +193,7 @@ unsigned long llz_mdct_init(int type, int size)
     }
     mdct1_t *f = (mdct1_t *)calloc(1, sizeof(*f));
     if (!f) return LLZ_BAD_HANDLE;
-    f->tag = LLZ_TAG_MDCT; f->form = type; f->length = length;
+    f->tag = LLZ_TAG_MDCT; f->form = type; f->length = length; f->device = llzs_device_get();
     f->d_frame = (double *)llzs_malloc(sizeof(double) * (size_t)length);
     f->d_bins = (double *)llzs_malloc(sizeof(double) * (size_t)length);
     int rc = (f->d_frame && f->d_bins) ? LLZ_OK : LLZ_ERR_NOMEM;
@@ -207,60 +207,73 @@ unsigned long llz_mdct_init(int type, int size)
 
 void llz_mdct_uninit(unsigned long handle)
 {
-    if (LLZ_HANDLE_OK(handle, mdct1_t, LLZ_TAG_MDCT)) mdct1_destroy((mdct1_t *)handle);
+    if (!LLZ_HANDLE_OK(handle, mdct1_t, LLZ_TAG_MDCT)) return;
+    const int prev = llzs_device_enter(((mdct1_t *)handle)->device);
+    llzs_sync(NULL);
+    mdct1_destroy((mdct1_t *)handle);
+    llzs_device_leave(prev);
 }
 
-/* one direction of one frame, entirely on the device between the two copies */
-static int mdct1_run(mdct1_t *f, const double *src, double *dst, int inverse)
+/* one direction of one frame between two DEVICE buffers (the frame handles of llz_asmodel_host.c chain this with their own
+ * windowing kernels; d_src is not modified, d_dst != d_src) */
+static int mdct1_on_device(mdct1_t *f, const double *d_src, double *d_dst, int inverse)
 {
     const int N = f->length, K = N >> 1;
     const int n_src = inverse ? K : N, n_dst = inverse ? N : K;
-    double *d_src = inverse ? f->d_bins : f->d_frame, *d_dst = inverse ? f->d_frame : f->d_bins;
-    int rc = llzs_h2d(d_src, src, sizeof(double) * (size_t)n_src, NULL);
-    if (rc != LLZ_OK) return rc;
+    int rc;
     if (f->form == MDCT_ORIGIN) {                                    /* llz_mdct.c:185-222: the defining sums */
         rc = llzs_matvec_exact_f64(inverse ? f->d_sum_inv : f->d_sum_fwd, d_src, d_dst, n_dst, n_src, NULL);
-    } else {
-        const int quarter = f->form == MDCT_FFT4;
-        /* the N-point form inverts with the inverse transform (llz_mdct.c:258); the N/4-point form uses the FORWARD
-         * transform in both directions (llz_mdct.c:291, :328) */
-        const int fft_inverse = inverse && !quarter;
-        rc = llzs_mdct_rot_f64(quarter, 0, d_src, f->d_work, f->d_rot[inverse ? ROT_INV_PRE : ROT_FWD_PRE], N, inverse,
-                               f->norm, NULL);
-        if (rc == LLZ_OK) rc = llzs_fft_f64(f->d_work, f->fft_size, f->d_fft_cs, fft_inverse, NULL);
-        if (rc == LLZ_OK)
-            rc = llzs_mdct_rot_f64(quarter, 1, f->d_work, d_dst, f->d_rot[inverse ? ROT_INV_POST : ROT_FWD_POST], N,
-                                   inverse, f->norm, NULL);
+        if (rc == LLZ_OK && inverse) rc = llzs_scale_4_over_n_f64(d_dst, N, (double)N, NULL);   /* llz_mdct.c:219-220 */
+        return rc;
     }
-    if (rc == LLZ_OK) rc = llzs_d2h(dst, d_dst, sizeof(double) * (size_t)n_dst, NULL);
+    const int quarter = f->form == MDCT_FFT4;
+    /* the N-point form inverts with the inverse transform (llz_mdct.c:258); the N/4-point form uses the FORWARD
+     * transform in both directions (llz_mdct.c:291, :328) */
+    const int fft_inverse = inverse && !quarter;
+    rc = llzs_mdct_rot_f64(quarter, 0, d_src, f->d_work, f->d_rot[inverse ? ROT_INV_PRE : ROT_FWD_PRE], N, inverse,
+                           f->norm, NULL);
+    if (rc == LLZ_OK) rc = llzs_fft_f64(f->d_work, f->fft_size, f->d_fft_cs, fft_inverse, NULL);
+    if (rc == LLZ_OK)
+        rc = llzs_mdct_rot_f64(quarter, 1, f->d_work, d_dst, f->d_rot[inverse ? ROT_INV_POST : ROT_FWD_POST], N,
+                               inverse, f->norm, NULL);
     return rc;
 }
 
-void llz_mdct(unsigned long handle, double *x, double *X)
+int llz_host_mdct_on_device(unsigned long handle, const double *d_src, double *d_dst, int inverse)
 {
-    if (!LLZ_HANDLE_OK(handle, mdct1_t, LLZ_TAG_MDCT) || !x || !X) {
-        llzs_set_error("llz_mdct: bad handle or arguments");
-        return;                                                     /* void in the reference ABI */
-    }
-    (void)mdct1_run((mdct1_t *)handle, x, X, 0);
+    if (!LLZ_HANDLE_OK(handle, mdct1_t, LLZ_TAG_MDCT) || !d_src || !d_dst || d_src == d_dst) return LLZ_ERR_ARG;
+    mdct1_t *f = (mdct1_t *)handle;
+    const int prev = llzs_device_enter(f->device);
+    const int rc = mdct1_on_device(f, d_src, d_dst, inverse);
+    llzs_device_leave(prev);
+    return rc;
 }
 
-void llz_imdct(unsigned long handle, double *X, double *x)
+/* the reference's symbols: a frame travels host -> device once and back once */
+static void mdct1_run(unsigned long handle, const double *src, double *dst, int inverse, const char *who)
 {
-    if (!LLZ_HANDLE_OK(handle, mdct1_t, LLZ_TAG_MDCT) || !x || !X) {
-        llzs_set_error("llz_imdct: bad handle or arguments");
-        return;
+    if (!LLZ_HANDLE_OK(handle, mdct1_t, LLZ_TAG_MDCT) || !src || !dst) {
+        llzs_set_error("%s: bad handle or arguments", who);
+        return;                                                     /* void in the reference ABI */
     }
     mdct1_t *f = (mdct1_t *)handle;
-    if (mdct1_run(f, X, x, 1) != LLZ_OK) return;
-    if (f->form == MDCT_ORIGIN)                                     /* llz_mdct.c:219-220: (sum * 4) / N, two roundings */
-        for (int n = 0; n < f->length; n++) x[n] = (x[n] * 4) / f->length;
+    const int N = f->length, K = N >> 1;
+    const int n_src = inverse ? K : N, n_dst = inverse ? N : K;
+    double *d_src = inverse ? f->d_bins : f->d_frame, *d_dst = inverse ? f->d_frame : f->d_bins;
+    const int prev = llzs_device_enter(f->device);
+    int rc = llzs_h2d(d_src, src, sizeof(double) * (size_t)n_src, NULL);
+    if (rc == LLZ_OK) rc = mdct1_on_device(f, d_src, d_dst, inverse);
+    if (rc == LLZ_OK) rc = llzs_d2h(dst, d_dst, sizeof(double) * (size_t)n_dst, NULL);
+    llzs_device_leave(prev);
 }
+
+void llz_mdct(unsigned long handle, double *x, double *X) { mdct1_run(handle, x, X, 0, "llz_mdct"); }
+void llz_imdct(unsigned long handle, double *X, double *x) { mdct1_run(handle, X, x, 1, "llz_imdct"); }
 
 /* ---- Part 2: batch extension ---- */
 
 typedef struct {
-    int tag, length;
+    int tag, length, device;
     float *d_tc, *d_ts, *d_cs;
     llz_stage_t st_in, st_out;
     void *stream;
@@ -286,7 +299,7 @@ unsigned long llz_mdct_batch_init(int len)
     float *tab = (float *)malloc(sizeof(float) * 4 * (size_t)N4);
     int rc = (f && tab) ? LLZ_OK : LLZ_ERR_NOMEM;
     if (rc == LLZ_OK) {
-        f->tag = LLZ_TAG_MDCB; f->length = len;
+        f->tag = LLZ_TAG_MDCB; f->length = len; f->device = llzs_device_get();
         for (int k = 0; k < N4; k++) {
             tab[k] = (float)cos(-2 * M_PI * (k + 0.125) / len);           /* llz_mdct.c:459-462 */
             tab[N4 + k] = (float)sin(-2 * M_PI * (k + 0.125) / len);
@@ -313,8 +326,10 @@ unsigned long llz_mdct_batch_init(int len)
 void llz_mdct_batch_uninit(unsigned long handle)
 {
     if (LLZ_HANDLE_OK(handle, mdcb_t, LLZ_TAG_MDCB)) {
+        const int prev = llzs_device_enter(((mdcb_t *)handle)->device);
         llzs_sync(((mdcb_t *)handle)->stream);
         mdcb_destroy((mdcb_t *)handle);
+        llzs_device_leave(prev);
     }
 }
 
@@ -332,21 +347,24 @@ static int mdcb_run(unsigned long handle, const float *in, float *out, int count
         return LLZ_ERR_ARG;
     }
     mdcb_t *f = (mdcb_t *)handle;
+    const int prev = llzs_device_enter(f->device);
     const size_t full = sizeof(float) * (size_t)count * f->length, half = full / 2;
     const size_t ib = inverse ? half : full, ob = inverse ? full : half;
+    const int in_dev = llzs_is_device_ptr(in), out_dev = llzs_is_device_ptr(out);
     const float *d_in = in;
     float *d_out = out;
-    int rc = LLZ_OK;
-    if (!llzs_is_device_ptr(in)) {
+    int rc = (in_dev < 0 || out_dev < 0) ? LLZ_ERR_ARG : LLZ_OK;
+    if (rc == LLZ_OK && !in_dev) {
         d_in = (const float *)llz_stage_reserve(&f->st_in, ib);
         rc = d_in ? llzs_h2d((void *)d_in, in, ib, f->stream) : LLZ_ERR_NOMEM;
     }
-    if (rc == LLZ_OK && !llzs_is_device_ptr(out)) {
+    if (rc == LLZ_OK && !out_dev) {
         d_out = (float *)llz_stage_reserve(&f->st_out, ob);
         if (!d_out) rc = LLZ_ERR_NOMEM;
     }
     if (rc == LLZ_OK) rc = llzs_mdct4_f32(d_in, d_out, count, f->length, f->d_tc, f->d_ts, f->d_cs, inverse, f->stream);
-    if (rc == LLZ_OK && d_out != out) rc = llzs_d2h(out, d_out, ob, f->stream);
+    if (rc == LLZ_OK && !out_dev) rc = llzs_d2h(out, d_out, ob, f->stream);
+    llzs_device_leave(prev);
     return rc == LLZ_OK ? count : rc;
 }
 

@@ -12,6 +12,7 @@ static int pcm_run(int deint, const void *in, void *out, int channels, long n, f
     const size_t in_bytes = count * (deint ? sizeof(short) : sizeof(float));
     const size_t out_bytes = count * (deint ? sizeof(float) : sizeof(short));
     const int in_dev = llzs_is_device_ptr(in), out_dev = llzs_is_device_ptr(out);
+    if (in_dev < 0 || out_dev < 0) return LLZ_ERR_ARG;            /* device memory of a GPU that is not current */
     void *d_in = (void *)in, *d_out = out;
     int rc = LLZ_OK;
     if (!in_dev) {

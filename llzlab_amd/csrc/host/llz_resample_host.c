@@ -544,6 +544,7 @@ static long rsm_process(rsm_t *r, unsigned long handle, const void *in, long n_i
     const size_t in_bytes = sb * (size_t)r->channels * (size_t)n_in;
     const size_t out_bytes = sb * (size_t)r->channels * (size_t)n_out;
     const int in_dev = llzs_is_device_ptr(in), out_dev = llzs_is_device_ptr(out);
+    if (in_dev < 0 || out_dev < 0) return LLZ_ERR_ARG;            /* a buffer of another GPU: refused, message set */
     const void *d_in = in;
     void *d_out = out;
     int rc = LLZ_OK;

@@ -31,20 +31,6 @@ k_matvec_exact_f64(const double *__restrict__ A, const double *__restrict__ x, d
     y[r] = acc;
 }
 
-// y[r] = sum_c (int)(((int64)x[c] * A[r][c]) >> 15) with wrapping int32 adds: the defining sums of MDCT_FIXED_ORIGIN
-// (llz_mdct_fixed.c:116-152).  Integer adds are associative modulo 2^32, so any order is the reference's result.
-__global__ void __launch_bounds__(256)
-k_matvec_q15(const short *__restrict__ A, const int *__restrict__ x, int *__restrict__ y, int rows, int cols)
-{
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
-    const short *row = A + (size_t)r * cols;
-    unsigned acc = 0;
-    for (int c = 0; c < cols; c++) acc += (unsigned)(int)(((long long)x[c] * (long long)row[c]) >> 15);
-    y[r] = (int)acc;
-}
-
-
 // ---- exact-order twiddle steps of the FFT forms (double, one frame) ----------------------------------------------------
 // Tables are (cos, sin) pairs.  "N-point form" (llz_mdct.c:225-264): pre = modulate the frame into N complex points, post =
 // rotate each bin and keep the real part.  "quarter form" (llz_mdct.c:266-353): pre = fold the frame into N/4 complex
@@ -248,18 +234,6 @@ extern "C" int llzs_mdct_rot_f64(int quarter, int post, const double *in, double
     else
         hipLaunchKernelGGL(k_mdct_rot_quarter_post_f64, grid, block, 0, as_stream(stream), in, out, cs2, N, inverse, cof);
     LLZ_LAUNCH_CHECK("k_mdct_rot_f64");
-    return LLZ_OK;
-}
-
-extern "C" int llzs_matvec_q15(const short *A, const int *x, int *y, int rows, int cols, void *stream)
-{
-    if (!A || !x || !y || rows < 1 || cols < 1) {
-        llzs_set_error("matvec_q15: bad arguments");
-        return LLZ_ERR_ARG;
-    }
-    hipLaunchKernelGGL(k_matvec_q15, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream), A, x, y, rows,
-                       cols);
-    LLZ_LAUNCH_CHECK("k_matvec_q15");
     return LLZ_OK;
 }
 

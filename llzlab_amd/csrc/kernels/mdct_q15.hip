@@ -1,0 +1,164 @@
+// mdct_q15.hip -- the fixed-point MDCT's own steps on the device (fixed half; reference
+// libllzfilter/llz_mdct_fixed.c:116-283), for any number of frames per launch (grid.y = frame).
+//
+// Data are int32, tables Q15.  Every product is the reference's LLZ_FIXMUL_32X15 (llz_fft_fixed.h:67):
+// (int)(((int64)a * (int64)b) >> 15), floored separately; sums, differences and negations wrap modulo 2^32 as the
+// reference's int arithmetic does on this ABI (written on unsigned operands here, so the wrap is defined).  Integer
+// arithmetic has no rounding order: one lane per output computing the output's own expression IS the reference's result,
+// whatever the reference's loop structure was.  The transform between the two steps is the bit-exact Q15 FFT of fft.hip.
+//
+//  k_mdctq_sums        MDCT_FIXED_ORIGIN: the defining sums (a Q15 cosine matrix times the frame), optional (4 v) / N
+//  k_mdctq_modulate    MDCT_FIXED_FFT, in front of the N-point transform: sample k -> complex point k
+//  k_mdctq_demodulate  MDCT_FIXED_FFT, behind it: rotate a bin, keep the real part
+//  k_mdctq_fold        MDCT_FIXED_FFT4, in front of the N/4-point transform: fold the frame to N/4 points, rotate, halve
+//  k_mdctq_unfold      MDCT_FIXED_FFT4, behind it: rotate and scatter (forward) / rebuild the time frame (inverse)
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ int q15(int a, int b) { return (int)(((long long)a * (long long)b) >> 15); }
+__device__ __forceinline__ int wrap_add(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+__device__ __forceinline__ int wrap_sub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+__device__ __forceinline__ int wrap_neg(int a) { return (int)(0u - (unsigned)a); }
+__device__ __forceinline__ int wrap_scale(int a, int by) { return (int)((unsigned)a * (unsigned)by); }
+
+// y[f][r] = sum_c q15(x[f][c], A[r][c]); with quarter_over_n the reference's "(sum * 4) / N" (wrapping product, C division)
+__global__ void __launch_bounds__(256)
+k_mdctq_sums(const short *__restrict__ A, const int *__restrict__ x, int *__restrict__ y, int rows, int cols,
+             int quarter_over_n)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const short *row = A + (size_t)r * cols;
+    const int *frame = x + (size_t)blockIdx.y * cols;
+    unsigned acc = 0;
+    for (int c = 0; c < cols; c++) acc += (unsigned)q15(frame[c], row[c]);
+    int v = (int)acc;
+    if (quarter_over_n) v = wrap_scale(v, 4) / quarter_over_n;
+    y[(size_t)blockIdx.y * rows + r] = v;
+}
+
+// forward: frame [N] -> points [N] complex; inverse: coefficients [N/2], continued with odd symmetry (X[k], then -X[N-1-k])
+__global__ void __launch_bounds__(256)
+k_mdctq_modulate(const int *__restrict__ in, int *__restrict__ z, const short2 *__restrict__ tw, int N, int inverse)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= N) return;
+    const int *src = in + (size_t)blockIdx.y * (inverse ? N >> 1 : N);
+    int v;
+    if (!inverse) v = src[k];
+    else v = k < (N >> 1) ? src[k] : wrap_neg(src[N - 1 - k]);
+    const short2 w = tw[k];
+    int2 p;
+    p.x = q15(v, w.x);
+    p.y = q15(v, w.y);
+    reinterpret_cast<int2 *>(z)[(size_t)blockIdx.y * N + k] = p;
+}
+
+// forward: N/2 coefficients; inverse: N samples, doubled
+__global__ void __launch_bounds__(256)
+k_mdctq_demodulate(const int *__restrict__ z, int *__restrict__ out, const short2 *__restrict__ tw, int N, int inverse)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int n_out = inverse ? N : N >> 1;
+    if (k >= n_out) return;
+    const int2 p = reinterpret_cast<const int2 *>(z)[(size_t)blockIdx.y * N + k];
+    const short2 w = tw[k];
+    const int d = wrap_sub(q15(p.x, w.x), q15(p.y, w.y));
+    out[(size_t)blockIdx.y * n_out + k] = inverse ? (int)((unsigned)d << 1) : d;
+}
+
+// (re + j im)(c + j s) with four separately floored products
+__device__ __forceinline__ void q15_rotate(int re, int im, short2 w, int *zr, int *zi)
+{
+    *zr = wrap_sub(q15(re, w.x), q15(im, w.y));
+    *zi = wrap_add(q15(re, w.y), q15(im, w.x));
+}
+
+__global__ void __launch_bounds__(256)
+k_mdctq_fold(const int *__restrict__ in, int *__restrict__ z, const short2 *__restrict__ tw, int N, int inverse)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int N2 = N >> 1, N4 = N >> 2;
+    if (k >= N4) return;
+    const int *src = in + (size_t)blockIdx.y * (inverse ? N2 : N);
+    int re, im;
+    if (!inverse) {
+        // the frame turned by a quarter, the quarter that wraps to the front negated
+        auto turned = [&](int i) { return i < N4 ? wrap_neg(src[i + 3 * N4]) : src[i - N4]; };
+        re = wrap_sub(turned(2 * k), turned(N - 1 - 2 * k));
+        im = wrap_sub(turned(N2 - 1 - 2 * k), turned(N2 + 2 * k));
+    } else {
+        re = src[2 * k];
+        im = src[N2 - 1 - 2 * k];
+    }
+    int zr, zi;
+    q15_rotate(re, im, tw[k], &zr, &zi);
+    reinterpret_cast<int2 *>(z)[(size_t)blockIdx.y * N4 + k] = make_int2(zr >> 1, zi >> 1);
+}
+
+__global__ void __launch_bounds__(256)
+k_mdctq_unfold(const int *__restrict__ z, int *__restrict__ out, const short2 *__restrict__ tw, int N, int inverse,
+               int cof)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int N2 = N >> 1, N4 = N >> 2;
+    const int2 *pts = reinterpret_cast<const int2 *>(z) + (size_t)blockIdx.y * N4;
+    if (!inverse) {
+        if (t >= N4) return;
+        int zr, zi;
+        q15_rotate(pts[t].x, pts[t].y, tw[t], &zr, &zi);
+        int *X = out + (size_t)blockIdx.y * N2;
+        X[2 * t] = wrap_scale(zr, 2);
+        X[N2 - 1 - 2 * t] = wrap_scale(zi, -2);
+        return;
+    }
+    if (t >= N) return;
+    // the turned sequence r: r[2m] = 8 q15(Re v[m], cof), r[N/2 + 2m] = 8 q15(Im v[m], cof) with v = the rotated bins; odd
+    // entries mirror the even ones with the sign flipped; the frame is r turned back by a quarter (wrapped quarter negated),
+    // times cof
+    auto r_even = [&](int i) {
+        const int m = i < N2 ? i >> 1 : (i - N2) >> 1;
+        int zr, zi;
+        q15_rotate(pts[m].x, pts[m].y, tw[m], &zr, &zi);
+        return wrap_scale(q15(i < N2 ? zr : zi, cof), 8);
+    };
+    auto r_at = [&](int i) { return (i & 1) ? wrap_neg(r_even(N - 1 - i)) : r_even(i); };
+    out[(size_t)blockIdx.y * N + t] = t < 3 * N4 ? q15(r_at(N4 + t), cof) : q15(wrap_neg(r_at(t - 3 * N4)), cof);
+}
+
+} // namespace
+
+extern "C" int llzs_mdctq_sums(const short *A, const int *x, int *y, int count, int rows, int cols, int quarter_over_n,
+                               void *stream)
+{
+    if (!A || !x || !y || count < 1 || count > 65535 || rows < 1 || cols < 1) {
+        llzs_set_error("mdctq_sums: bad arguments");
+        return LLZ_ERR_ARG;
+    }
+    hipLaunchKernelGGL(k_mdctq_sums, dim3((unsigned)((rows + 255) / 256), (unsigned)count), dim3(256), 0,
+                       as_stream(stream), A, x, y, rows, cols, quarter_over_n);
+    LLZ_LAUNCH_CHECK("k_mdctq_sums");
+    return LLZ_OK;
+}
+
+extern "C" int llzs_mdctq_step(int quarter, int post, const int *in, int *out, const short *tw, int count, int N,
+                               int inverse, int cof, void *stream)
+{
+    if (!in || !out || !tw || count < 1 || count > 65535 || N < 4 || (N & (N - 1))) {
+        llzs_set_error("mdctq_step: bad arguments (N=%d count=%d)", N, count);
+        return LLZ_ERR_ARG;
+    }
+    const short2 *t2 = reinterpret_cast<const short2 *>(tw);
+    const dim3 grid((unsigned)((N + 255) / 256), (unsigned)count), block(256);
+    if (!quarter && !post)
+        hipLaunchKernelGGL(k_mdctq_modulate, grid, block, 0, as_stream(stream), in, out, t2, N, inverse);
+    else if (!quarter)
+        hipLaunchKernelGGL(k_mdctq_demodulate, grid, block, 0, as_stream(stream), in, out, t2, N, inverse);
+    else if (!post)
+        hipLaunchKernelGGL(k_mdctq_fold, grid, block, 0, as_stream(stream), in, out, t2, N, inverse);
+    else
+        hipLaunchKernelGGL(k_mdctq_unfold, grid, block, 0, as_stream(stream), in, out, t2, N, inverse, cof);
+    LLZ_LAUNCH_CHECK("k_mdctq_step");
+    return LLZ_OK;
+}

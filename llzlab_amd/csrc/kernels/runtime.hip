@@ -127,6 +127,9 @@ extern "C" int llzs_sync(void *stream)
     return LLZ_OK;
 }
 
+// 1: device memory of the CURRENT device; 0: host memory (the caller's buffer gets staged); LLZ_ERR_ARG: device memory that
+// lives on another GPU.  A handle binds its device before it classifies the caller's pointers, so a buffer of the wrong GPU
+// is refused here with a message instead of reaching a kernel (no peer access is ever enabled by this library).
 extern "C" int llzs_is_device_ptr(const void *p)
 {
     hipPointerAttribute_t attr;
@@ -135,14 +138,20 @@ extern "C" int llzs_is_device_ptr(const void *p)
         (void)hipGetLastError();       // plain malloc'ed host memory is "invalid value" here: not an error
         return 0;
     }
-    return attr.type == hipMemoryTypeDevice ? 1 : 0;
+    if (attr.type != hipMemoryTypeDevice) return 0;
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && attr.device != cur) {
+        llzs_set_error("buffer %p lives on GPU %d, the handle (or the current device) is GPU %d", p, attr.device, cur);
+        return LLZ_ERR_ARG;
+    }
+    return 1;
 }
 
 extern "C" void *llz_hip_malloc(size_t bytes) { return llzs_malloc(bytes); }
 extern "C" void llz_hip_free(void *p) { llzs_free(p); }
 extern "C" int llz_hip_upload(void *d, const void *h, size_t n) { return llzs_h2d(d, h, n, nullptr); }
 extern "C" int llz_hip_download(void *h, const void *d, size_t n) { return llzs_d2h(h, d, n, nullptr); }
-extern "C" int llz_hip_is_device_ptr(const void *p) { return llzs_is_device_ptr(p); }
+extern "C" int llz_hip_is_device_ptr(const void *p) { return llzs_is_device_ptr(p); }    // 1 / 0 / LLZ_ERR_ARG as above
 
 // ---- event timer on a caller-chosen stream -------------------------------------------------------
 struct llz_timer {

@@ -241,8 +241,24 @@ int llzs_matvec_exact_f64(const double *A, const double *x, double *y, int rows,
  * form; post 0 = the step in front of the transform, 1 = the step behind it; cs2: (cos, sin) pairs */
 int llzs_mdct_rot_f64(int quarter, int post, const double *in, double *out, const double *cs2, int N, int inverse,
                       double cof, void *stream);
-/* y[r] = sum_c (int)(((int64)x[c]*A[r][c]) >> 15), wrapping adds (llz_mdct_fixed.c:116-152) */
-int llzs_matvec_q15(const short *A, const int *x, int *y, int rows, int cols, void *stream);
+/* fixed-point MDCT steps (mdct_q15.hip), `count` frames per launch, int32 data, Q15 tables, wrapping adds:
+ * sums: y[f][r] = sum_c q15(x[f][c], A[r][c]) (llz_mdct_fixed.c:116-152), then (4 y) / quarter_over_n when that is not 0;
+ * step: the twiddle steps of the two FFT forms (llz_mdct_fixed.c:155-283); quarter 0 = N-point form, 1 = N/4-point form;
+ * post 0 = the step in front of the transform, 1 = the step behind it; tw: (cos, sin) Q15 pairs; cof = Q15 1/sqrt(N) */
+int llzs_mdctq_sums(const short *A, const int *x, int *y, int count, int rows, int cols, int quarter_over_n, void *stream);
+int llzs_mdctq_step(int quarter, int post, const int *in, int *out, const short *tw, int count, int N, int inverse,
+                    int cof, void *stream);
+/* framing of the single-channel analysis / synthesis symbols in double, exact order (frames_f64.hip; llz_asmodel.c:177-462):
+ * slide_window: held_next = (held << hop) ++ fresh, dst = held_next * window (interleaved complex with zero imaginary part
+ * when as_complex); split / mirror: interleaved spectrum <-> planes [re 0..N/2 | im 0..N/2]; overlap_add: acc + src * window,
+ * the first hop sums leave scaled, the rest slides down into acc_next, zeros enter at the top (acc != acc_next) */
+int llzs_frame_slide_window_f64(const double *fresh, const double *held, double *held_next, const double *window,
+                                double *dst, int N, int hop, int as_complex, void *stream);
+int llzs_spectrum_split_f64(const double *z, double *planes, int bins, void *stream);
+int llzs_spectrum_mirror_f64(const double *planes, double *z, int N, void *stream);
+int llzs_frame_overlap_add_f64(const double *src, int src_stride, const double *window, const double *acc,
+                               double *acc_next, double *leaving, int N, int hop, double scale, void *stream);
+int llzs_scale_4_over_n_f64(double *v, int n, double divisor, void *stream);   /* v = (v * 4) / divisor, two roundings */
 /* N/4-point-FFT MDCT / IMDCT of `count` float32 frames: forward [count][N] -> [count][N/2], inverse the other way;
  * tc/ts: cos/sin of -2*pi*(k+1/8)/N, k < N/4; cs: cos then sin of 2*pi*i/(N/4) */
 int llzs_mdct4_f32(const float *in, float *out, int count, int N, const float *tc, const float *ts, const float *cs,

@@ -627,6 +627,23 @@ class MdctFixed:
     def inverse(self, X):
         return self._run(self._L.llz_imdct_fixed, X, self.length)
 
+    def _batch(self, fn, what, a, b, n_in, n_out):
+        """a [count][n_in] -> b [count][n_out]: int32 numpy arrays (staged) or device tensors (in place, on the handle's stream)"""
+        count = int(a.shape[0])
+        assert tuple(a.shape) == (count, n_in) and tuple(b.shape) == (count, n_out)
+        check(fn(self.handle, _ptr(a), _ptr(b), count), what)
+        return b
+
+    def forward_batch(self, x, X):
+        return self._batch(self._L.llz_mdct_fixed_batch, "llz_mdct_fixed_batch", x, X, self.length, self.length // 2)
+
+    def inverse_batch(self, X, x):
+        return self._batch(self._L.llz_imdct_fixed_batch, "llz_imdct_fixed_batch", X, x, self.length // 2, self.length)
+
+    def set_stream(self, stream):
+        check(self._L.llz_mdct_fixed_set_stream(self.handle, C.c_void_p(stream.cuda_stream if stream is not None else 0)),
+              "llz_mdct_fixed_set_stream")
+
     def close(self):
         if getattr(self, "handle", 0):
             self._L.llz_mdct_fixed_uninit(self.handle)

@@ -141,6 +141,9 @@ int main(void)
     for (int type = 0; type < 3; type++) {
         h = llz_mdct_init(type, 256); CHECK(h != BAD); llz_mdct(h, dx, dy); llz_imdct(h, dy, dx); llz_mdct_uninit(h);
         h = llz_mdct_fixed_init(type, 256); CHECK(h != BAD); llz_mdct_fixed(h, (int *)fx, (int *)fy); llz_imdct_fixed(h, (int *)fy, (int *)fx);
+        CHECK(llz_mdct_fixed_len(h) == 256);
+        CHECK(llz_mdct_fixed_batch(h, (int *)fx, (int *)fy, 5) == 5 && llz_imdct_fixed_batch(h, (int *)fy, (int *)fx, 5) == 5);
+        CHECK(llz_mdct_fixed_batch(h, (int *)fx, (int *)fx, 1) < 0 && llz_mdct_fixed_batch(h, (int *)fx, (int *)fy, 0) < 0);
         llz_mdct_fixed_uninit(h);
     }
     h = llz_analysis_mdct_init(256, 0); CHECK(h != BAD); llz_analysis_mdct(h, dx, dy); llz_analysis_mdct_uninit(h);

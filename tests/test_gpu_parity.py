@@ -906,6 +906,39 @@ def test_mdct_reference_symbols_exact(dev):
         filters.Mdct(5, 64)
 
 
+@pytest.mark.parametrize("t,n,count", [(0, 16, 7), (0, 256, 40), (1, 16, 3), (1, 256, 129), (1, 4096, 5), (2, 8, 4), (2, 64, 1000),
+                                       (2, 2048, 37), (2, 16384, 3)])
+def test_mdct_fixed_batch_vs_oracle(dev, oracle, t, n, count):
+    """llz_mdct_fixed_batch / llz_imdct_fixed_batch: `count` frames per call on the device kernels (mdct_q15.hip + the Q15
+    transform), device tensors in place and host arrays staged, against the oracle's frame-by-frame llz_mdct_fixed (itself
+    pinned by the reference's fixtures): bit-exact, including inputs large enough to wrap the int32 sums"""
+    rng = np.random.default_rng(1000 * t + n + count)
+    x = rng.integers(-(1 << 20), 1 << 20, (count, n), dtype=np.int32)
+    x[0, : n // 2] = rng.integers(-(1 << 31), (1 << 31) - 1, n // 2, dtype=np.int64).astype(np.int32)   # wrap-around case
+    uniq = sorted(set([0, 1, count // 2, count - 1]) & set(range(count)))
+    m = filters.MdctFixed(t, n)
+    xd = torch.from_numpy(x).to(dev)
+    Xd = torch.empty(count, n // 2, dtype=torch.int32, device=dev)
+    m.forward_batch(xd, Xd)
+    yd = torch.empty(count, n, dtype=torch.int32, device=dev)
+    m.inverse_batch(Xd, yd)
+    torch.cuda.synchronize()
+    X, y = Xd.cpu().numpy(), yd.cpu().numpy()
+    for c in uniq:
+        ref_X = oracle.mdct_fixed(t, x[c])
+        assert np.array_equal(X[c], ref_X), (t, n, c)
+        assert np.array_equal(y[c], oracle.mdct_fixed(t, ref_X, inverse=True)), (t, n, c)
+    # host arrays go through the staging buffers; one frame per call is the reference's own symbol
+    Xh = np.zeros((count, n // 2), dtype=np.int32)
+    m.forward_batch(x, Xh)
+    assert np.array_equal(Xh, X)
+    assert np.array_equal(m.forward(x[count - 1]), X[count - 1])
+    assert np.array_equal(m.inverse(X[0]), y[0])
+    assert capi.lib().llz_mdct_fixed_batch(m.handle, xd.data_ptr(), Xd.data_ptr(), 0) < 0          # no frames: refused
+    assert capi.lib().llz_mdct_fixed_batch(m.handle, xd.data_ptr(), xd.data_ptr(), 1) < 0          # in place: refused
+    m.close()
+
+
 @pytest.mark.parametrize("n,count", [(32, 5), (64, 1000), (256, 33), (2048, 9), (8192, 3),
                                      # all six register-transform sizes (k_mdct_reg_f32), counts that leave partial workgroups
                                      (256, 1000), (512, 77), (1024, 50), (2048, 130), (4096, 21), (8192, 19)])
