@@ -73,6 +73,9 @@ def cpu_baseline(taps64, oracle_mod):
     one, dt1 = leg(1)
     allc, dta = leg(threads)
     return {"value": allc, "unit": "Msamples/s", "cores": threads, "kind": kind,
+            # NOT a whole-box figure when the process is given fewer cores than the host has: it is the rate of this slice
+            "scope": (f"{threads}-thread slice of a {online}-core host (cores this process may use)" if threads < online
+                      else f"all {online} cores of the host"),
             "sample": f"{threads} threads x {ch_per_thread} ch x {n} samples, {FLT_LEN}-tap llz_fir_filter, frame {frame} "
                       f"({dta:.1f} s); sysconf(_SC_NPROCESSORS_ONLN) = {online}",
             "single_core": {"value": one, "unit": "Msamples/s/core", "cores": 1,
@@ -148,6 +151,25 @@ def main():
     taps = filters.fir_design("lpf", FLT_LEN, 0.1, 0.0, filters.KAISER) if rank == 0 else np.zeros(FLT_LEN)
     taps = shard.broadcast_table(taps, src=0, device=comm_dev)
 
+    # every coefficient table the run needs is designed on rank 0 (host C code) and broadcast HERE, before anything is timed
+    # and outside every guarded block: setup collectives either work on all ranks or end the job
+    tables = {"fir257": taps}
+    if not args.no_also:
+        for t in (513, 1025, 2049):
+            d = filters.fir_design("lpf", t, 0.1, 0.0, filters.KAISER) if rank == 0 else np.zeros(t)
+            tables[f"fir{t}"] = shard.broadcast_table(d, src=0, device=comm_dev)
+        mat = None
+        if rank == 0:
+            r0 = filters.ResampleMC(1, 1, 3, 1.0, filters.BLACKMAN, filters.PCM_F32)
+            mat = r0.matrix()
+            r0.close()
+        shape = shard.broadcast_shape(mat.shape if rank == 0 else (0, 0), device=comm_dev)
+        tables["rs_1to3"] = shard.broadcast_table(mat if rank == 0 else np.zeros(shape), device=comm_dev)
+        for key, row in (("iir8_1024ch_sharded", [0.2066, 0.4131, 0.2066, 1.0, -0.3695, 0.1958]),
+                         ("iir8_r099_1024ch_sharded", [0.01, 0.0, -0.01, 1.0, -2 * 0.99 * np.cos(0.3), 0.99 ** 2])):
+            coef = np.tile(np.array(row), (8, 1)) if rank == 0 else np.zeros((8, 6))
+            tables[key] = shard.broadcast_table(coef, device=comm_dev)
+
     stream = torch.cuda.current_stream()
     x = torch.empty(channels, n, dtype=torch.float32, device=dev)
     y = torch.empty_like(x)
@@ -203,6 +225,7 @@ def main():
     parity = None
     also = {}
     cpu = None
+    orc = None
     if rank == 0:
         from oracle import pyoracle
         orc = pyoracle.Oracle()
@@ -230,51 +253,83 @@ def main():
         if world == 1 and not args.no_cpu:
             cpu = cpu_baseline(taps, pyoracle)
 
-    # long filters on the same batch (weak scaling like the headline): 513 taps on the 2048-point overlap-save, 1025 and
-    # 2049 taps on the 4096-point one (the library's own choice) -- under 'also', never part of `value`
-    def guarded(label, fn):
-        """the 'also' configs must not cost the headline line: a failure is reported under its label instead"""
+    # ---- 'also' configurations (never part of `value`) ----
+    # A block times its configurations LOCALLY (no collective inside, so a rank that fails cannot leave its peers waiting in
+    # one); after the block all ranks agree in ONE all-reduce (MAX) on an error flag and the per-configuration times.  A block
+    # that failed on any rank is reported as an error by every rank and the run goes on to the headline line.
+    agree_group = cpu_group                                   # None = the default group (gloo rehearsal runs)
+
+    def run_block(label, keys, fn):
+        entries, err = {}, None
         try:
-            return fn()
+            entries = fn()                                    # {key: (local ms, make(ms) -> dict)}
+            missing = [k for k in keys if k not in entries]
+            if missing:
+                raise RuntimeError("block returned no timing for " + ", ".join(missing))
         except Exception as e:  # noqa: BLE001
-            sys.stderr.write(f"bench.py: also/{label} failed: {e}\n")
-            return {label: {"error": str(e).splitlines()[0][:200]}}
+            err = str(e).splitlines()[0][:200] if str(e) else type(e).__name__
+            sys.stderr.write(f"bench.py: also/{label} failed on rank {rank}: {err}\n")
+        ms = [entries[k][0] if err is None else 0.0 for k in keys]
+        if world > 1:
+            vec = torch.tensor([1.0 if err else 0.0] + ms, dtype=torch.float64)
+            dist.all_reduce(vec, op=dist.ReduceOp.MAX, group=agree_group)
+            if vec[0].item() > 0:
+                return {label: {"error": err or "failed on another rank"}}
+            ms = vec[1:].tolist()
+        elif err:
+            return {label: {"error": err}}
+        return {k: entries[k][1](m) for k, m in zip(keys, ms)}
+
+    def time_local(fn, steps, warm=1):
+        """average device time of `steps` calls on this rank's stream (HIP events), after `warm` untimed calls"""
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        tm = L.llz_hip_timer_new()
+        L.llz_hip_timer_start(tm, sptr)
+        for _ in range(steps):
+            fn()
+        L.llz_hip_timer_stop(tm, sptr)
+        ms = L.llz_hip_timer_ms(tm) / steps
+        L.llz_hip_timer_free(tm)
+        return ms
+
+    ctx = dict(torch=torch, filters=filters, capi=capi, shard=shard, dev=dev, stream=stream, rank=rank, world=world,
+               time_local=time_local, orc=(orc if rank == 0 else None), tables=tables)
+
+    # long filters on the same batch (weak scaling like the headline): 513 taps on the 2048-point overlap-save, 1025 and
+    # 2049 taps on the 4096-point one (the library's own choice)
+    LONG = (513, 1025, 2049)
 
     def long_fir():
         res = {}
-        for long_taps in (513, 1025, 2049):
-            lt = filters.fir_design("lpf", long_taps, 0.1, 0.0, filters.KAISER)
-            lf = filters.FirFilterMC(channels, n, lt, stream=stream)
-            lf.filter(x, y)
-            torch.cuda.synchronize()
-            barrier()
-            tm = L.llz_hip_timer_new()
-            L.llz_hip_timer_start(tm, sptr)
-            for _ in range(3):
-                lf.filter(x, y)
-            L.llz_hip_timer_stop(tm, sptr)
-            lms = shard.max_over_ranks(L.llz_hip_timer_ms(tm) / 3, device=comm_dev)
-            L.llz_hip_timer_free(tm)
-            res[f"fir_{long_taps}taps_{channels}ch_per_gpu"] = {
-                "Msamples_s": channels * n * world / lms / 1e3, "GBs_per_gpu": BYTES_PER_SAMPLE * channels * n / lms / 1e6,
-                "hbm_frac_per_gpu": BYTES_PER_SAMPLE * channels * n / lms / 1e6 / HBM_PEAK_GBS, "ms": lms,
-                "channels_per_gpu": channels, "scaling": "weak",
-                "algorithm": {4: "overlap-save-2048", 5: "overlap-save-4096"}.get(lf.algo, str(lf.algo))}
+        for long_taps in LONG:
+            lf = filters.FirFilterMC(channels, n, tables[f"fir{long_taps}"], stream=stream)
+            lms = time_local(lambda: lf.filter(x, y), 3)
+            algo = {4: "overlap-save-2048", 5: "overlap-save-4096"}.get(lf.algo, str(lf.algo))
             lf.close()
+            res[f"fir_{long_taps}taps_{channels}ch_per_gpu"] = (lms, lambda ms, algo=algo: {
+                "Msamples_s": channels * n * world / ms / 1e3, "GBs_per_gpu": BYTES_PER_SAMPLE * channels * n / ms / 1e6,
+                "hbm_frac_per_gpu": BYTES_PER_SAMPLE * channels * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms,
+                "channels_per_gpu": channels, "scaling": "weak", "algorithm": algo})
         return res
 
     if not args.no_also and fir_algo == 2:
-        also.update(guarded("long_fir", long_fir))
+        also.update(run_block("long_fir", [f"fir_{t}taps_{channels}ch_per_gpu" for t in LONG], long_fir))
 
     # release the FIR batch before the other configs allocate theirs
     fir.close()
     del x, y
     torch.cuda.empty_cache()
     if not args.no_also:
-        also.update(guarded("sharded_configs",
-                            lambda: sharded_configs(torch, filters, capi, shard, dev, comm_dev, stream, rank, world, barrier)))
+        for label, keys, fn in sharded_blocks(ctx):
+            also.update(run_block(label, keys, fn))
+            torch.cuda.empty_cache()
     if not args.no_also and world == 1:
-        also.update(guarded("extra_paths", lambda: extra_paths(torch, filters, capi, dev, stream)))
+        also.update(run_block("extra_paths", EXTRA_KEYS, lambda: extra_paths(ctx)))
+        torch.cuda.empty_cache()
+        if torch.cuda.device_count() > 1:
+            also.update(run_block("sharded_c_abi", ["sharded_c_abi"], lambda: sharded_c_abi(ctx)))
 
     if rank == 0:
         achieved = BYTES_PER_SAMPLE * channels * n / (kern_ms * 1e-3) / 1e9      # GB/s, algorithmic bytes
@@ -309,6 +364,9 @@ def main():
                          "frac_of_memcpy_d2d": (achieved / memcpy_gbs) if memcpy_gbs else None},
             "cpu_baseline": cpu,
             "parity": parity,
+            # north_star's scaling target (>= 6x at 8 GPUs) is on the channel-sharded RESAMPLE, a fixed 8192 channels over the
+            # ranks (strong scaling): that curve is this entry's Msamples_in_s per N, not `value` (weak-scaled FIR)
+            "strong_scaling_metric": "also.resample_1to3_f32_8192ch_sharded.Msamples_in_s",
         }
         if also:
             line["also"] = also
@@ -318,118 +376,127 @@ def main():
         dist.destroy_process_group()
 
 
-def sharded_configs(torch, filters, capi, shard, dev, comm_dev, stream, rank, world, barrier):
-    """BASELINE configs 5 and 4 as the north star states them: a FIXED total channel count sharded over the ranks
-    (strong scaling), coefficient tables designed on rank 0 and broadcast (RCCL when the backend is nccl).
-    Reported under 'also'; the headline 'value' is the FIR above."""
-    L = capi.lib()
-    sptr = stream.cuda_stream
-    out = {}
+def _spread(channels, k=8):
+    """k channel indices spread over [0, channels)"""
+    return sorted(set(int(round(i * (channels - 1) / max(k - 1, 1))) for i in range(min(k, channels))))
 
-    def timed(fn, steps, warm=1):
-        for _ in range(warm):
-            fn()
-        torch.cuda.synchronize()
-        barrier()
-        t = L.llz_hip_timer_new()
-        L.llz_hip_timer_start(t, sptr)
-        for _ in range(steps):
-            fn()
-        L.llz_hip_timer_stop(t, sptr)
-        ms = L.llz_hip_timer_ms(t) / steps
-        L.llz_hip_timer_free(t)
-        return shard.max_over_ranks(ms, device=comm_dev)
+
+def sharded_blocks(ctx):
+    """BASELINE configs 5 and 4 as the north star states them: a FIXED total channel count sharded over the ranks (strong
+    scaling); the coefficient tables were designed on rank 0 and broadcast at setup (ctx["tables"]).  Reported under 'also';
+    the headline 'value' is the FIR.  Returns (label, keys, fn) blocks for run_block: fn times locally and returns
+    {key: (ms, make)}."""
+    torch, filters, shard = ctx["torch"], ctx["filters"], ctx["shard"]
+    dev, stream, rank, world, time_local, orc, tables = (ctx[k] for k in ("dev", "stream", "rank", "world", "time_local",
+                                                                          "orc", "tables"))
 
     # config 5: 8192-ch polyphase resample 48 kHz -> 16 kHz (L=1, M=3), 4 Mi samples/ch
-    total_ch = 8192
-    lo, hi = shard.channel_range(total_ch, rank, world)
-    ch = hi - lo
-    n = 3 * (((1 << 22) // 3) // 256 * 256)            # 4 Mi rounded down to whole 3:1 periods x 256
-    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
-    y = torch.empty(ch, n // 3, dtype=torch.float32, device=dev)
-    filters.synth_f32(x, SEED, chan0=lo, stream=stream)
-    r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, filters.PCM_F32, stream=stream)
-    shape = shard.broadcast_shape((1, r.Q) if rank == 0 else (0, 0), device=comm_dev)
-    mat = shard.broadcast_table(r.matrix() if rank == 0 else np.zeros(shape), device=comm_dev)
-    r.set_matrix(mat)                                   # every rank runs with rank 0's tap matrix
-    ms = timed(lambda: r.process(x, y), 3)
-    out["resample_1to3_f32_8192ch_sharded"] = {
-        "Msamples_in_s": total_ch * n / ms / 1e3, "GBs_per_gpu": (4 + 4 / 3) * ch * n / ms / 1e6,
-        "hbm_frac_per_gpu": (4 + 4 / 3) * ch * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "channels_per_gpu": ch,
-        "scaling": "strong"}
-    r.close()
-    del x, y
-    torch.cuda.empty_cache()
+    RS_CH = 8192
+    rs_n = 3 * (((1 << 22) // 3) // 256 * 256)            # 4 Mi rounded down to whole 3:1 periods x 256
 
-    # config 5, int16 PCM in and out (the reference resampler's own sample format): the bit-exact form (double accumulate
-    # in the reference's order) and the matrix-core form (within 1 LSB of it), same sharding and matrix broadcast
-    xi = torch.empty(ch, n, dtype=torch.int16, device=dev)
-    yi = torch.empty(ch, n // 3, dtype=torch.int16, device=dev)
-    filters.synth_i16(xi, SEED, chan0=lo, stream=stream)
-    for key, fmt, steps in (("resample_1to3_i16_exact_8192ch_sharded", filters.PCM_I16, 1),
-                            ("resample_1to3_i16_fast_8192ch_sharded", filters.PCM_I16_FAST, 3)):
-        r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, fmt, stream=stream)
-        r.set_matrix(mat)
-        ms = timed(lambda: r.process(xi, yi), steps)
-        out[key] = {"Msamples_in_s": total_ch * n / ms / 1e3, "GBs_per_gpu": (2 + 2 / 3) * ch * n / ms / 1e6,
-                    "hbm_frac_per_gpu": (2 + 2 / 3) * ch * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms,
-                    "channels_per_gpu": ch, "scaling": "strong",
-                    "parity": "bit-exact" if fmt == filters.PCM_I16 else "within 1 LSB of the reference"}
+    def rs_entry(total_ch, ch, n, bytes_per_in, extra=None):
+        def make(ms):
+            e = {"Msamples_in_s": total_ch * n / ms / 1e3, "GBs_per_gpu": bytes_per_in * ch * n / ms / 1e6,
+                 "hbm_frac_per_gpu": bytes_per_in * ch * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "channels_per_gpu": ch,
+                 "scaling": "strong"}
+            e.update(extra or {})
+            return e
+        return make
+
+    def resample_f32():
+        lo, hi = shard.channel_range(RS_CH, rank, world)
+        ch = hi - lo
+        x = torch.empty(ch, rs_n, dtype=torch.float32, device=dev)
+        y = torch.empty(ch, rs_n // 3, dtype=torch.float32, device=dev)
+        filters.synth_f32(x, SEED, chan0=lo, stream=stream)
+        r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, filters.PCM_F32, stream=stream)
+        r.set_matrix(tables["rs_1to3"])                     # every rank runs with rank 0's tap matrix
+        ms = time_local(lambda: r.process(x, y), 3)
         r.close()
-    del xi, yi
-    torch.cuda.empty_cache()
+        return {"resample_1to3_f32_8192ch_sharded": (ms, rs_entry(RS_CH, ch, rs_n, 4 + 4 / 3))}
 
-    # config 4: 1024-ch IIR, 8-biquad cascade, 1 Mi samples/ch
-    total_ch = 1024
-    lo, hi = shard.channel_range(total_ch, rank, world)
-    ch = hi - lo
-    n = 1 << 20
-    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
-    y = torch.empty_like(x)
-    filters.synth_f32(x, SEED, chan0=lo, stream=stream)
-    # two coefficient sets (SURVEY.md 8d config 4): 8 copies of the in-tree low-pass section (pole radius 0.44, float32
-    # arithmetic passes the noise-gain check) and 8 high-Q sections at pole radius 0.99 (double arithmetic)
-    for key, row in (("iir8_1024ch_sharded", [0.2066, 0.4131, 0.2066, 1.0, -0.3695, 0.1958]),
-                     ("iir8_r099_1024ch_sharded", [0.01, 0.0, -0.01, 1.0, -2 * 0.99 * np.cos(0.3), 0.99 ** 2])):
-        coef = np.tile(np.array(row), (8, 1)) if rank == 0 else np.zeros((8, 6))
-        coef = shard.broadcast_table(coef, device=comm_dev)
-        q = filters.IirCascadeMC(ch, coef, stream=stream)
-        ms = timed(lambda: q.filter(x, y), 20, warm=10)      # a 2 ms kernel: clocks need tens of ms to settle after idling
-        # packed-FMA equivalents per sample and section: 6 in the float32 kernel (b0 folded into one input gain), 7 in double
-        fma = 6 if q.precision == 32 else 7
-        out[key] = {
-            "Msamples_s": total_ch * n / ms / 1e3, "GBs_per_gpu": 8 * ch * n / ms / 1e6,
-            "hbm_frac_per_gpu": 8 * ch * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "channels_per_gpu": ch,
-            "scaling": "strong",
-            # the binding roof of this kernel is the vector pipe, not HBM (DESIGN.md K2): float32 when every section's
-            # rounding-noise gain allows it, else double
-            "arithmetic": "f32" if q.precision == 32 else "f64",
-            "valu_TFLOPs_per_gpu": 2 * fma * 8 * ch * n / ms / 1e9,
-            "valu_peak_TFLOPs": 157.3 if q.precision == 32 else 78.6,
-            "valu_frac_per_gpu": 2 * fma * 8 * ch * n / ms / 1e9 / (157.3 if q.precision == 32 else 78.6)}
-        q.close()
-    del x, y
-    torch.cuda.empty_cache()
-    return out
+    # config 5, int16 PCM in and out (the reference resampler's own sample format): the bit-exact form (screened on the matrix
+    # cores, the reference's double order where the screen cannot decide) and the matrix-core fp32-accumulate form (within 1
+    # LSB), same sharding and matrix.  `parity` is COMPUTED here (rank 0, outside the timed region): spread channels x the
+    # first 64 Ki outputs against the oracle's llz_resample loop.
+    def resample_i16():
+        lo, hi = shard.channel_range(RS_CH, rank, world)
+        ch = hi - lo
+        xi = torch.empty(ch, rs_n, dtype=torch.int16, device=dev)
+        yi = torch.empty(ch, rs_n // 3, dtype=torch.int16, device=dev)
+        filters.synth_i16(xi, SEED, chan0=lo, stream=stream)
+        out = {}
+        for key, fmt, steps in (("resample_1to3_i16_exact_8192ch_sharded", filters.PCM_I16, 2),
+                                ("resample_1to3_i16_fast_8192ch_sharded", filters.PCM_I16_FAST, 3)):
+            r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, fmt, stream=stream)
+            r.set_matrix(tables["rs_1to3"])
+            ms = time_local(lambda: r.process(xi, yi), steps)
+            r.close()
+            out[key] = (ms, rs_entry(RS_CH, ch, rs_n, 2 + 2 / 3, {"parity": i16_parity(orc, xi, yi, 1, 3, 1 << 16)}))
+        return out
+
+    # config 4: 1024-ch IIR, 8-biquad cascade, 1 Mi samples/ch; two coefficient sets (SURVEY.md 8d config 4): 8 copies of the
+    # in-tree low-pass section (pole radius 0.44, float32 arithmetic passes the noise-gain check) and 8 high-Q sections at
+    # pole radius 0.99 (double arithmetic)
+    IIR_CH = 1024
+
+    def iir():
+        lo, hi = shard.channel_range(IIR_CH, rank, world)
+        ch = hi - lo
+        n = 1 << 20
+        x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+        y = torch.empty_like(x)
+        filters.synth_f32(x, SEED, chan0=lo, stream=stream)
+        out = {}
+        for key in ("iir8_1024ch_sharded", "iir8_r099_1024ch_sharded"):
+            q = filters.IirCascadeMC(ch, tables[key], stream=stream)
+            ms = time_local(lambda: q.filter(x, y), 20, warm=10)   # a 2 ms kernel: clocks need tens of ms to settle after idling
+            prec = q.precision
+            q.close()
+
+            def make(ms, prec=prec, ch=ch):
+                # FMA equivalents per sample and section: 6 in the float32 kernel (b0 folded into one input gain), 7 in double
+                fma = 6 if prec == 32 else 7
+                peak = 157.3 if prec == 32 else 78.6
+                return {"Msamples_s": IIR_CH * n / ms / 1e3, "GBs_per_gpu": 8 * ch * n / ms / 1e6,
+                        "hbm_frac_per_gpu": 8 * ch * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "channels_per_gpu": ch,
+                        "scaling": "strong",
+                        # the binding roof of this kernel is the vector pipe, not HBM (DESIGN.md K2)
+                        "arithmetic": "f32" if prec == 32 else "f64",
+                        "valu_TFLOPs_per_gpu": 2 * fma * 8 * ch * n / ms / 1e9, "valu_peak_TFLOPs": peak,
+                        "valu_frac_per_gpu": 2 * fma * 8 * ch * n / ms / 1e9 / peak}
+            out[key] = (ms, make)
+        return out
+
+    return [("resample_f32", ["resample_1to3_f32_8192ch_sharded"], resample_f32),
+            ("resample_i16", ["resample_1to3_i16_exact_8192ch_sharded", "resample_1to3_i16_fast_8192ch_sharded"], resample_i16),
+            ("iir", ["iir8_1024ch_sharded", "iir8_r099_1024ch_sharded"], iir)]
 
 
-def extra_paths(torch, filters, capi, dev, stream):
+def i16_parity(orc, xi, yi, L_, M_, n_out_check, gain=1.0, win=1):
+    """compare spread channels x the first n_out_check outputs of an int16 resampler run with the oracle's llz_resample loop
+    (rank 0 only; None elsewhere).  xi / yi: the device tensors of a FIRST call on a fresh handle (zero history)."""
+    if orc is None:
+        return None
+    info = orc.rs_info(2, L_, M_, gain, win)
+    nin, nout = info["bytes_in"] // 2, info["bytes_out"] // 2
+    frames = max(1, min(n_out_check // nout, xi.shape[1] // nin))
+    sel = _spread(xi.shape[0])
+    ref = orc.rs_batch_i16(xi[sel, : frames * nin].cpu().numpy(), L_, M_, gain, win)
+    got = yi[sel, : frames * nout].cpu().numpy()
+    diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    return {"checked": f"{len(sel)} ch x {frames * nout} outputs vs oracle llz_resample", "mismatches": int((diff != 0).sum()),
+            "max_abs_diff_lsb": int(diff.max()), "bit_exact": bool((diff == 0).all())}
+
+
+EXTRA_KEYS = ["fir63_64ch_time_domain", "fir63_64ch_overlap_save", "resample_147to160_f32_256ch", "resample_160to147_f32_256ch",
+              "resample_147to160_i16_256ch", "resample_160to147_i16_256ch"]
+
+
+def extra_paths(ctx):
     """Other BASELINE.json configs on one GPU, few steps each (context, not the headline)."""
-    L = capi.lib()
-    sptr = stream.cuda_stream
+    torch, filters, dev, stream, time_local, orc = (ctx[k] for k in ("torch", "filters", "dev", "stream", "time_local", "orc"))
     out = {}
-
-    def timeit(fn, steps=3):
-        fn()
-        torch.cuda.synchronize()
-        t = L.llz_hip_timer_new()
-        L.llz_hip_timer_start(t, sptr)
-        for _ in range(steps):
-            fn()
-        L.llz_hip_timer_stop(t, sptr)
-        ms = L.llz_hip_timer_ms(t) / steps
-        L.llz_hip_timer_free(t)
-        return ms
 
     # config 2: 64 ch x 63 taps x 1 Mi on its stated algorithm (time domain) and on the library's own choice
     ch, n = 64, 1 << 20
@@ -439,25 +506,76 @@ def extra_paths(torch, filters, capi, dev, stream):
     taps63 = filters.fir_design("lpf", 63, 0.25, 0.0, filters.HAMMING)
     for name, algo in (("fir63_64ch_time_domain", filters.FIR_ALGO_TIME), ("fir63_64ch_overlap_save", filters.FIR_ALGO_OVERLAP_SAVE)):
         f = filters.FirFilterMC(ch, n, taps63, algo=algo, stream=stream)
-        ms = timeit(lambda: f.filter(x, y), 10)
-        out[name] = {"Msamples_s": ch * n / ms / 1e3, "GBs": 8 * ch * n / ms / 1e6,
-                     "hbm_frac": 8 * ch * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms}
+        ms = time_local(lambda: f.filter(x, y), 10)
+        out[name] = (ms, lambda ms, ch=ch, n=n: {"Msamples_s": ch * n / ms / 1e3, "GBs": 8 * ch * n / ms / 1e6,
+                                                  "hbm_frac": 8 * ch * n / ms / 1e6 / HBM_PEAK_GBS, "ms": ms})
         f.close()
     del x, y
-    # the reference CLI's default ratio 147:160 (48 kHz -> 44.1 kHz) and its inverse, 256 channels, float32 (general L/M path)
+    # the reference CLI's default ratio 147:160 (48 kHz -> 44.1 kHz) and its inverse, 256 channels (general L/M path): float32,
+    # and the reference's own int16 format, bit-exact (parity computed against the oracle, outside the timed region)
     for (L_, M_) in ((147, 160), (160, 147)):
         ch, n = 256, M_ * 8192
         x = torch.empty(ch, n, dtype=torch.float32, device=dev)
         y = torch.empty(ch, n * L_ // M_, dtype=torch.float32, device=dev)
         filters.synth_f32(x, SEED, stream=stream)
         r = filters.ResampleMC(ch, L_, M_, 1.0, filters.BLACKMAN, filters.PCM_F32, stream=stream)
-        ms = timeit(lambda: r.process(x, y), 20)
-        gb = (4 + 4 * L_ / M_) * ch * n / ms / 1e6
-        out[f"resample_{L_}to{M_}_f32_256ch"] = {"Msamples_in_s": ch * n / ms / 1e3, "GBs": gb, "hbm_frac": gb / HBM_PEAK_GBS,
-                                                "ms": ms}
+        ms = time_local(lambda: r.process(x, y), 20)
         r.close()
+
+        def make(ms, ch=ch, n=n, bpi=4 + 4 * L_ / M_, extra=None):
+            gb = bpi * ch * n / ms / 1e6
+            e = {"Msamples_in_s": ch * n / ms / 1e3, "GBs": gb, "hbm_frac": gb / HBM_PEAK_GBS, "ms": ms}
+            e.update(extra or {})
+            return e
+        out[f"resample_{L_}to{M_}_f32_256ch"] = (ms, make)
         del x, y
+        xi = torch.empty(ch, n, dtype=torch.int16, device=dev)
+        yi = torch.empty(ch, n * L_ // M_, dtype=torch.int16, device=dev)
+        filters.synth_i16(xi, SEED, stream=stream)
+        r = filters.ResampleMC(ch, L_, M_, 1.0, filters.BLACKMAN, filters.PCM_I16, stream=stream)
+        ms = time_local(lambda: r.process(xi, yi), 5)
+        r.close()
+        par = i16_parity(orc, xi, yi, L_, M_, 1 << 16)
+        out[f"resample_{L_}to{M_}_i16_256ch"] = (ms, lambda ms, ch=ch, n=n, bpi=2 + 2 * L_ / M_, par=par, make=make:
+                                                  make(ms, ch, n, bpi, {"parity": par}))
+        del xi, yi
     return out
+
+
+def sharded_c_abi(ctx):
+    """The library's OWN multi-GPU path (include/llz_shard.h: one process, one handle, ncclCommInitAll + ncclBroadcast of the
+    tables at init), reachable when one process sees several GPUs: BASELINE config 5 (8192 ch, 1:3, float32) through
+    llz_resample_mc_sharded over all visible devices, timed with llz_sharded_timer_* (per-GPU events, max reported)."""
+    torch, filters, capi = ctx["torch"], ctx["filters"], ctx["capi"]
+    ndev = torch.cuda.device_count()
+    devices = list(range(ndev))
+    total_ch = 8192
+    n = 3 * (((1 << 22) // 3) // 256 * 256)
+    h = filters.ResampleMCSharded(total_ch, 1, 3, 1.0, filters.BLACKMAN, filters.PCM_F32, devices)
+    xs, ys = h.alloc(n, torch.float32), h.alloc(n // 3, torch.float32)
+    for (d, c0, _cnt), x in zip(h.shards, xs):
+        with torch.cuda.device(d):
+            capi.check(capi.lib().llz_hip_set_device(d), "llz_hip_set_device")
+            filters.synth_f32(x, SEED, chan0=c0, stream=torch.cuda.current_stream(d))
+            torch.cuda.synchronize(d)
+    capi.check(capi.lib().llz_hip_set_device(ctx["dev"].index), "llz_hip_set_device")
+    h.process(xs, ys)
+    h.synchronize()
+    steps = 3
+    h.timer_start()
+    for _ in range(steps):
+        h.process(xs, ys)
+    h.timer_stop()
+    ms, per = h.timer_ms()
+    ms, per = ms / steps, [float(v) / steps for v in per]
+    ranks = h.rccl_ranks
+    h.close()
+
+    def make(ms):
+        return {"workload": f"{total_ch}-ch resample 1:3 float32, {n} samples/ch, one process, {ndev} GPUs through "
+                            "llz_resample_mc_sharded", "Msamples_in_s": total_ch * n / ms / 1e3, "ms": ms,
+                "per_shard_ms": per, "n_devices": ndev, "rccl_ranks": ranks, "scaling": "strong"}
+    return {"sharded_c_abi": (ms, make)}
 
 
 if __name__ == "__main__":

@@ -54,6 +54,8 @@ long llz_resample_mc_sharded(unsigned long handle, const void *const *in, long n
 /* ---- common to the three kinds ---- */
 void llz_sharded_uninit(unsigned long handle);
 int  llz_sharded_count(unsigned long handle);                                   /* number of shards */
+int  llz_sharded_rccl_ranks(unsigned long handle);   /* ranks of the RCCL communicator that carried the coefficient tables at
+                                                      * init: the number of distinct devices, 0 when all shards share one GPU */
 int  llz_sharded_shard(unsigned long handle, int shard, int *device, int *chan0, int *count);
 void *llz_sharded_stream(unsigned long handle, int shard);                      /* hipStream_t of a shard */
 unsigned long llz_sharded_sub(unsigned long handle, int shard);                 /* the shard's own *_mc handle */

@@ -251,6 +251,7 @@ def lib():
     sig("llz_resample_mc_sharded", lng, ul, pp, lng, pp)
     sig("llz_sharded_uninit", None, ul)
     sig("llz_sharded_count", i, ul)
+    sig("llz_sharded_rccl_ranks", i, ul)
     sig("llz_sharded_shard", i, ul, i, ip, ip, ip)
     sig("llz_sharded_stream", vp, ul, i)
     sig("llz_sharded_sub", ul, ul, i)

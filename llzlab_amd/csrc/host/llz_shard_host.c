@@ -14,7 +14,7 @@ enum { SHARD_FIR = 1, SHARD_IIR = 2, SHARD_RS = 3 };
 #define SHARD_MAX 64
 
 typedef struct {
-    int tag, kind, n, channels;
+    int tag, kind, n, channels, rccl_ranks;
     int device[SHARD_MAX], chan0[SHARD_MAX], count[SHARD_MAX];
     unsigned long sub[SHARD_MAX];
     void *stream[SHARD_MAX];
@@ -111,6 +111,7 @@ static unsigned long shard_create(int kind, int channels, const int *devices, in
         rc = shard_sub_set_stream(kind, g->sub[s], g->stream[s]);
     }
     if (rc == LLZ_OK) rc = llzs_tables_broadcast(tab_ptr, ntab, n_devices, g->device, g->stream);
+    if (rc == LLZ_OK) g->rccl_ranks = llzs_tables_broadcast_ranks();
     if (prev >= 0) llzs_device_set(prev);
     if (rc != LLZ_OK) {
         shard_destroy(g);
@@ -227,6 +228,12 @@ int llz_sharded_count(unsigned long handle)
 {
     shard_t *g = shard_of(handle, 0, "llz_sharded_count");
     return g ? g->n : LLZ_ERR_ARG;
+}
+
+int llz_sharded_rccl_ranks(unsigned long handle)
+{
+    shard_t *g = shard_of(handle, 0, "llz_sharded_rccl_ranks");
+    return g ? g->rccl_ranks : LLZ_ERR_ARG;
 }
 
 int llz_sharded_shard(unsigned long handle, int shard, int *device, int *chan0, int *count)

@@ -163,9 +163,13 @@ rccl_api &rccl()
 
 } // namespace
 
+static thread_local int g_last_comm_ranks = 0;
+extern "C" int llzs_tables_broadcast_ranks(void) { return g_last_comm_ranks; }
+
 extern "C" int llzs_tables_broadcast(llzs_table_ref *const *tables, int ntables, int nshards, const int *device,
                                      void *const *stream)
 {
+    g_last_comm_ranks = 0;
     if (!tables || !device || !stream || nshards < 1 || ntables < 0 || nshards > 64) {
         llzs_set_error("tables_broadcast: bad arguments");
         return LLZ_ERR_ARG;
@@ -199,6 +203,7 @@ extern "C" int llzs_tables_broadcast(llzs_table_ref *const *tables, int ntables,
         // shard 0's uploads ran on the default stream and were synchronous for the host: the data is there
         LLZ_NCCL_CHECK(R.CommInitAll(comm, nu, udev));
         ncomm = nu;
+        g_last_comm_ranks = nu;
         for (int t = 0; t < ntables; t++) {
             LLZ_NCCL_CHECK(R.GroupStart());
             for (int u = 0; u < nu; u++) {

@@ -79,6 +79,7 @@ int  llzs_h2d_table(void *dev_dst, const void *host_src, size_t bytes);
  * the distinct devices (ncclCommInitAll, librccl loaded on first use) and hands copies to its further shards. */
 int  llzs_tables_broadcast(llzs_table_ref *const *tables, int ntables, int nshards, const int *device,
                            void *const *stream);
+int  llzs_tables_broadcast_ranks(void);     /* ranks of the RCCL communicator the last broadcast of this thread used (0: none) */
 
 /* ---- FIR ---- */
 #define LLZS_FIR_TAP_PAD 8      /* time-domain kernels read taps in groups of 8: pad the table with zeros */

@@ -762,8 +762,23 @@ class _Sharded:
         return (C.c_void_p * self.n_shards)(*[_ptr(b) for b in bufs])
 
     def split(self, tensor):
-        """views of a [channels, ...] tensor / array, one per shard (all shards on the tensor's device, or host memory)"""
+        """views of a [channels, ...] tensor / array, one per shard.  Host arrays are staged by each shard; a DEVICE tensor can
+        only serve shards that live on its own GPU (the library refuses a buffer of another device, it never enables peer
+        access), so with shards on several GPUs allocate per shard instead: see alloc()."""
+        if hasattr(tensor, "is_cuda") and tensor.is_cuda:
+            other = sorted({d for (d, _c0, _cnt) in self.shards if d != tensor.device.index})
+            if other:
+                raise LlzError(f"split(): tensor is on cuda:{tensor.device.index}, shards also live on GPU(s) {other}")
         return [tensor[c0:c0 + cnt] for (_d, c0, cnt) in self.shards]
+
+    def alloc(self, per_channel, dtype):
+        """one torch tensor [count, per_channel] per shard, each on its shard's GPU"""
+        import torch
+        return [torch.empty(cnt, per_channel, dtype=dtype, device=torch.device("cuda", d)) for (d, _c0, cnt) in self.shards]
+
+    @property
+    def rccl_ranks(self):
+        return check(self._L.llz_sharded_rccl_ranks(self.handle), "llz_sharded_rccl_ranks")
 
     def synchronize(self):
         check(self._L.llz_sharded_synchronize(self.handle), "llz_sharded_synchronize")

@@ -7,7 +7,7 @@ gloo in the CPU tests.  There is no steady-state collective.
 import numpy as np
 
 # how the setup collectives travelled in this process: "rccl" (device tensors over the nccl backend), "gloo" (host tensors), and
-# the reason if the device path was given up (one failure switches every later call to the host group)
+# the reason if the device path was given up (one failure on ANY rank switches every later call of EVERY rank to the host group)
 _state = {"cpu_group": None, "device_ok": True, "used": [], "error": None}
 
 
@@ -23,21 +23,51 @@ def transport():
 
 
 def _device_collective(t, device, fn):
-    """run fn(tensor) on a device copy of t over the default (nccl) group; on failure fall back to the host group for good"""
+    """run fn(tensor) on a device copy of t over the default (nccl) group.  Whether the device path worked is decided by ALL
+    ranks together (a MIN all-reduce of an ok flag over the host group): if any rank failed -- communicator creation or the
+    collective itself -- every rank repeats the operation on the host group and stays there; a rank never falls back alone
+    (it would enter a collective no peer joins).  Without a host group to agree on, a failure is raised."""
     import torch
+    import torch.distributed as dist
 
-    if device is not None and _state["device_ok"]:
-        try:
+    if device is None:                                   # the default group carries host tensors (gloo runs, CPU tests)
+        h = t.clone()
+        fn(h, None)
+        _state["used"].append("gloo")
+        return h
+    cpu_group = _state["cpu_group"]
+
+    def agreed(err):
+        """True when NO rank reported an error (MIN all-reduce over the host group); without a host group: this rank's own"""
+        if cpu_group is None:
+            return err is None
+        ok = torch.tensor([1 if err is None else 0], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=cpu_group)
+        return int(ok.item()) == 1
+
+    if _state["device_ok"]:
+        d, err = None, None
+        try:                                             # phase 1, local: the tensor reaches this rank's device
             d = t.to(device)
-            fn(d, None)
-            torch.cuda.synchronize()
-            _state["used"].append("rccl")
-            return d.cpu()
-        except Exception as e:  # noqa: BLE001  (communicator creation or the collective itself)
-            _state["device_ok"] = False
-            _state["error"] = str(e).splitlines()[0][:160]
+        except Exception as e:  # noqa: BLE001
+            err = str(e).splitlines()[0][:160]
+        if agreed(err):
+            try:                                         # phase 2: the collective itself (communicator creation included)
+                fn(d, None)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                err = str(e).splitlines()[0][:160]
+            if agreed(err):
+                _state["used"].append("rccl")
+                return d.cpu()
+        if cpu_group is None:
+            raise RuntimeError("device collective failed and there is no host group to fall back to: " + str(err))
+        _state["device_ok"] = False
+        _state["error"] = err or "a peer rank's device collective failed"
+    if cpu_group is None:
+        raise RuntimeError("device collectives were given up and there is no host group to fall back to")
     h = t.clone()
-    fn(h, _state["cpu_group"] if device is not None else None)
+    fn(h, cpu_group)
     _state["used"].append("gloo")
     return h
 

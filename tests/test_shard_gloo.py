@@ -43,9 +43,14 @@ def _worker(rank, world, port, q):
         # reported
         if not __import__("torch").cuda.is_available():
             shard.use_cpu_group(dist.new_group(backend="gloo"))
-            again = shard.broadcast_table(taps, device="cuda:0")
+            # ONE rank fails (rank 1 has no such device; rank 0's "device" is the CPU, which works): the fallback must be a
+            # decision of all ranks -- rank 0 may not stay on the device path while rank 1 waits in the host group
+            again = shard.broadcast_table(taps, device="cpu" if rank == 0 else "cuda:0")
             assert again.tobytes() == got.tobytes() and "rccl failed" in shard.transport(), shard.transport()
+            assert shard._state["device_ok"] is False                  # on BOTH ranks, also the one whose own step worked
             assert shard.max_over_ranks(5.0 - rank, device="cuda:0") == 5.0
+            shape2 = shard.broadcast_shape((7, 9) if rank == 0 else (0, 0), device="cuda:0")
+            assert shape2 == (7, 9)
         q.put((rank, got.tobytes(), shape, float(gotm.sum()), t, lo, hi))
     finally:
         dist.destroy_process_group()

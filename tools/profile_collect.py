@@ -48,18 +48,40 @@ json.dump(warm, open(os.path.join(dst, f"{tag}_headline_kernel_trace.json"), "w"
 
 
 def counters(sub):
+    """{(kernel name, grid size): {counter: [value per dispatch]}} plus the dispatch durations (ms) under the key "_ms".
+    One kernel name can be launched with several grids in one run (the headline batch and the 64-channel config share
+    k_fir_ols_chain_f32): dispatches are told apart by (name, grid), never averaged across grids."""
     f = newest(f"{src}/{sub}/*/*_counter_collection.csv")
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    seen = set()
     for r in csv.DictReader(open(f)):
-        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        key = (r["Kernel_Name"], r["Grid_Size"])
+        agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if (key, r["Dispatch_Id"]) not in seen:
+            seen.add((key, r["Dispatch_Id"]))
+            agg[key]["_ms"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     return agg
 
 
-def pick(agg, needle):
-    for k, v in agg.items():
-        if needle in k:
-            return {c: sum(x) / len(x) for c, x in v.items()}, {c: len(x) for c, x in v.items()}
-    return {}, {}
+def pick(agg, needle, grid=None):
+    """per-launch averages of the dispatches of ONE (kernel, grid): the grid asked for, else the heaviest group (longest mean
+    duration) -- for the headline kernel that is the 4096-channel batch"""
+    groups = [(k, v) for k, v in agg.items() if needle in k[0] and (grid is None or str(grid) == k[1])]
+    if not groups:
+        return {}, {}
+    k, v = max(groups, key=lambda kv: sum(kv[1]["_ms"]) / len(kv[1]["_ms"]))
+    avg = {c: sum(x) / len(x) for c, x in v.items()}
+    avg["_grid"] = int(k[1])
+    return avg, {c: len(x) for c, x in v.items()}
+
+
+def by_name(agg):
+    """{kernel name: {counter: [values]}} of each name's heaviest grid (for the per-kernel utilisation table)"""
+    out = {}
+    for name in {k[0] for k in agg}:
+        groups = [(k, v) for k, v in agg.items() if k[0] == name]
+        out[name] = max(groups, key=lambda kv: sum(kv[1]["_ms"]) / len(kv[1]["_ms"]))[1]
+    return out
 
 
 fetch, nf = pick(counters("pmc_fetch"), kern)
@@ -68,6 +90,7 @@ tailf, _ = pick(counters("pmc_fetch"), "k_fir_tail_f32")
 synw, _ = pick(counters("pmc_write"), "k_synth_f32")
 out = {
     "kernel": kern,
+    "grid": fetch.get("_grid"),
     "FETCH_SIZE_KB_per_launch_raw": fetch["FETCH_SIZE"], "FETCH_SIZE_launches": nf["FETCH_SIZE"],
     "WRITE_SIZE_KB_per_launch_raw": write["WRITE_SIZE"], "WRITE_SIZE_launches": nw["WRITE_SIZE"],
     "fetch_bytes_per_launch_corrected_x2": 2 * fetch["FETCH_SIZE"] * 1024,
@@ -95,27 +118,50 @@ for name in ("bench.json", "bench_under_rocprof.json"):
     line = json.loads(open(path).read())
     line["roofline"]["traffic"] = out["headline_kernel_bytes_per_launch"]
     open(path, "w").write(json.dumps(line) + "\n")
-sq = {}
+sq, per_pass = {}, {}
 for sub in ("pmc_sq1", "pmc_sq2"):
-    v, _ = pick(counters(sub), kern)
+    v, cnt = pick(counters(sub), kern)
+    per_pass[sub] = {"grid": v.pop("_grid", None), "launch_ms_in_this_pass": v.pop("_ms", None), "launches": max(cnt.values())}
     sq.update(v)
+# what the counters say about the vector pipe (units: SQ_INSTS_* count wave-instructions; SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES /
+# SQ_WAIT_* count quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs -- MI355X_MICROARCH.md)
+SIMDS = 1024
+derived = {}
+if "GRBM_GUI_ACTIVE" in sq:
+    cyc = sq["GRBM_GUI_ACTIVE"] / 8
+    ms2 = per_pass["pmc_sq2"]["launch_ms_in_this_pass"]
+    derived["shader_cycles_per_launch"] = cyc
+    derived["shader_clock_GHz_during_kernel"] = cyc / (ms2 * 1e6)
+    if "SQ_INSTS_VALU" in sq:
+        derived["valu_wave_instructions_per_simd"] = sq["SQ_INSTS_VALU"] / SIMDS
+        derived["shader_cycles_per_valu_instruction_per_simd"] = cyc / (sq["SQ_INSTS_VALU"] / SIMDS)
+    if "SQ_ACTIVE_INST_VALU" in sq:
+        # measured in the OTHER pass: scale its launch time to cycles with this pass's clock
+        cyc1 = derived["shader_clock_GHz_during_kernel"] * per_pass["pmc_sq1"]["launch_ms_in_this_pass"] * 1e6
+        derived["valu_active_fraction_of_simd_cycles"] = 4 * sq["SQ_ACTIVE_INST_VALU"] / (SIMDS * cyc1)
+        derived["wave_cycles_fraction_waiting"] = sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]
+        derived["wave_cycles_fraction_issue_stalled"] = sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]
+        derived["mean_waves_per_simd"] = 4 * sq["SQ_WAVE_CYCLES"] / (SIMDS * cyc1)
 with open(os.path.join(dst, f"{tag}_sq_counters.json"), "w") as f:
-    json.dump({"kernel": kern, "per_launch_average": sq,
-               "command": "rocprofv3 --pmc <8 counters> -- python3 bench.py --steps 3 --warmup 1 --no-cpu (two passes)"},
+    json.dump({"kernel": kern, "per_launch_average": sq, "passes": per_pass, "derived": derived,
+               "selection": "dispatches of the kernel's heaviest (name, grid) group only: other grids of the same kernel name "
+                            "(the 64-channel config) are not averaged in",
+               "command": "rocprofv3 --pmc <8 counters> -- python3 bench.py --steps 3 --warmup 1 --no-cpu [--no-also] (two passes)"},
               f, indent=1)
 # matrix-pipe utilisation of the kernels that use MFMA (north_star: "MFMA utilisation reported"): busy cycles of the matrix
 # pipe over the SIMD-cycles of the dispatch (duration x shader clock x 1024 SIMDs; clock from GRBM_GUI_ACTIVE of the sq2 pass)
-mf = counters("pmc_mfma")
-sq2 = counters("pmc_sq2")
+mf = by_name(counters("pmc_mfma"))
+sq2 = by_name(counters("pmc_sq2"))
 stats = {r["Name"]: r for r in csv.DictReader(open(newest(src + "/stats/*/*_kernel_stats.csv")))}
 util = {}
 for name, v in mf.items():
     busy = v.get("SQ_VALU_MFMA_BUSY_CYCLES")
     if not busy or sum(busy) == 0:
         continue
-    ns = float(stats[name]["AverageNs"]) if name in stats else None
-    gui = sq2.get(name, {}).get("GRBM_GUI_ACTIVE")
-    clock_ghz = (sum(gui) / len(gui) / 8) / ns if (gui and ns) else None
+    ns = 1e6 * sum(v["_ms"]) / len(v["_ms"])                 # this pass's own dispatch durations
+    g2 = sq2.get(name, {})
+    gui = g2.get("GRBM_GUI_ACTIVE")
+    clock_ghz = (sum(gui) / len(gui) / 8) / (1e6 * sum(g2["_ms"]) / len(g2["_ms"])) if gui else None
     simd_cycles = ns * clock_ghz * 1024 if clock_ghz else None
     util[name[:90]] = {"mfma_busy_cycles_per_launch": sum(busy) / len(busy),
                        "mfma_instructions_per_launch": sum(v["SQ_INSTS_MFMA"]) / len(v["SQ_INSTS_MFMA"]),

@@ -44,6 +44,16 @@ static void run(const float *in, float *out, long bytes, long D, long R)
     const long nitems = D ? (bytes / (2 * D)) * per_unit : bytes / (2 * R);
     const int steps = (int)(R / 4096);
     if ((D && (D % R || R % 4096)) || nitems < 1) { printf("D=%ld R=%ld: skipped (shape)\n", D, R); return; }
+    {   // host-side bounds check of the LAST item's LAST request before anything is launched (floats): item base + last step +
+        // the farthest row of a request group (+ the partner place D further on) + one 32-float row
+        const long Dfl = D / 4, Rfl = R / 4, last = nitems - 1;
+        const long base = D ? (last / per_unit) * 2 * Dfl + (last % per_unit) * Rfl : last * 2 * Rfl;
+        const long reach = D ? base + (long)(steps - 1) * 1024 + Dfl + 31 * 32 + 32 : base + (long)(steps - 1) * 2048 + 63 * 32 + 32;
+        if (reach > bytes / 4) {
+            printf("D=%ld R=%ld: REFUSED, last access would end at float %ld of %ld\n", D, R, reach, bytes / 4);
+            return;
+        }
+    }
     hipEvent_t a, b;
     (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     auto go = [&] { hipLaunchKernelGGL(k_walk, dim3(512), dim3(256), 0, 0, in, out, nitems, D / 4, R / 4, per_unit, steps); };
@@ -67,6 +77,7 @@ int main()
     run(in, out, bytes, 0, 16L << 10);
     run(in, out, bytes, 0, 48L << 10);
     for (long kb : {16L, 32L, 64L, 128L, 256L, 512L, 1024L, 2048L, 4096L, 8192L, 16384L}) run(in, out, bytes, kb << 10, 16L << 10);
+    run(in, out, bytes, 48L << 10, 16L << 10);      // 2 D does not divide the buffer: whole units only, the tail stays untouched
     run(in, out, bytes, 32L << 10, 32L << 10);
     run(in, out, bytes, 4096L << 10, 64L << 10);
     run(in, out, bytes, 0, 16L << 10);
