@@ -428,11 +428,14 @@ def sharded_blocks(ctx):
         out = {}
         for key, fmt, steps in (("resample_1to3_i16_exact_8192ch_sharded", filters.PCM_I16, 2),
                                 ("resample_1to3_i16_fast_8192ch_sharded", filters.PCM_I16_FAST, 3)):
-            r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, fmt, stream=stream)
-            r.set_matrix(tables["rs_1to3"])
+            def handle(fmt=fmt):
+                r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, fmt, stream=stream)
+                r.set_matrix(tables["rs_1to3"])
+                return r
+            r = handle()
             ms = time_local(lambda: r.process(xi, yi), steps)
             r.close()
-            out[key] = (ms, rs_entry(RS_CH, ch, rs_n, 2 + 2 / 3, {"parity": i16_parity(orc, xi, yi, 1, 3, 1 << 16)}))
+            out[key] = (ms, rs_entry(RS_CH, ch, rs_n, 2 + 2 / 3, {"parity": i16_parity(orc, handle, xi, yi, 1, 3, 1 << 16)}))
         return out
 
     # config 4: 1024-ch IIR, 8-biquad cascade, 1 Mi samples/ch; two coefficient sets: 8 copies of the
@@ -473,11 +476,17 @@ def sharded_blocks(ctx):
             ("iir", ["iir8_1024ch_sharded", "iir8_r099_1024ch_sharded"], iir)]
 
 
-def i16_parity(orc, xi, yi, L_, M_, n_out_check, gain=1.0, win=1):
-    """compare spread channels x the first n_out_check outputs of an int16 resampler run with the oracle's llz_resample loop
-    (rank 0 only; None elsewhere).  xi / yi: the device tensors of a FIRST call on a fresh handle (zero history)."""
+def i16_parity(orc, fresh_handle, xi, yi, L_, M_, n_out_check, gain=1.0, win=1):
+    """compare spread channels x the first n_out_check outputs of an int16 resampler with the oracle's llz_resample loop (rank
+    0 only; None elsewhere).  The timed handle has streamed several calls (its history is no longer zero), so ONE more call is
+    made here on a fresh handle (fresh_handle() -> ResampleMC), outside every timed region."""
     if orc is None:
         return None
+    import torch
+    r = fresh_handle()
+    r.process(xi, yi)
+    torch.cuda.synchronize()
+    r.close()
     info = orc.rs_info(2, L_, M_, gain, win)
     nin, nout = info["bytes_in"] // 2, info["bytes_out"] // 2
     frames = max(1, min(n_out_check // nout, xi.shape[1] // nin))
@@ -532,10 +541,12 @@ def extra_paths(ctx):
         xi = torch.empty(ch, n, dtype=torch.int16, device=dev)
         yi = torch.empty(ch, n * L_ // M_, dtype=torch.int16, device=dev)
         filters.synth_i16(xi, SEED, stream=stream)
-        r = filters.ResampleMC(ch, L_, M_, 1.0, filters.BLACKMAN, filters.PCM_I16, stream=stream)
+        def handle(L_=L_, M_=M_, ch=ch):
+            return filters.ResampleMC(ch, L_, M_, 1.0, filters.BLACKMAN, filters.PCM_I16, stream=stream)
+        r = handle()
         ms = time_local(lambda: r.process(xi, yi), 5)
         r.close()
-        par = i16_parity(orc, xi, yi, L_, M_, 1 << 16)
+        par = i16_parity(orc, handle, xi, yi, L_, M_, 1 << 16)
         out[f"resample_{L_}to{M_}_i16_256ch"] = (ms, lambda ms, ch=ch, n=n, bpi=2 + 2 * L_ / M_, par=par, make=make:
                                                   make(ms, ch, n, bpi, {"parity": par}))
         del xi, yi
