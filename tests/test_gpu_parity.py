@@ -350,7 +350,7 @@ def test_resample_mc_f32_vs_oracle(dev, oracle, L, M, win):
     ref = oracle.rs_batch_f32(x, L, M, 1.0, win)
     got = yd.cpu().numpy().astype(np.float64)
     err = float(np.sqrt(np.mean((got - ref) ** 2)))
-    assert err <= TOL and err / float(np.sqrt(np.mean(ref ** 2))) <= 3e-5, err
+    assert err <= TOL and err / float(np.sqrt(np.mean(ref ** 2))) <= TOL, err
 
 
 @pytest.mark.parametrize("L,M", [(2, 3), (3, 2), (3, 4), (4, 3), (2, 1), (3, 1), (4, 1), (5, 3)])
@@ -376,7 +376,7 @@ def test_resample_mc_f32_small_ratios_streaming(dev, oracle, L, M):
     ref = oracle.rs_batch_f32(x, L, M, 1.0, po.BLACKMAN)[:, :got.shape[1]]
     assert got.shape[1] >= sum(lens) * L // M - 1
     err = float(np.sqrt(np.mean((got - ref) ** 2)))
-    assert err <= TOL and err / float(np.sqrt(np.mean(ref ** 2))) <= 3e-5, (L, M, err)
+    assert err <= TOL and err / float(np.sqrt(np.mean(ref ** 2))) <= TOL, (L, M, err)
 
 
 @pytest.mark.parametrize("form", ["phase-tile waves", "period-tile waves"])
@@ -404,7 +404,7 @@ def test_resample_mc_f32_matrix_core_streaming(dev, oracle, L, M, form):
     got = np.concatenate(outs, axis=1).astype(np.float64)
     ref = oracle.rs_batch_f32(x, L, M, 1.0, po.BLACKMAN)[:, :got.shape[1]]
     err = float(np.sqrt(np.mean((got - ref) ** 2)))
-    assert err <= TOL and err / float(np.sqrt(np.mean(ref ** 2))) <= 3e-5, (L, M, form, err)
+    assert err <= TOL and err / float(np.sqrt(np.mean(ref ** 2))) <= TOL, (L, M, form, err)
 
 
 def test_resample_mc_f32_integer_input_matches_int16_reference(dev, oracle):
@@ -1214,12 +1214,12 @@ def test_resample_config5_full_size_f32(dev, oracle):
     ref = oracle.rs_batch_f32(x[sel].cpu().numpy(), 1, M, 1.0, po.BLACKMAN)
     got = y[sel].cpu().numpy().astype(np.float64)
     err = float(np.sqrt(np.mean((got - ref) ** 2)))
-    assert err <= TOL and err / float(np.sqrt(np.mean(ref ** 2))) <= 3e-5, err
+    assert err <= TOL and err / float(np.sqrt(np.mean(ref ** 2))) <= TOL, err
     m_in = 3 * 4096
     ref = oracle.rs_batch_f32(x[:, :m_in].cpu().numpy(), 1, M, 1.0, po.BLACKMAN)
     got = y[:, :m_in // M].cpu().numpy().astype(np.float64)
     err = float(np.sqrt(np.mean((got - ref) ** 2)))
-    assert err <= TOL and err / float(np.sqrt(np.mean(ref ** 2))) <= 3e-5, err
+    assert err <= TOL and err / float(np.sqrt(np.mean(ref ** 2))) <= TOL, err
 
 
 def test_iir_wave_first_version_kernels(dev, oracle):
@@ -1461,6 +1461,72 @@ def test_sharded_tables_through_rccl_on_one_device(dev, oracle):
     ref_h.close(); sh.close()
 
 
+def _per_device(sh, whole):
+    """copies of a [channels, n] tensor's shard rows, each on its shard's GPU"""
+    return [whole[c0:c0 + cnt].to(torch.device("cuda", d)) for (d, c0, cnt) in sh.shards]
+
+
+def test_sharded_over_distinct_devices(dev, oracle):
+    """the library's own multi-GPU path where a node offers it: llz_*_mc_sharded_init over DISTINCT devices (one shard per
+    visible GPU: ncclCommInitAll + one grouped ncclBroadcast per table), every shard's buffers on its own GPU, against one
+    unsharded handle on GPU 0 -- bit for bit, FIR / resample / IIR.  Also: a buffer that lives on the wrong GPU is refused
+    with LLZ_ERR_ARG (no peer access is ever enabled).  Skipped on a one-GPU box."""
+    ndev = capi.lib().llz_hip_device_count()
+    if ndev < 2:
+        pytest.skip("one GPU visible: the distinct-device path needs two")
+    devices = list(range(ndev))
+    L = capi.lib()
+    channels, n = 8 * ndev + 3, 1536 * 6
+    taps = oracle.fir_design(po.LPF, 257, 0.1, 0.0, po.KAISER)
+    x = torch.empty(channels, n, dtype=torch.float32, device=dev)
+    filters.synth_f32(x, seed=31)
+    torch.cuda.synchronize()
+    # FIR
+    ref_h = filters.FirFilterMC(channels, n, taps)
+    y_ref = torch.empty_like(x)
+    ref_h.filter(x, y_ref)
+    sh = filters.FirFilterMCSharded(channels, n, taps, devices)
+    assert sh.rccl_ranks == ndev and [d for (d, _c0, _c) in sh.shards] == devices
+    xs, ys = _per_device(sh, x), sh.alloc(n, torch.float32)
+    sh.filter(xs, ys)
+    sh.synchronize()
+    assert L.llz_hip_get_device() == 0                                   # the caller's device is restored
+    assert torch.equal(torch.cat([y.to(dev) for y in ys]), y_ref)
+    with pytest.raises(capi.LlzError, match="lives on GPU"):
+        sh.filter([xs[0]] * ndev, ys)                                    # shard 1 handed a buffer of GPU 0
+    with pytest.raises(capi.LlzError):
+        sh.split(x)                                                      # one tensor cannot serve shards on several GPUs
+    ref_h.close(); sh.close()
+    # resample 1:3, float32 and the reference's int16
+    n_in = 3 * 4096
+    for fmt, dt, synth in ((filters.PCM_F32, torch.float32, filters.synth_f32), (filters.PCM_I16, torch.int16, filters.synth_i16)):
+        xr = torch.empty(channels, n_in, dtype=dt, device=dev)
+        synth(xr, seed=32)
+        torch.cuda.synchronize()
+        ref_r = filters.ResampleMC(channels, 1, 3, 1.0, po.BLACKMAN, fmt)
+        yr_ref = torch.empty(channels, n_in // 3, dtype=dt, device=dev)
+        ref_r.process(xr, yr_ref)
+        shr = filters.ResampleMCSharded(channels, 1, 3, 1.0, po.BLACKMAN, fmt, devices)
+        xs, ys = _per_device(shr, xr), shr.alloc(n_in // 3, dt)
+        assert shr.process(xs, ys) == n_in // 3
+        shr.synchronize()
+        assert torch.equal(torch.cat([y.to(dev) for y in ys]), yr_ref), fmt
+        ref_r.close(); shr.close()
+    # IIR (both runs pinned to one kernel form: the form is shape dependent)
+    coef = np.tile(np.array([0.2066, 0.4131, 0.2066, 1.0, -0.3695, 0.1958]), (8, 1))
+    with capi.tuned(iir_segs=1, iir_pipe=1):
+        ref_q = filters.IirCascadeMC(channels, coef)
+        yq_ref = torch.empty_like(x)
+        ref_q.filter(x, yq_ref)
+        shq = filters.IirCascadeMCSharded(channels, coef, devices)
+        xs, ys = _per_device(shq, x), shq.alloc(n, torch.float32)
+        shq.filter(xs, ys)
+        shq.synchronize()
+        assert torch.equal(torch.cat([y.to(dev) for y in ys]), yq_ref)
+        ref_q.close(); shq.close()
+    torch.cuda.synchronize()
+
+
 def test_sharded_refusals(dev, oracle):
     taps = oracle.fir_design(po.LPF, 33, 0.2, 0.0, po.HAMMING)
     for devices in ([], [0, 99], [0] * 65, [-1]):
@@ -1471,7 +1537,9 @@ def test_sharded_refusals(dev, oracle):
 
 
 def test_handle_binds_its_device(dev, oracle):
-    """a handle records the device it was created on and binds it in every call (the caller's current device is restored)"""
+    """a handle records the device it was created on and binds it in every call (the caller's current device is restored).
+    On a one-GPU box this only shows that binding does not disturb anything; test_sharded_over_distinct_devices is the real
+    check where two GPUs are visible."""
     L = capi.lib()
     taps = oracle.fir_design(po.LPF, 33, 0.2, 0.0, po.HAMMING)
     f = filters.FirFilterMC(3, 512, taps)
