@@ -296,8 +296,8 @@ static void rsm_destroy(rsm_t *r)
  *                        + the rounding of fl(gain g[k])   <= 32768 u |gain| sum_k |g[k]|
  *   reference's sum      |fl(sum x g) - sum x g|          <= Q u / (1 - Q u) sum |x g| <= Q 2^-52 32768 sum_k |g[k]|
  *   reference's * gain   one more rounding of a value <= 32768 |gain| sum|g|
- * eps = 2 (the sum of those) + 2^-30: the factor 2 and the constant are margin (they also cover this function's own
- * floating-point sums).  Returns 0 when the taps do not suit the screen (the all-double kernel then runs). */
+ * eps = 2 (the sum of those) + 2^-30 + (the integer terms the kernel does not form, see below): the factor 2 and the constant
+ * are margin (they also cover this function's own floating-point sums).  Returns 0 when the taps do not suit the screen (the all-double kernel then runs). */
 static int rsm_build_screen(rsm_t *r)
 {
     const int Q = r->Q;
@@ -320,7 +320,7 @@ static int rsm_build_screen(rsm_t *r)
     if (shift < 32) return 0;                           /* (gains above ~64: the integer decision needs shift >= 32) */
     signed char *digits = (signed char *)malloc((size_t)LLZS_MX_PLANES * Q);
     if (!digits) return 0;
-    long long sumG = 0;
+    long long sumG = 0, sum_d0 = 0;
     double qerr = 0.0;
     int ok = 1;
     for (int k = 0; k < Q; k++) {
@@ -331,11 +331,16 @@ static int rsm_build_screen(rsm_t *r)
         for (int p = 0; p < LLZS_MX_PLANES; p++) {
             const int d = (int)(((G + 128) & 255) - 128);            /* balanced digit in [-128, 127] */
             digits[(size_t)p * Q + k] = (signed char)d;
+            if (p == 0) sum_d0 += d < 0 ? -d : d;
             G = (G - d) / 256;
         }
         if (G != 0) ok = 0;
     }
-    const double eps = 2.0 * 32768.0 * (qerr + (double)(Q + 2) * ldexp(1.0, -52) * sumabs) + ldexp(1.0, -30);
+    /* the kernel leaves out two integer terms of S = sum x G: the product of the samples' low digit (|.| <= 128) with the
+     * taps' lowest digit, |.| <= 128 sum|d_0|, and the low 8 bits of the bias 128 sum G, < 256 -- both exact bounds, in
+     * units of 2^-shift */
+    const double eps = 2.0 * 32768.0 * (qerr + (double)(Q + 2) * ldexp(1.0, -52) * sumabs) + ldexp(1.0, -30) +
+                       ldexp(128.0 * (double)sum_d0 + 256.0, -shift);
     if (ok && eps < 0.0625) {
         if (!r->d_digits) r->d_digits = (signed char *)llzs_malloc((size_t)LLZS_MX_PLANES * Q);
         ok = r->d_digits && llzs_h2d_table(r->d_digits, digits, (size_t)LLZS_MX_PLANES * Q) == LLZ_OK;

@@ -12,14 +12,16 @@
 //   1. SCREEN (matrix cores, exact integer arithmetic).  Taps are quantised once on the host to G[k] = round(g[k] 2^s),
 //      |G| < 2^39, and written as five balanced base-256 digits G = sum_p d_p 256^p, d_p in [-128, 127]; a sample is
 //      x = 256 xh + xl' + 128 with xh = x >> 8 and xl' = (x & 255) - 128, both int8.  v_mfma_i32_16x16x64_i8 accumulates
-//      the ten digit-plane products in int32 -- exactly: |sum| <= 2 Q 2^14 -- into six accumulators by weight w = p + a, and
-//            S = sum_w 256^w acc_w + 128 sum_k G[k]        (int64, exact)       = sum_k x[iM - k] G[k]
+//      the digit-plane products in int32 -- exactly: |sum| <= 2 Q 2^14 -- into five accumulators by weight w = 1 .. 5 (nine
+//      products; the tenth, low sample digit x lowest tap digit at weight 0, is at most 128 sum|d_0| and is left inside eps):
+//            S = sum_w 256^w acc_w + 128 sum_k G[k]        (exact integers)     = sum_k x[iM - k] G[k] - (weight-0 product)
 //      (the gain is folded into G: G[k] = round(gain g[k] 2^s)), so v = S 2^-s differs from the reference's y only by the
 //      tap quantisation and the reference's own rounding:
 //            |v - y| <= eps := 2 (32768 sum_k |gain g[k] - G[k] 2^-s|  +  |gain| (Q + 2) 2^-52 32768 sum_k |g[k]|) + 2^-30
 //      (the host evaluates this for the handle's taps: ~4e-6 at Q = 134; DESIGN.md has the derivation).
-//   2. DECIDE, in integers.  With E = ceil(eps 2^s): if the fractional field of S + E (s bits) exceeds 2 E, no integer
-//      lies within eps of v, so v and y truncate (and clamp) to the same int16: S >> s, plus one if negative.
+//   2. DECIDE, in 32-bit integer arithmetic with explicit carries (mx_decide: ~18 vector instructions per output, no
+//      branch): the integer part I and the top 32 bits F of the fraction of v; if F is farther than eps from both ends no
+//      integer lies within eps of v, so v and y truncate (and clamp) to the same int16: I, plus one if negative.
 //   3. RECOMPUTE the others -- about 2 eps of all outputs, ~1e-5 -- in the reference's exact order, in double, by the lane
 //      that found them, from the tile's samples in LDS (rounded multiply, rounded add, ascending k: the loop above).
 //      All-zero tiles (digital silence: every output would sit ON the integer 0) are written as zeros without arithmetic.
@@ -46,6 +48,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int MX_WAVES = 4;
 constexpr int MX_THREADS = MX_WAVES * 64;
 constexpr int MX_PLANES = 5;                // tap digit planes
+constexpr int MX_ACCS = 5;                  // accumulators by weight: 256^1 .. 256^5 (the weight-0 product is not formed)
 constexpr int MX_NV_MAX = 8;                // prefetch registers: 8 x 16 B (8 samples each) per thread
 
 struct mx_shape {
@@ -57,11 +60,13 @@ struct mx_shape {
     int tiles_per_ch;
 };
 
+// The screen's value of an output is v = S 2^-shift with S = sum_k x[k] G[k].  The kernel forms
+//     T' = sum_{w=1..5} 256^(w-1) acc_w + floor(bias / 256)          (S = 256 T' + (bias mod 256) + the weight-0 product;
+// both leftovers are bounded by the host and sit inside eps), so v = T' 2^-(shift-8) up to eps.
 struct mx_params {
-    long long bias;          // 128 * sum_k G[k]: the samples' +128 offset
-    unsigned long long E;    // ceil(eps 2^shift): the screen's uncertainty in units of 2^-shift
-    unsigned thr;            // (2 E >> (shift - 32)) + 1
-    int shift;               // 32 .. 46: S 2^-shift is the screen's value of the output (the taps carry the gain)
+    int bq_lo, bq_hi;        // floor(bias / 256) as a 64-bit two's complement pair; bias = 128 sum_k G[k]
+    unsigned e32;            // ceil(eps 2^32) + 2: the screen's uncertainty in units of 2^-32 of an output step
+    int rs;                  // shift - 40 in [-8, 6]: T' 2^-(32 + rs) is the output value
     double gain;             // only the recompute path multiplies by it, as the reference does
 };
 
@@ -82,11 +87,51 @@ __device__ __noinline__ short mx_exact(const signed char *hi, const signed char 
     return (short)y;                                // :601, toward zero
 }
 
-template <int NACC, int NV>
+// One output from its five accumulators, in exact 32-bit integer arithmetic (|acc| <= 2 T 2^14 < 2^22.7 for T <= 200):
+//   T' = a0 + 2^8 a1 + 2^16 a2 + 2^24 a3 + 2^32 a4 + Bq  as a 64-bit pair (hi, lo) with explicit carries;
+//   I = floor(T' / 2^(32 + rs)), F = the top 32 bits of the fraction below it.
+// Returns the reference's int16 when no integer lies within eps of the value (fraction outside [-e32, e32] of a step), and
+// sets `unsure` otherwise.  NEG selects rs < 0 (the handle's shift below 40).
+template <bool NEG>
+__device__ __forceinline__ int mx_decide(int a0, int a1, int a2, int a3, int a4, const mx_params &pr, int &I_out, bool &unsure)
+{
+    const int p = a0 + (a1 << 8);
+    const int q = a2 + (a3 << 8);
+    const unsigned u = (unsigned)q << 16;                       // q 2^16 = (q >> 16) 2^32 + u
+    const int h0 = a4 + (q >> 16) + pr.bq_hi;
+    const unsigned lo0 = u + (unsigned)pr.bq_lo;
+    const int h1 = h0 + (int)(lo0 < u);                         // carry of the first add
+    const unsigned lo = lo0 + (unsigned)p;
+    const int hi = h1 + (p >> 31) + (int)(lo < lo0);            // sign extension of p and the second carry
+    int I;
+    unsigned F;
+    if (NEG) {
+        I = (int)__builtin_amdgcn_alignbit((unsigned)hi, lo, (unsigned)(32 + pr.rs));
+        F = lo << (-pr.rs);
+    } else {
+        I = hi >> pr.rs;
+        F = __builtin_amdgcn_alignbit((unsigned)hi, lo, (unsigned)pr.rs);
+    }
+    unsure = F + pr.e32 <= 2u * pr.e32;                         // wrapping: the fraction is within e32 of 0 or of 1
+    I_out = I;
+    int t = I + (int)((unsigned)I >> 31);                       // toward zero: the value is not an integer here
+    t = t > 32767 ? 32767 : t;
+    t = t < -32768 ? -32768 : t;
+    return t;
+}
+
+// lane n of a 16-lane row takes segment mx_seg(n) of the wave's 16, and quarter kq of the lanes takes the 16-byte chunk
+// mx_chunk(kq) of a 64-sample step: with an odd decimation M the sixteen lanes a ds_read_b128 serves together
+// ({0-3, 12-15} of one quarter with {4-11} of its neighbour) then read sixteen different 16-byte bank groups
+// (chunk index M seg + chunk: odd segments against even segments + 2) -- the natural order collides two by two
+__device__ __forceinline__ int mx_seg(int n) { return n < 4 ? 2 * n + 1 : (n < 12 ? 2 * (n - 4) : 2 * (n - 12) + 9); }
+__host__ __device__ __forceinline__ int mx_chunk(int kq) { return ((kq & 1) << 1) | (kq >> 1); }
+
+template <int NACC, int NV, bool NEG>
 __global__ void __launch_bounds__(MX_THREADS)
 k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const short *__restrict__ hist,
                const signed char *__restrict__ digits /* [MX_PLANES][T] */, const double *__restrict__ gd, long n_in,
-               long n_out, long in_pitch, long out_pitch, mx_shape sh, mx_params pr, long ntiles)
+               long n_out, long in_pitch, long out_pitch, mx_shape sh, mx_params pr, int channels)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int TILE_OUT = MX_WAVES * NACC * 256;
@@ -96,6 +141,7 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
     signed char *xs_hi = xs_lo + sh.plane;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, kq = lane >> 4;
+    const int seg = mx_seg(n);
     const int total = sh.total, last8 = sh.total - 8;
     const bool aligned_in = (in_pitch & 7) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
     const bool aligned_out = (out_pitch & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0;
@@ -103,22 +149,25 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
     for (int e = tid; e < MX_PLANES * aplane; e += MX_THREADS) {
         const int p = e / aplane, r = e - p * aplane;
         const int s = r >> 10, l = (r >> 4) & 63, j = r & 15;
-        const int t = 64 * s + 16 * (l >> 4) + j;
+        const int t = 64 * s + 16 * mx_chunk(l >> 4) + j;
         const int k = (l & 15) * sh.M + sh.tpad - t;
         atab[e] = (k >= 0 && k < sh.T) ? digits[p * sh.T + k] : (signed char)0;
     }
 
-    auto tile_first = [&](long q, int &c, long &o0) {
-        c = (int)(q / sh.tiles_per_ch);
-        o0 = (q - (long)c * sh.tiles_per_ch) * TILE_OUT;
-        return o0 * sh.M - sh.tpad;
+    // the walk: tile (c, t) = channel c, tile t of the channel; a workgroup advances by gridDim.x tiles, channel by channel
+    // (no division in the loop: gridDim.x = cdiv tiles_per_ch + crem is split once)
+    const int cdiv = (int)(gridDim.x / (unsigned)sh.tiles_per_ch), crem = (int)(gridDim.x % (unsigned)sh.tiles_per_ch);
+    auto advance = [&](int &c, int &t) {
+        c += cdiv;
+        t += crem;
+        if (t >= sh.tiles_per_ch) { t -= sh.tiles_per_ch; c++; }
     };
+    auto first_of = [&](int t) { return (long)t * (TILE_OUT * sh.M) - sh.tpad; };
     auto is_interior = [&](long first) { return aligned_in && first >= 0 && first + total <= n_in; };
 
-    auto prefetch = [&](i16x8 (&v)[NV], long q) {
-        int c; long o0;
-        const long first = tile_first(q, c, o0);
-        if (!is_interior(first)) return false;
+    auto prefetch = [&](i16x8 (&v)[NV], int c, int t) {
+        const long first = first_of(t);
+        if (c >= channels || !is_interior(first)) return false;
         const short *src = in + (size_t)c * in_pitch + first;
 #pragma unroll
         for (int j = 0; j < NV; j++) {
@@ -131,9 +180,9 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         return true;
     };
 
-    auto tile = [&](long q, i16x8 (&v)[NV], bool &have) {
-        int c; long o0;
-        const long first = tile_first(q, c, o0);
+    auto tile = [&](int c, int t, int cn, int tn, i16x8 (&v)[NV], bool &have) {
+        const long o0 = (long)t * TILE_OUT;
+        const long first = first_of(t);
         __syncthreads();
         int nonzero = 0;
         if (have) {
@@ -173,19 +222,38 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
             }
         }
         const int any = __syncthreads_or(nonzero);
-        have = q + gridDim.x < ntiles && prefetch(v, q + gridDim.x);
+        have = prefetch(v, cn, tn);
 
         short *orow = out + (size_t)c * out_pitch;
         const bool whole = aligned_out && o0 + TILE_OUT <= n_out;
-        i32x4 acc[NACC][MX_PLANES + 1];
-        if (any) {
+        auto store4 = [&](int a, const int (&r4)[4]) {
+            const long o = o0 + ((wave * NACC + a) * 16 + seg) * 16 + 4 * kq;   // first of this lane's 4 outputs of block a
+            i16x4 y;
+#pragma unroll
+            for (int j = 0; j < 4; j++) y[j] = (short)r4[j];
+            if (whole) {
+                *reinterpret_cast<i16x4 *>(orow + o) = y;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (o + j < n_out) orow[o + j] = y[j];
+            }
+        };
+        if (!any) {                                     // digital silence: every output sits ON the integer 0
+            const int zero[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int a = 0; a < NACC; a++) store4(a, zero);
+            return;
+        }
+        i32x4 acc[NACC][MX_ACCS];
+        {
             const signed char *bp[NACC];
 #pragma unroll
-            for (int a = 0; a < NACC; a++) bp[a] = xs_lo + ((wave * NACC + a) * 16 + n) * 16 * sh.M + 16 * kq;
+            for (int a = 0; a < NACC; a++) bp[a] = xs_lo + ((wave * NACC + a) * 16 + seg) * 16 * sh.M + 16 * mx_chunk(kq);
             const signed char *ap = atab + lane * 16;
-            // one step = 64 window samples: 5 tap planes x 2 sample planes.  The first step starts every accumulator from
-            // the constant 0 (no zeroing pass); the other resident waves cover the LDS latency of a step's operands
-            auto step = [&](int s, auto first) {
+            // one step = 64 window samples: tap planes 0..4 against the high sample plane (weights 1..5), planes 1..4 against
+            // the low one (weights 1..4).  The first step starts every accumulator from the constant 0 (no zeroing pass).
+            auto step = [&](int s, auto first_step) {
                 i32x4 ad[MX_PLANES], bd[NACC][2];
 #pragma unroll
                 for (int p = 0; p < MX_PLANES; p++) ad[p] = *reinterpret_cast<const i32x4 *>(ap + p * aplane + s * 1024);
@@ -197,63 +265,63 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
 #pragma unroll
                 for (int p = 0; p < MX_PLANES; p++)
 #pragma unroll
-                    for (int d = 0; d < 2; d++)
+                    for (int d = 1; d >= 0; d--)
 #pragma unroll
                         for (int a = 0; a < NACC; a++) {
-                            // weight p + d is first written by (p = 0, d = 0), (p, d = 1) for p < 5 ... in this loop order:
-                            // (p, d) is the first visitor of p + d exactly when d == 1 or p == 0
-                            const bool fresh = decltype(first)::value && (d == 1 || p == 0);
-                            const i32x4 c = fresh ? (i32x4){0, 0, 0, 0} : acc[a][p + d];
-                            acc[a][p + d] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ad[p], bd[a][d], c, 0, 0, 0);
+                            if (d == 0 && p == 0) continue;          // low sample digit x lowest tap digit: not formed (inside eps)
+                            // accumulator p + d - 1; in this order (p, d = 1) is always its first visitor
+                            const bool fresh = decltype(first_step)::value && d == 1;
+                            const i32x4 c0 = fresh ? (i32x4){0, 0, 0, 0} : acc[a][p + d - 1];
+                            acc[a][p + d - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ad[p], bd[a][d], c0, 0, 0, 0);
                         }
             };
             step(0, std::true_type{});
             for (int s = 1; s < sh.ksteps; s++) step(s, std::false_type{});
         }
 
+        // every output decided without a branch; the lanes that could not decide are collected per output slot and handled
+        // together afterwards (about 2 eps of all outputs: most tiles have none)
+        int res[NACC][4];
+        unsigned long long unsure_mask[NACC][4];
+        unsigned long long unsure_any = 0;
 #pragma unroll
-        for (int a = 0; a < NACC; a++) {
-            const int oo = ((wave * NACC + a) * 16 + n) * 16 + 4 * kq;        // first of this lane's 4 outputs in the tile
-            const long o = o0 + oo;
-            i16x4 y;
+        for (int a = 0; a < NACC; a++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                short r = 0;
-                if (any) {
-                    // S = sum_w 256^w acc_w + bias, exact: the plane sums pair up in 32 bits (|acc_w| <= 2 T 2^14, T <= 200)
-                    const int p01 = acc[a][0][j] + acc[a][1][j] * 256;
-                    const int p23 = acc[a][2][j] + acc[a][3][j] * 256;
-                    const int p45 = acc[a][4][j] + acc[a][5][j] * 256;
-                    long long S = (long long)p23 * 65536 + ((long long)p01 + pr.bias);
-                    S += (long long)((unsigned long long)(unsigned)p45 << 32);
-                    const int I = (int)(S >> pr.shift);                                   // floor(v)
-                    const unsigned frac = (unsigned)(((unsigned long long)S + pr.E) >> (pr.shift - 32));
-                    if (frac <= pr.thr && (unsigned)(I + 32770) <= 65540u) {
-                        // an integer within eps of v (and v inside the clamp range): the reference's own arithmetic decides
-                        r = (o + j < n_out) ? mx_exact(xs_hi, xs_lo, (oo + j) * sh.M + sh.tpad, gd, sh.T, pr.gain) : (short)0;
-                    } else {
-                        int t = I + (int)((unsigned long long)S >> 63);                   // toward zero: v is not an integer here
-                        t = t > 32767 ? 32767 : t;
-                        t = t < -32768 ? -32768 : t;
-                        r = (short)t;
-                    }
-                }
-                y[j] = r;
+                int I;
+                bool unsure;
+                res[a][j] = mx_decide<NEG>(acc[a][0][j], acc[a][1][j], acc[a][2][j], acc[a][3][j], acc[a][4][j], pr, I, unsure);
+                unsure_mask[a][j] = __ballot(unsure);
+                unsure_any |= unsure_mask[a][j];
             }
-            if (whole) {
-                *reinterpret_cast<i16x4 *>(orow + o) = y;
-            } else {
+        if (unsure_any) {
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (o + j < n_out) orow[o + j] = y[j];
+            for (int a = 0; a < NACC; a++) {
+                const int oo = ((wave * NACC + a) * 16 + seg) * 16 + 4 * kq;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (unsure_mask[a][j] == 0) continue;
+                    // an integer within eps of the value: the reference's own arithmetic decides, in the lane that found it
+                    // (a value far outside the clamp range needs none: its int16 is the rail either way)
+                    if (((unsure_mask[a][j] >> lane) & 1) && (unsigned)(res[a][j] + 32767) <= 65533u && o0 + oo + j < n_out)
+                        res[a][j] = mx_exact(xs_hi, xs_lo, (oo + j) * sh.M + sh.tpad, gd, sh.T, pr.gain);
+                }
             }
         }
+#pragma unroll
+        for (int a = 0; a < NACC; a++) store4(a, res[a]);
     };
 
-    long q = blockIdx.x;
+    int c = (int)(blockIdx.x / (unsigned)sh.tiles_per_ch), t = (int)(blockIdx.x % (unsigned)sh.tiles_per_ch);
     i16x8 v[NV];
-    bool have = q < ntiles && prefetch(v, q);
-    for (; q < ntiles; q += gridDim.x) tile(q, v, have);
+    bool have = prefetch(v, c, t);
+    while (c < channels) {
+        int cn = c, tn = t;
+        advance(cn, tn);
+        tile(c, t, cn, tn, v, have);
+        c = cn;
+        t = tn;
+    }
 }
 
 bool mx_make_shape(int T, int M, int nacc, long n_out, mx_shape *sh, size_t *lds_bytes)
@@ -281,7 +349,7 @@ int mx_pick_nacc(int T, int M)
     return 0;
 }
 
-template <int NACC, int NV>
+template <int NACC, int NV, bool NEG>
 int mx_launch(const short *in, short *out, const short *hist, const signed char *digits, const double *gd, int channels,
               long n_in, long n_out, long in_pitch, long out_pitch, int T, int M, const mx_params &pr, void *stream)
 {
@@ -289,7 +357,7 @@ int mx_launch(const short *in, short *out, const short *hist, const signed char 
     size_t lds_bytes;
     mx_make_shape(T, M, NACC, n_out, &sh, &lds_bytes);
     if (lds_bytes > 64 * 1024)
-        LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma_i8x<NACC, NV>),
+        LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma_i8x<NACC, NV, NEG>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     const long ntiles = (long)sh.tiles_per_ch * channels;
     int cus = 256, dev = 0;
@@ -301,7 +369,7 @@ int mx_launch(const short *in, short *out, const short *hist, const signed char 
     // a persistent grid: exactly the workgroups the chip holds at once (a workgroup that has to wait for a slot would
     // run its share of the tiles after everyone else: 768 workgroups on 512 slots measured 48 ms instead of 36)
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_fir_mfma_i8x<NACC, NV>),
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_fir_mfma_i8x<NACC, NV, NEG>),
                                                      MX_THREADS, lds_bytes) != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 2;
@@ -309,8 +377,8 @@ int mx_launch(const short *in, short *out, const short *hist, const signed char 
     if (const int v = llzs_tune(LLZS_TUNE_MFMA_WG_PER_CU); v >= 1 && v <= 8) per_cu = v;
     long grid = (long)cus * per_cu;
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL((k_fir_mfma_i8x<NACC, NV>), dim3((unsigned)grid), dim3(MX_THREADS), lds_bytes, as_stream(stream), in,
-                       out, hist, digits, gd, n_in, n_out, in_pitch, out_pitch, sh, pr, ntiles);
+    hipLaunchKernelGGL((k_fir_mfma_i8x<NACC, NV, NEG>), dim3((unsigned)grid), dim3(MX_THREADS), lds_bytes, as_stream(stream),
+                       in, out, hist, digits, gd, n_in, n_out, in_pitch, out_pitch, sh, pr, channels);
     LLZ_LAUNCH_CHECK("k_fir_mfma_i8x");
     return LLZ_OK;
 }
@@ -327,7 +395,7 @@ extern "C" int llzs_fir_mfma_i16x(const short *in, short *out, const short *hist
                                   int T, int M, int shift, long long bias, double gain, double eps, void *stream)
 {
     if (!in || !out || !digits || !gd || channels <= 0 || n_in <= 0 || n_out <= 0 || T < 1 || M < 1 || in_pitch < n_in ||
-        out_pitch < n_out || (n_out - 1) * M >= n_in || shift < 32 || shift > 46 || !(eps > 0.0) || !(eps < 0.125)) {
+        out_pitch < n_out || (n_out - 1) * M >= n_in || shift < 32 || shift > 46 || !(eps > 0.0) || !(eps < 0.0625)) {
         llzs_set_error("fir_mfma_i16x: bad arguments (channels=%d n_in=%ld n_out=%ld T=%d M=%d shift=%d eps=%g)", channels,
                        n_in, n_out, T, M, shift, eps);
         return LLZ_ERR_ARG;
@@ -338,16 +406,22 @@ extern "C" int llzs_fir_mfma_i16x(const short *in, short *out, const short *hist
         return LLZ_ERR_RANGE;
     }
     mx_params pr;
-    pr.bias = bias;
-    pr.shift = shift;
-    pr.E = (unsigned long long)ceil(ldexp(eps, shift)) + 1;
-    pr.thr = (unsigned)((2 * pr.E) >> (shift - 32)) + 1;
+    const long long bq = bias >= 0 ? bias / 256 : -((-bias + 255) / 256);        // floor(bias / 256)
+    pr.bq_lo = (int)(unsigned)((unsigned long long)bq & 0xffffffffull);
+    pr.bq_hi = (int)(bq >> 32);
+    pr.rs = shift - 40;
+    pr.e32 = (unsigned)ceil(ldexp(eps, 32)) + 2u;
     pr.gain = gain;
     mx_shape sh;
     size_t bytes;
     mx_make_shape(T, M, nb, n_out, &sh, &bytes);
     const bool small = sh.total <= 4 * MX_THREADS * 8;
-#define MX_GO(A, V) return mx_launch<A, V>(in, out, hist, digits, gd, channels, n_in, n_out, in_pitch, out_pitch, T, M, pr, stream)
+#define MX_GO(A, V)                                                                                                            \
+    do {                                                                                                                       \
+        if (pr.rs < 0)                                                                                                         \
+            return mx_launch<A, V, true>(in, out, hist, digits, gd, channels, n_in, n_out, in_pitch, out_pitch, T, M, pr, stream); \
+        return mx_launch<A, V, false>(in, out, hist, digits, gd, channels, n_in, n_out, in_pitch, out_pitch, T, M, pr, stream);    \
+    } while (0)
     if (nb == 2) { if (small) MX_GO(2, 4); else MX_GO(2, 8); }
     if (small) MX_GO(1, 4); else MX_GO(1, 8);
 #undef MX_GO
