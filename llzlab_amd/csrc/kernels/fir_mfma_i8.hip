@@ -70,12 +70,15 @@ struct mx_params {
     double gain;             // only the recompute path multiplies by it, as the reference does
 };
 
-// the reference's loop for one output, from the tile's LDS image: sample p of the window is 256 hi[p] + lo[p] + 128
-__device__ __noinline__ short mx_exact(const signed char *hi, const signed char *lo, int p0, const double *__restrict__ gd,
-                                        int T, double gain)
+// the reference's loop for one output, from the tile's LDS image: sample p of the window is 256 hi[p] + lo[p] + 128; gd = the
+// double taps, in LDS too (no vector-memory operation and no call in here: the compiler's wait counts for the sample
+// prefetch and the output stores survive this rarely taken path)
+__device__ __forceinline__ short mx_exact(const signed char *hi, const signed char *lo, int p0, const double *gd, int T,
+                                          double gain)
 {
 #pragma clang fp contract(off)
     double y = 0.0;
+#pragma unroll 1
     for (int k = 0; k < T; k++) {
         const int xv = 256 * (int)hi[p0 - k] + (int)lo[p0 - k] + 128;
         const double prod = (double)xv * gd[k];
@@ -120,6 +123,34 @@ __device__ __forceinline__ int mx_decide(int a0, int a1, int a2, int a3, int a4,
     return t;
 }
 
+// The sample prefetch is issued and awaited by hand.  Left to the compiler, every use of a prefetched register was preceded
+// by s_waitcnt vmcnt(0): that also waits for the previous tile's output STORES (and would wait for the other register set's
+// loads), once per tile.  Vector-memory operations complete in issue order per wave, so a set requested `younger` operations
+// ago is complete once at most `younger` operations are outstanding; the kernel counts the operations it issues (a lower
+// bound is safe: it only makes the wait stricter) and waits for exactly the set it is about to use.
+__device__ __forceinline__ i16x8 mx_load_nt(const short *p)
+{
+    i16x8 r;
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void mx_wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+// ONE point behind the waits through which the prefetched registers pass (no instruction): every use of them depends on it,
+// so none can be placed in front of a wait -- and being a single definition it needs no copies (a wait that took the
+// registers as operands itself did: three alternative waits merged into new registers, copied BEFORE each wait)
+template <int NV>
+__device__ __forceinline__ void mx_pin(i16x8 (&v)[NV])
+{
+    if constexpr (NV == 4)
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
+    else
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
+}
+
 // lane n of a 16-lane row takes segment mx_seg(n) of the wave's 16, and quarter kq of the lanes takes the 16-byte chunk
 // mx_chunk(kq) of a 64-sample step: with an odd decimation M the sixteen lanes a ds_read_b128 serves together
 // ({0-3, 12-15} of one quarter with {4-11} of its neighbour) then read sixteen different 16-byte bank groups
@@ -139,6 +170,7 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
     signed char *atab = reinterpret_cast<signed char *>(lds);
     signed char *xs_lo = atab + MX_PLANES * aplane;      // sample planes: low digit (x & 255) - 128, then x >> 8
     signed char *xs_hi = xs_lo + sh.plane;
+    double *gd_lds = reinterpret_cast<double *>(xs_hi + sh.plane);      // the T double taps (recompute path)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, kq = lane >> 4;
     const int seg = mx_seg(n);
@@ -153,6 +185,7 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         const int k = (l & 15) * sh.M + sh.tpad - t;
         atab[e] = (k >= 0 && k < sh.T) ? digits[p * sh.T + k] : (signed char)0;
     }
+    for (int k = tid; k < sh.T; k += MX_THREADS) gd_lds[k] = gd[k];
 
     // the walk: tile (c, t) = channel c, tile t of the channel; a workgroup advances by gridDim.x tiles, channel by channel
     // (no division in the loop: gridDim.x = cdiv tiles_per_ch + crem is split once)
@@ -165,6 +198,8 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
     auto first_of = [&](int t) { return (long)t * (TILE_OUT * sh.M) - sh.tpad; };
     auto is_interior = [&](long first) { return aligned_in && first >= 0 && first + total <= n_in; };
 
+    // a tile's samples, 8 per register, requested two tiles ahead of their use (interior tiles: all but the first and the last
+    // of a channel; those two are read sample by sample when their turn comes)
     auto prefetch = [&](i16x8 (&v)[NV], int c, int t) {
         const long first = first_of(t);
         if (c >= channels || !is_interior(first)) return false;
@@ -174,22 +209,31 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
             if (j * MX_THREADS * 8 < total) {
                 int p = (j * MX_THREADS + tid) * 8;
                 p = p < last8 ? p : last8;
-                v[j] = __builtin_nontemporal_load(reinterpret_cast<const i16x8 *>(src + p));
+                v[j] = mx_load_nt(src + p);
             }
         }
         return true;
     };
+    const int nvu = (total + MX_THREADS * 8 - 1) / (MX_THREADS * 8);     // loads per thread and request (<= NV)
 
-    auto tile = [&](int c, int t, int cn, int tn, i16x8 (&v)[NV], bool &have) {
+    // young = vector-memory operations this wave has issued since the set `v` was requested (a lower bound); young_other =
+    // the same for the other register set
+    auto tile = [&](int c, int t, int cn, int tn, i16x8 (&v)[NV], bool &have, int &young, int &young_other) {
         const long o0 = (long)t * TILE_OUT;
         const long first = first_of(t);
         __syncthreads();
         int nonzero = 0;
         if (have) {
+            // steady state: the previous tile's stores, the other set's request and the stores before it are younger
+            if (young >= 2 * NACC + 4) mx_wait_vm<2 * NACC + 4>();
+            else if (young >= 2 * NACC + 3) mx_wait_vm<2 * NACC + 3>();
+            else mx_wait_vm<0>();
+            mx_pin(v);
 #pragma unroll
             for (int j = 0; j < NV; j++) {
                 if (j * MX_THREADS * 8 < total) {
-                    const int p = (j * MX_THREADS + tid) * 8;
+                    int p = (j * MX_THREADS + tid) * 8;
+                    p = p < last8 ? p : last8;              // (the threads past the end rewrite the last group: same bytes)
                     // 8 samples = 4 dwords; v_perm_b32 gathers the low / high bytes of four samples at a time, and
                     // (x & 255) - 128 as a signed byte is the low byte with its top bit flipped
                     const u32x4 d = __builtin_bit_cast(u32x4, v[j]);
@@ -199,10 +243,8 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
                     lo[1] = __builtin_amdgcn_perm(d[3], d[2], 0x06040200u) ^ 0x80808080u;
                     hi[0] = __builtin_amdgcn_perm(d[1], d[0], 0x07050301u);
                     hi[1] = __builtin_amdgcn_perm(d[3], d[2], 0x07050301u);
-                    if (p < total) {
-                        *reinterpret_cast<u32x2 *>(&xs_lo[p]) = lo;
-                        *reinterpret_cast<u32x2 *>(&xs_hi[p]) = hi;
-                    }
+                    *reinterpret_cast<u32x2 *>(&xs_lo[p]) = lo;
+                    *reinterpret_cast<u32x2 *>(&xs_hi[p]) = hi;
                 }
             }
         } else {
@@ -223,6 +265,7 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         }
         const int any = __syncthreads_or(nonzero);
         have = prefetch(v, cn, tn);
+        if (have) { young = 0; young_other += nvu; }
 
         short *orow = out + (size_t)c * out_pitch;
         const bool whole = aligned_out && o0 + TILE_OUT <= n_out;
@@ -233,6 +276,8 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
             for (int j = 0; j < 4; j++) y[j] = (short)r4[j];
             if (whole) {
                 *reinterpret_cast<i16x4 *>(orow + o) = y;
+                young++;
+                young_other++;
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
@@ -304,7 +349,7 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
                     // an integer within eps of the value: the reference's own arithmetic decides, in the lane that found it
                     // (a value far outside the clamp range needs none: its int16 is the rail either way)
                     if (((unsure_mask[a][j] >> lane) & 1) && (unsigned)(res[a][j] + 32767) <= 65533u && o0 + oo + j < n_out)
-                        res[a][j] = mx_exact(xs_hi, xs_lo, (oo + j) * sh.M + sh.tpad, gd, sh.T, pr.gain);
+                        res[a][j] = mx_exact(xs_hi, xs_lo, (oo + j) * sh.M + sh.tpad, gd_lds, sh.T, pr.gain);
                 }
             }
         }
@@ -312,15 +357,25 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         for (int a = 0; a < NACC; a++) store4(a, res[a]);
     };
 
-    int c = (int)(blockIdx.x / (unsigned)sh.tiles_per_ch), t = (int)(blockIdx.x % (unsigned)sh.tiles_per_ch);
-    i16x8 v[NV];
-    bool have = prefetch(v, c, t);
-    while (c < channels) {
-        int cn = c, tn = t;
-        advance(cn, tn);
-        tile(c, t, cn, tn, v, have);
-        c = cn;
-        t = tn;
+    // two tiles of samples are always on their way: tile i is staged from one register set, which is then refilled with tile
+    // i + 2 while tile i + 1 waits in the other (one tile ahead left ~12 KB per workgroup in flight -- too little for the
+    // latency of a loaded HBM: the int16 kernels ran at the same speed whatever their arithmetic)
+    int c0 = (int)(blockIdx.x / (unsigned)sh.tiles_per_ch), t0 = (int)(blockIdx.x % (unsigned)sh.tiles_per_ch);
+    int c1 = c0, t1 = t0;
+    advance(c1, t1);
+    i16x8 va[NV], vb[NV];
+    bool have_a = prefetch(va, c0, t0), have_b = prefetch(vb, c1, t1);
+    int young_a = 0, young_b = 0;                       // (0 = "wait for everything" until the counts have built up)
+    while (c0 < channels) {
+        int c2 = c1, t2 = t1;
+        advance(c2, t2);
+        tile(c0, t0, c2, t2, va, have_a, young_a, young_b);
+        if (c1 >= channels) break;
+        int c3 = c2, t3 = t2;
+        advance(c3, t3);
+        tile(c1, t1, c3, t3, vb, have_b, young_b, young_a);
+        c0 = c2; t0 = t2;
+        c1 = c3; t1 = t3;
     }
 }
 
@@ -334,7 +389,7 @@ bool mx_make_shape(int T, int M, int nacc, long n_out, mx_shape *sh, size_t *lds
     sh->total = ((tile_out - 16) * M + 64 * sh->ksteps + 7) & ~7;
     sh->plane = (sh->total + 16 + 15) & ~15;
     sh->tiles_per_ch = (int)((n_out + tile_out - 1) / tile_out);
-    *lds_bytes = (size_t)MX_PLANES * sh->ksteps * 1024 + 2 * (size_t)sh->plane;
+    *lds_bytes = (size_t)MX_PLANES * sh->ksteps * 1024 + 2 * (size_t)sh->plane + sizeof(double) * (size_t)T;
     // pairs of plane sums are combined in 32 bits: (2 T 2^14)(256 + 1) < 2^31 needs T <= 200; the staging needs
     // total <= NV_MAX x 256 x 8 samples
     return *lds_bytes <= 160 * 1024 && sh->total <= MX_NV_MAX * MX_THREADS * 8 && T <= 200;
