@@ -567,10 +567,12 @@ static long rsm_process(rsm_t *r, unsigned long handle, const void *in, long n_i
         if (r->fmt == LLZ_PCM_I16_FAST)
             rc = llzs_fir_mfma_i16((const short *)d_in, (short *)d_out, (const short *)hist, (const float *)r->d_mat,
                                    r->channels, n_in, n_out, n_in, n_out, r->Q, r->M, (float)r->gain, r->stream);
-        else if (r->fmt == LLZ_PCM_I16 && r->use_screen)
-            rc = llzs_fir_mfma_i16x((const short *)d_in, (short *)d_out, (const short *)hist, r->d_digits,
-                                    (const double *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->Q, r->M,
-                                    r->screen_shift, r->screen_bias, r->gain, r->screen_eps, r->stream);
+        else if (r->fmt == LLZ_PCM_I16 && r->use_screen &&
+                 (rc = llzs_fir_mfma_i16x((const short *)d_in, (short *)d_out, (const short *)hist, r->d_digits,
+                                          (const double *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->Q, r->M,
+                                          r->screen_shift, r->screen_bias, r->gain, r->screen_eps, r->stream)) !=
+                     LLZ_ERR_RANGE)
+            ;                                   /* (LLZ_ERR_RANGE: a frame too short or misaligned for the screened kernel) */
         else if (r->fmt == LLZ_PCM_I16)
             rc = llzs_resample_i16((const short *)d_in, (short *)d_out, (const short *)hist,
                                    (const double *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->L, r->M,

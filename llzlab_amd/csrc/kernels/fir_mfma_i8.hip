@@ -100,12 +100,12 @@ __device__ __forceinline__ int mx_decide(int a0, int a1, int a2, int a3, int a4,
 {
     const int p = a0 + (a1 << 8);
     const int q = a2 + (a3 << 8);
-    const unsigned u = (unsigned)q << 16;                       // q 2^16 = (q >> 16) 2^32 + u
-    const int h0 = a4 + (q >> 16) + pr.bq_hi;
-    const unsigned lo0 = u + (unsigned)pr.bq_lo;
-    const int h1 = h0 + (int)(lo0 < u);                         // carry of the first add
-    const unsigned lo = lo0 + (unsigned)p;
-    const int hi = h1 + (p >> 31) + (int)(lo < lo0);            // sign extension of p and the second carry
+    // T' = (p + Bq) + q 2^16 + a4 2^32 as two add-with-carry pairs (q 2^16 = (q >> 16) 2^32 + (q << 16) mod 2^32)
+    unsigned c1, c2;
+    const unsigned lo_w = __builtin_addc((unsigned)p, (unsigned)pr.bq_lo, 0u, &c1);
+    const unsigned hi_w = (unsigned)(p >> 31) + (unsigned)pr.bq_hi + c1;
+    const unsigned lo = __builtin_addc(lo_w, (unsigned)q << 16, 0u, &c2);
+    const int hi = (int)(hi_w + (unsigned)((q >> 16) + a4) + c2);
     int I;
     unsigned F;
     if (NEG) {
@@ -124,14 +124,20 @@ __device__ __forceinline__ int mx_decide(int a0, int a1, int a2, int a3, int a4,
 }
 
 // The sample prefetch is issued and awaited by hand.  Left to the compiler, every use of a prefetched register was preceded
-// by s_waitcnt vmcnt(0): that also waits for the previous tile's output STORES (and would wait for the other register set's
-// loads), once per tile.  Vector-memory operations complete in issue order per wave, so a set requested `younger` operations
-// ago is complete once at most `younger` operations are outstanding; the kernel counts the operations it issues (a lower
-// bound is safe: it only makes the wait stricter) and waits for exactly the set it is about to use.
-__device__ __forceinline__ i16x8 mx_load_nt(const short *p)
+// by s_waitcnt vmcnt(0): that also waits for the previous tile's output STORES, once per tile.  Vector-memory operations
+// complete in issue order per wave, so a request issued `young` operations ago is complete once at most `young` operations
+// are outstanding; the kernel counts the operations it issues behind a request (a lower bound is safe: it only makes the wait
+// stricter).  Rules that keep this safe against the compiler, which does not know that the registers are pending:
+//   * ONE request site in the whole kernel, unconditional (a tile that cannot use the streamed form requests a harmless
+//     in-bounds address and ignores the data): a value defined in two places, or under a branch, is merged by copies -- and a
+//     copy of a pending register reads (and may write back) stale data;
+//   * ONE point behind the waits through which the registers pass (mx_pin, no instruction): every use depends on it, so
+//     none can be placed in front of a wait.
+// base: wave-uniform 64-bit address (SGPR pair); off: per-lane byte offset
+__device__ __forceinline__ i16x8 mx_load_nt(const short *base, int off)
 {
     i16x8 r;
-    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(r) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(r) : "v"(off), "s"(base) : "memory");
     return r;
 }
 template <int N>
@@ -139,9 +145,6 @@ __device__ __forceinline__ void mx_wait_vm()
 {
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
 }
-// ONE point behind the waits through which the prefetched registers pass (no instruction): every use of them depends on it,
-// so none can be placed in front of a wait -- and being a single definition it needs no copies (a wait that took the
-// registers as operands itself did: three alternative waits merged into new registers, copied BEFORE each wait)
 template <int NV>
 __device__ __forceinline__ void mx_pin(i16x8 (&v)[NV])
 {
@@ -171,6 +174,8 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
     signed char *xs_lo = atab + MX_PLANES * aplane;      // sample planes: low digit (x & 255) - 128, then x >> 8
     signed char *xs_hi = xs_lo + sh.plane;
     double *gd_lds = reinterpret_cast<double *>(xs_hi + sh.plane);      // the T double taps (recompute path)
+    int *any_flag = reinterpret_cast<int *>(gd_lds + sh.T);             // two words: see the staging barrier
+    int flip = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, kq = lane >> 4;
     const int seg = mx_seg(n);
@@ -186,6 +191,7 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         atab[e] = (k >= 0 && k < sh.T) ? digits[p * sh.T + k] : (signed char)0;
     }
     for (int k = tid; k < sh.T; k += MX_THREADS) gd_lds[k] = gd[k];
+    if (tid < 2) any_flag[tid] = 0;
 
     // the walk: tile (c, t) = channel c, tile t of the channel; a workgroup advances by gridDim.x tiles, channel by channel
     // (no division in the loop: gridDim.x = cdiv tiles_per_ch + crem is split once)
@@ -196,58 +202,45 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         if (t >= sh.tiles_per_ch) { t -= sh.tiles_per_ch; c++; }
     };
     auto first_of = [&](int t) { return (long)t * (TILE_OUT * sh.M) - sh.tpad; };
-    auto is_interior = [&](long first) { return aligned_in && first >= 0 && first + total <= n_in; };
-
-    // a tile's samples, 8 per register, requested two tiles ahead of their use (interior tiles: all but the first and the last
-    // of a channel; those two are read sample by sample when their turn comes)
-    auto prefetch = [&](i16x8 (&v)[NV], int c, int t) {
+    // streamed form: all but the first and the last tile of a channel (those two are read sample by sample: history in front
+    // of the frame, zeros behind it)
+    auto streams = [&](int c, int t) {
         const long first = first_of(t);
-        if (c >= channels || !is_interior(first)) return false;
-        const short *src = in + (size_t)c * in_pitch + first;
-#pragma unroll
-        for (int j = 0; j < NV; j++) {
-            if (j * MX_THREADS * 8 < total) {
-                int p = (j * MX_THREADS + tid) * 8;
-                p = p < last8 ? p : last8;
-                v[j] = mx_load_nt(src + p);
-            }
-        }
-        return true;
+        return c < channels && aligned_in && first >= 0 && first + total <= n_in;
     };
-    const int nvu = (total + MX_THREADS * 8 - 1) / (MX_THREADS * 8);     // loads per thread and request (<= NV)
+    // per-lane byte offsets of a request's 16-byte groups (the threads past the end re-read the last group)
+    int poff[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int p = (j * MX_THREADS + tid) * 8;
+        poff[j] = 2 * (p < last8 ? p : last8);
+    }
 
-    // young = vector-memory operations this wave has issued since the set `v` was requested (a lower bound); young_other =
-    // the same for the other register set
-    auto tile = [&](int c, int t, int cn, int tn, i16x8 (&v)[NV], bool &have, int &young, int &young_other) {
-        const long o0 = (long)t * TILE_OUT;
-        const long first = first_of(t);
-        __syncthreads();
+    // front half of a tile: its samples into the LDS planes; returns "some sample is non-zero"
+    auto stage = [&](int c, int t, i16x8 (&v)[NV], bool streamed, int young) {
+        __syncthreads();                                  // the previous tile's readers of the planes are done
         int nonzero = 0;
-        if (have) {
-            // steady state: the previous tile's stores, the other set's request and the stores before it are younger
-            if (young >= 2 * NACC + 4) mx_wait_vm<2 * NACC + 4>();
-            else if (young >= 2 * NACC + 3) mx_wait_vm<2 * NACC + 3>();
+        if (streamed) {
+            // the stores of the previous tile are the only operations younger than the request
+            if (young >= NACC) mx_wait_vm<NACC>();
             else mx_wait_vm<0>();
             mx_pin(v);
 #pragma unroll
             for (int j = 0; j < NV; j++) {
-                if (j * MX_THREADS * 8 < total) {
-                    int p = (j * MX_THREADS + tid) * 8;
-                    p = p < last8 ? p : last8;              // (the threads past the end rewrite the last group: same bytes)
-                    // 8 samples = 4 dwords; v_perm_b32 gathers the low / high bytes of four samples at a time, and
-                    // (x & 255) - 128 as a signed byte is the low byte with its top bit flipped
-                    const u32x4 d = __builtin_bit_cast(u32x4, v[j]);
-                    nonzero |= (int)(d[0] | d[1] | d[2] | d[3]);
-                    u32x2 lo, hi;
-                    lo[0] = __builtin_amdgcn_perm(d[1], d[0], 0x06040200u) ^ 0x80808080u;
-                    lo[1] = __builtin_amdgcn_perm(d[3], d[2], 0x06040200u) ^ 0x80808080u;
-                    hi[0] = __builtin_amdgcn_perm(d[1], d[0], 0x07050301u);
-                    hi[1] = __builtin_amdgcn_perm(d[3], d[2], 0x07050301u);
-                    *reinterpret_cast<u32x2 *>(&xs_lo[p]) = lo;
-                    *reinterpret_cast<u32x2 *>(&xs_hi[p]) = hi;
-                }
+                // 8 samples = 4 dwords; v_perm_b32 gathers the low / high bytes of four samples at a time, and
+                // (x & 255) - 128 as a signed byte is the low byte with its top bit flipped
+                const u32x4 d = __builtin_bit_cast(u32x4, v[j]);
+                nonzero |= (int)(d[0] | d[1] | d[2] | d[3]);
+                u32x2 lo, hi;
+                lo[0] = __builtin_amdgcn_perm(d[1], d[0], 0x06040200u) ^ 0x80808080u;
+                lo[1] = __builtin_amdgcn_perm(d[3], d[2], 0x06040200u) ^ 0x80808080u;
+                hi[0] = __builtin_amdgcn_perm(d[1], d[0], 0x07050301u);
+                hi[1] = __builtin_amdgcn_perm(d[3], d[2], 0x07050301u);
+                *reinterpret_cast<u32x2 *>(&xs_lo[poff[j] >> 1]) = lo;
+                *reinterpret_cast<u32x2 *>(&xs_hi[poff[j] >> 1]) = hi;
             }
         } else {
+            const long first = first_of(t);
             const short *row = in + (size_t)c * in_pitch;
             const short *hrow = hist ? hist + (size_t)c * (sh.T - 1) : nullptr;
             for (int p = tid; p < total; p += MX_THREADS) {
@@ -263,10 +256,21 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
                 xs_hi[p] = (signed char)(x >> 8);
             }
         }
-        const int any = __syncthreads_or(nonzero);
-        have = prefetch(v, cn, tn);
-        if (have) { young = 0; young_other += nvu; }
+        // "is any sample of the tile non-zero": one LDS word per tile parity, set by the first lane of each wave that saw one
+        // (plain stores of the same value), read behind the staging barrier -- __syncthreads_or costs two more barriers and
+        // an LDS atomic per tile.  The word of the NEXT tile is cleared here, behind this tile's barrier (its last readers
+        // passed two barriers ago).
+        if (__ballot(nonzero != 0) != 0 && lane == 0) any_flag[flip] = 1;
+        __syncthreads();
+        const int any = any_flag[flip];
+        if (tid == 0) any_flag[flip ^ 1] = 0;
+        flip ^= 1;
+        return any;
+    };
 
+    // back half: products, decisions, stores; returns the number of store instructions issued per lane (for the wait count)
+    auto finish = [&](int c, int t, int any) {
+        const long o0 = (long)t * TILE_OUT;
         short *orow = out + (size_t)c * out_pitch;
         const bool whole = aligned_out && o0 + TILE_OUT <= n_out;
         auto store4 = [&](int a, const int (&r4)[4]) {
@@ -276,8 +280,6 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
             for (int j = 0; j < 4; j++) y[j] = (short)r4[j];
             if (whole) {
                 *reinterpret_cast<i16x4 *>(orow + o) = y;
-                young++;
-                young_other++;
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
@@ -288,7 +290,7 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
             const int zero[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int a = 0; a < NACC; a++) store4(a, zero);
-            return;
+            return whole ? NACC : 0;
         }
         i32x4 acc[NACC][MX_ACCS];
         {
@@ -324,11 +326,10 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
             for (int s = 1; s < sh.ksteps; s++) step(s, std::false_type{});
         }
 
-        // every output decided without a branch; the lanes that could not decide are collected per output slot and handled
-        // together afterwards (about 2 eps of all outputs: most tiles have none)
+        // every output decided without a branch; a lane notes the slots it could not decide in a bit mask, and the rare lanes
+        // that have any (about 2 eps of all outputs: most tiles have none) work them off one by one afterwards
         int res[NACC][4];
-        unsigned long long unsure_mask[NACC][4];
-        unsigned long long unsure_any = 0;
+        unsigned mine = 0;
 #pragma unroll
         for (int a = 0; a < NACC; a++)
 #pragma unroll
@@ -336,46 +337,58 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
                 int I;
                 bool unsure;
                 res[a][j] = mx_decide<NEG>(acc[a][0][j], acc[a][1][j], acc[a][2][j], acc[a][3][j], acc[a][4][j], pr, I, unsure);
-                unsure_mask[a][j] = __ballot(unsure);
-                unsure_any |= unsure_mask[a][j];
+                mine = mine + mine + (unsure ? 1u : 0u);            // slot 4 a + j ends up at bit 4 NACC - 1 - (4 a + j)
             }
-        if (unsure_any) {
+        if (__ballot(mine != 0) != 0) {
+#pragma unroll 1
+            while (mine != 0) {
+                // an integer within eps of the value: the reference's own arithmetic decides, in the lane that found it
+                const int slot = 4 * NACC - 1 - __builtin_ctz(mine);
+                mine &= mine - 1;
+                const int oo = ((wave * NACC + (slot >> 2)) * 16 + seg) * 16 + 4 * kq + (slot & 3);
+                int cur = 0;
 #pragma unroll
-            for (int a = 0; a < NACC; a++) {
-                const int oo = ((wave * NACC + a) * 16 + seg) * 16 + 4 * kq;
+                for (int a = 0; a < NACC; a++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (unsure_mask[a][j] == 0) continue;
-                    // an integer within eps of the value: the reference's own arithmetic decides, in the lane that found it
-                    // (a value far outside the clamp range needs none: its int16 is the rail either way)
-                    if (((unsure_mask[a][j] >> lane) & 1) && (unsigned)(res[a][j] + 32767) <= 65533u && o0 + oo + j < n_out)
-                        res[a][j] = mx_exact(xs_hi, xs_lo, (oo + j) * sh.M + sh.tpad, gd_lds, sh.T, pr.gain);
+                    for (int j = 0; j < 4; j++) cur = slot == 4 * a + j ? res[a][j] : cur;
+                // (a value far outside the clamp range needs no second look: its int16 is the rail either way)
+                if (o0 + oo < n_out && (unsigned)(cur + 32767) <= 65533u) {
+                    const int r = mx_exact(xs_hi, xs_lo, oo * sh.M + sh.tpad, gd_lds, sh.T, pr.gain);
+#pragma unroll
+                    for (int a = 0; a < NACC; a++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) res[a][j] = slot == 4 * a + j ? r : res[a][j];
                 }
             }
         }
 #pragma unroll
         for (int a = 0; a < NACC; a++) store4(a, res[a]);
+        return whole ? NACC : 0;
     };
 
-    // two tiles of samples are always on their way: tile i is staged from one register set, which is then refilled with tile
-    // i + 2 while tile i + 1 waits in the other (one tile ahead left ~12 KB per workgroup in flight -- too little for the
-    // latency of a loaded HBM: the int16 kernels ran at the same speed whatever their arithmetic)
-    int c0 = (int)(blockIdx.x / (unsigned)sh.tiles_per_ch), t0 = (int)(blockIdx.x % (unsigned)sh.tiles_per_ch);
-    int c1 = c0, t1 = t0;
-    advance(c1, t1);
-    i16x8 va[NV], vb[NV];
-    bool have_a = prefetch(va, c0, t0), have_b = prefetch(vb, c1, t1);
-    int young_a = 0, young_b = 0;                       // (0 = "wait for everything" until the counts have built up)
-    while (c0 < channels) {
-        int c2 = c1, t2 = t1;
-        advance(c2, t2);
-        tile(c0, t0, c2, t2, va, have_a, young_a, young_b);
-        if (c1 >= channels) break;
-        int c3 = c2, t3 = t2;
-        advance(c3, t3);
-        tile(c1, t1, c3, t3, vb, have_b, young_b, young_a);
-        c0 = c2; t0 = t2;
-        c1 = c3; t1 = t3;
+    // One loop, one request site.  Iteration k stages and finishes tile k (none in the first iteration) and requests tile
+    // k + 1 between the two halves, right behind the staging barrier: the request has a whole tile's arithmetic to arrive.
+    int c = 0, t = 0;                                   // the tile in work (none yet)
+    int cn = (int)(blockIdx.x / (unsigned)sh.tiles_per_ch), tn = (int)(blockIdx.x % (unsigned)sh.tiles_per_ch);
+    bool in_work = false, streamed = false;
+    int young = 0;
+    i16x8 v[NV];
+    while (in_work || cn < channels) {
+        int any = 0;
+        if (in_work) any = stage(c, t, v, streamed, young);
+        const bool next_streams = streams(cn, tn);
+        // (a tile that does not stream requests the first row instead: in bounds -- the launcher requires n_in >= total --
+        //  and never looked at)
+        const short *src = next_streams ? in + (size_t)cn * in_pitch + first_of(tn) : in;
+#pragma unroll
+        for (int j = 0; j < NV; j++) v[j] = mx_load_nt(src, poff[j]);
+        young = 0;
+        if (in_work) young = finish(c, t, any);
+        c = cn;
+        t = tn;
+        in_work = c < channels;
+        streamed = next_streams;
+        advance(cn, tn);
     }
 }
 
@@ -389,7 +402,7 @@ bool mx_make_shape(int T, int M, int nacc, long n_out, mx_shape *sh, size_t *lds
     sh->total = ((tile_out - 16) * M + 64 * sh->ksteps + 7) & ~7;
     sh->plane = (sh->total + 16 + 15) & ~15;
     sh->tiles_per_ch = (int)((n_out + tile_out - 1) / tile_out);
-    *lds_bytes = (size_t)MX_PLANES * sh->ksteps * 1024 + 2 * (size_t)sh->plane + sizeof(double) * (size_t)T;
+    *lds_bytes = (size_t)MX_PLANES * sh->ksteps * 1024 + 2 * (size_t)sh->plane + sizeof(double) * (size_t)T + 2 * sizeof(int);
     // pairs of plane sums are combined in 32 bits: (2 T 2^14)(256 + 1) < 2^31 needs T <= 200; the staging needs
     // total <= NV_MAX x 256 x 8 samples
     return *lds_bytes <= 160 * 1024 && sh->total <= MX_NV_MAX * MX_THREADS * 8 && T <= 200;
@@ -470,6 +483,13 @@ extern "C" int llzs_fir_mfma_i16x(const short *in, short *out, const short *hist
     mx_shape sh;
     size_t bytes;
     mx_make_shape(T, M, nb, n_out, &sh, &bytes);
+    // the kernel's sample requests are unconditional: a tile that cannot stream reads the head of the first row instead, so
+    // that head must exist and be aligned (frames shorter than one tile, odd pitches: the caller takes the all-double kernel)
+    if (n_in < sh.total || (in_pitch & 7) != 0 || (reinterpret_cast<uintptr_t>(in) & 15) != 0) {
+        llzs_set_error("fir_mfma_i16x: frame of %ld samples (pitch %ld) is too short or not 16-byte aligned for the tile of %d",
+                       n_in, in_pitch, sh.total);
+        return LLZ_ERR_RANGE;
+    }
     const bool small = sh.total <= 4 * MX_THREADS * 8;
 #define MX_GO(A, V)                                                                                                            \
     do {                                                                                                                       \

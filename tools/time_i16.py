@@ -1,29 +1,34 @@
-"""time the int16 1:3 decimator forms on BASELINE config 5's per-GPU shape (or smaller): python tools/time_i16.py [channels]"""
-import os, sys
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-import torch
-from llzlab_amd import capi, filters
+#!/usr/bin/env python3
+"""Event-timed int16 1:3 decimator (LLZ_PCM_I16, the screened bit-exact path): python tools/time_i16.py [channels] [L M]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from llzlab_amd import capi, filters  # noqa: E402
+
 ch = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-n = 3 * (((1 << 22) // 3) // 256 * 256)
+L_, M_ = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1, 3)
 dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+Lb = capi.lib()
+capi.check(Lb.llz_hip_set_device(0), "set_device")
+stream = torch.cuda.current_stream()
+n = M_ * (((1 << 22) // M_) // 256 * 256) if L_ == 1 else M_ * 8192
 x = torch.empty(ch, n, dtype=torch.int16, device=dev)
-y = torch.empty(ch, n // 3, dtype=torch.int16, device=dev)
-filters.synth_i16(x, 0x11C0FFEE)
-L = capi.lib()
-def timed(fn, steps):
-    fn(); torch.cuda.synchronize()
-    t = L.llz_hip_timer_new(); L.llz_hip_timer_start(t, None)
-    for _ in range(steps): fn()
-    L.llz_hip_timer_stop(t, None); ms = L.llz_hip_timer_ms(t) / steps; L.llz_hip_timer_free(t)
-    return ms
-res = {}
-for name, fmt, tune, steps in (("screened (bit-exact)", filters.PCM_I16, {}, 3), ("fast (1 LSB)", filters.PCM_I16_FAST, {}, 3),
-                               ("all-double (bit-exact)", filters.PCM_I16, {"rs_i16_path": 1}, 1)):
-    with capi.tuned(**tune):
-        r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, fmt)
-        ms = timed(lambda: r.process(x, y), steps)
-        res[name] = y.clone() if "exact" in name else None
-        print(f"{name:24s} {ch} ch x {n}: {ms:.2f} ms  {(2 + 2 / 3) * ch * n / ms / 1e6:.0f} GB/s ({(2 + 2 / 3) * ch * n / ms / 1e6 / 80:.1f} % of 8 TB/s)", flush=True)
-        r.close()
-a, b = res["screened (bit-exact)"], res["all-double (bit-exact)"]
-print("screened == all-double on the whole batch:", bool(torch.equal(a, b)))
+y = torch.empty(ch, n * L_ // M_, dtype=torch.int16, device=dev)
+filters.synth_i16(x, 1, stream=stream)
+r = filters.ResampleMC(ch, L_, M_, 1.0, filters.BLACKMAN, filters.PCM_I16, stream=stream)
+for _ in range(3):
+    r.process(x, y)
+torch.cuda.synchronize()
+t = Lb.llz_hip_timer_new()
+reps = 5 if ch >= 4096 else 20
+Lb.llz_hip_timer_start(t, stream.cuda_stream)
+for _ in range(reps):
+    r.process(x, y)
+Lb.llz_hip_timer_stop(t, stream.cuda_stream)
+ms = Lb.llz_hip_timer_ms(t) / reps
+gb = (2 + 2 * L_ / M_) * ch * n / ms / 1e6
+print(f"{os.path.basename(capi.LIB_PATH)}: resample {L_}:{M_} i16 exact {ch}ch x {n}: {ms:.3f} ms  {gb:.0f} GB/s ({gb / 80:.1f} %)")
