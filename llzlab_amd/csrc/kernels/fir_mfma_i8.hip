@@ -196,18 +196,23 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
     // the walk: tile (c, t) = channel c, tile t of the channel; a workgroup advances by gridDim.x tiles, channel by channel
     // (no division in the loop: gridDim.x = cdiv tiles_per_ch + crem is split once)
     const int cdiv = (int)(gridDim.x / (unsigned)sh.tiles_per_ch), crem = (int)(gridDim.x % (unsigned)sh.tiles_per_ch);
-    auto advance = [&](int &c, int &t) {
+    // (ioff / ooff: element offsets of the tile's first input sample, without the -tpad, and of its first output, kept by
+    //  increments as well: the 64-bit products c * pitch + t * tile per tile cost ~60 scalar instructions)
+    const long tile_in = (long)TILE_OUT * sh.M;
+    const long in_step = (long)cdiv * in_pitch + (long)crem * tile_in, in_wrap = in_pitch - (long)sh.tiles_per_ch * tile_in;
+    const long out_step = (long)cdiv * out_pitch + (long)crem * TILE_OUT, out_wrap = out_pitch - (long)sh.tiles_per_ch * TILE_OUT;
+    auto advance = [&](int &c, int &t, long &ioff, long &ooff) {
         c += cdiv;
         t += crem;
-        if (t >= sh.tiles_per_ch) { t -= sh.tiles_per_ch; c++; }
+        ioff += in_step;
+        ooff += out_step;
+        if (t >= sh.tiles_per_ch) { t -= sh.tiles_per_ch; c++; ioff += in_wrap; ooff += out_wrap; }
     };
-    auto first_of = [&](int t) { return (long)t * (TILE_OUT * sh.M) - sh.tpad; };
+    auto first_of = [&](int t) { return (long)t * tile_in - sh.tpad; };
     // streamed form: all but the first and the last tile of a channel (those two are read sample by sample: history in front
     // of the frame, zeros behind it)
-    auto streams = [&](int c, int t) {
-        const long first = first_of(t);
-        return c < channels && aligned_in && first >= 0 && first + total <= n_in;
-    };
+    const int t_stream_end = (int)((n_in - total + sh.tpad) / tile_in);          // largest t with first + total <= n_in
+    auto streams = [&](int c, int t) { return c < channels && aligned_in && t >= 1 && t <= t_stream_end; };
     // per-lane byte offsets of a request's 16-byte groups (the threads past the end re-read the last group)
     int poff[NV];
 #pragma unroll
@@ -269,21 +274,21 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
     };
 
     // back half: products, decisions, stores; returns the number of store instructions issued per lane (for the wait count)
-    auto finish = [&](int c, int t, int any) {
+    auto finish = [&](int t, long ooff, int any) {
         const long o0 = (long)t * TILE_OUT;
-        short *orow = out + (size_t)c * out_pitch;
+        short *otile = out + ooff;                                   // wave-uniform: the tile's first output
         const bool whole = aligned_out && o0 + TILE_OUT <= n_out;
         auto store4 = [&](int a, const int (&r4)[4]) {
-            const long o = o0 + ((wave * NACC + a) * 16 + seg) * 16 + 4 * kq;   // first of this lane's 4 outputs of block a
+            const int oo = ((wave * NACC + a) * 16 + seg) * 16 + 4 * kq;        // first of this lane's 4 outputs of block a
             i16x4 y;
 #pragma unroll
             for (int j = 0; j < 4; j++) y[j] = (short)r4[j];
             if (whole) {
-                *reinterpret_cast<i16x4 *>(orow + o) = y;
+                *reinterpret_cast<i16x4 *>(otile + oo) = y;
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    if (o + j < n_out) orow[o + j] = y[j];
+                    if (o0 + oo + j < n_out) otile[oo + j] = y[j];
             }
         };
         if (!any) {                                     // digital silence: every output sits ON the integer 0
@@ -369,7 +374,9 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
     // One loop, one request site.  Iteration k stages and finishes tile k (none in the first iteration) and requests tile
     // k + 1 between the two halves, right behind the staging barrier: the request has a whole tile's arithmetic to arrive.
     int c = 0, t = 0;                                   // the tile in work (none yet)
+    long ooff = 0;
     int cn = (int)(blockIdx.x / (unsigned)sh.tiles_per_ch), tn = (int)(blockIdx.x % (unsigned)sh.tiles_per_ch);
+    long ioff_n = (long)cn * in_pitch + (long)tn * tile_in, ooff_n = (long)cn * out_pitch + (long)tn * TILE_OUT;
     bool in_work = false, streamed = false;
     int young = 0;
     i16x8 v[NV];
@@ -379,16 +386,17 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         const bool next_streams = streams(cn, tn);
         // (a tile that does not stream requests the first row instead: in bounds -- the launcher requires n_in >= total --
         //  and never looked at)
-        const short *src = next_streams ? in + (size_t)cn * in_pitch + first_of(tn) : in;
+        const short *src = next_streams ? in + (ioff_n - sh.tpad) : in;
 #pragma unroll
         for (int j = 0; j < NV; j++) v[j] = mx_load_nt(src, poff[j]);
         young = 0;
-        if (in_work) young = finish(c, t, any);
+        if (in_work) young = finish(t, ooff, any);
         c = cn;
         t = tn;
+        ooff = ooff_n;
         in_work = c < channels;
         streamed = next_streams;
-        advance(cn, tn);
+        advance(cn, tn, ioff_n, ooff_n);
     }
 }
 
