@@ -265,6 +265,11 @@ typedef struct {
     long long screen_bias;
     double screen_eps;
     signed char *d_digits;      /* [LLZS_MX_PLANES][Q] */
+    /* I16, L >= 2: the same screen per phase, on the phase-tile mapping (resample_i8.hip) */
+    int use_screen_lm;
+    signed char *d_scr_atab;    /* [ceil(L/16)][steps][5][64][16] tap digits in matrix-core operand order */
+    int *d_scr_aoff;            /* [ceil(L/16)] band starts */
+    int *d_scr_bq;              /* [16 ceil(L/16)][2] per-phase bias */
     /* F32, L >= 5: the banded tap matrix in matrix-core operand order (resample_mfma.hip) */
     float *d_band;
     int *d_band_c0;
@@ -282,7 +287,8 @@ static void rsm_destroy(rsm_t *r)
 {
     if (!r) return;
     tapmat_free(&r->taps);
-    llzs_free(r->d_mat); llzs_free(r->d_phase); llzs_free(r->d_digits); llzs_free(r->d_band); llzs_free(r->d_band_c0); llzs_free(r->d_hist[0]); llzs_free(r->d_hist[1]);
+    llzs_free(r->d_mat); llzs_free(r->d_phase); llzs_free(r->d_digits); llzs_free(r->d_scr_atab); llzs_free(r->d_scr_aoff);
+    llzs_free(r->d_scr_bq); llzs_free(r->d_band); llzs_free(r->d_band_c0); llzs_free(r->d_hist[0]); llzs_free(r->d_hist[1]);
     llz_stage_release(&r->st_in); llz_stage_release(&r->st_out);
     r->tag = 0;
     free(r);
@@ -356,12 +362,107 @@ static int rsm_build_screen(rsm_t *r)
     return ok;
 }
 
+/* The same screen for L >= 2 (resample_i8.hip): one tap row per phase f, g_f[k] = taps.mat[f][k]; ONE shift for all rows (from
+ * the largest |gain g|), per-row digits, bias and error bound (the formulas of rsm_build_screen with the row's own sums), eps =
+ * the largest row bound.  The digits go straight into matrix-core operand order: phase tile t = phases 16 t .. 16 t + 15; its
+ * band starts at window position a_t = (c_{16t} + Hp - (Q-1)) & ~15 (Hp = Q-1 rounded up to 8, the position of a period's own
+ * first sample; c_f = (f M) / L); lane (r = lane % 16, kq = lane / 16) of step s and digit plane p holds, in byte j, digit p of
+ * the tap of phase f = 16 t + r that multiplies window position pos = a_t + 64 s + 16 chunk(kq) + j, i.e. tap k = c_f + Hp - pos
+ * (chunk(kq) = ((kq & 1) << 1) | (kq >> 1): kernels/screen_i8.hpp). */
+static int rsm_build_screen_lm(rsm_t *r)
+{
+    const int L = r->L, M = r->M, Q = r->Q, nt = (L + 15) / 16;
+    const double gain = r->gain;
+    if (!llzs_resample_i16x_fits(L, M, Q)) return 0;
+    double maxabs = 0.0, max_sumabs = 0.0;
+    for (int f = 0; f < L; f++) {
+        double sumabs = 0.0;
+        for (int k = 0; k < Q; k++) {
+            const double a = fabs(r->taps.mat[(size_t)f * Q + k] * gain);
+            if (!(a < 1e30)) return 0;
+            if (a > maxabs) maxabs = a;
+            sumabs += a;
+        }
+        if (sumabs > max_sumabs) max_sumabs = sumabs;
+    }
+    if (maxabs == 0.0) return 0;
+    int e_max, e_sum;
+    (void)frexp(maxabs, &e_max);
+    (void)frexp(max_sumabs, &e_sum);
+    int shift = 38 - e_max;                             /* |G| < 2^38: five balanced digits hold it */
+    if (shift > 46 - e_sum) shift = 46 - e_sum;         /* 2^15 sum|G| < 2^62 */
+    if (shift > 46) shift = 46;
+    if (shift < 32) return 0;
+    const int steps = llzs_resample_i16x_ksteps(L, M, Q), Hp = (Q - 1 + 7) & ~7;
+    const size_t abytes = (size_t)nt * steps * 5 * 1024;
+    signed char *atab = (signed char *)calloc(abytes, 1);
+    signed char *dig = (signed char *)malloc((size_t)5 * Q);
+    int *aoff = (int *)calloc((size_t)nt, sizeof(int)), *bq = (int *)calloc((size_t)nt * 32, sizeof(int));
+    int ok = atab && dig && aoff && bq;
+    double eps = 0.0;
+    for (int f = 0; ok && f < L; f++) {
+        const double *g = r->taps.mat + (size_t)f * Q;
+        const int t = f / 16, row = f % 16, cf = (int)(((long)f * M) / L);
+        const int a_t = (int)((((long)16 * t * M) / L) + Hp - (Q - 1)) & ~15;
+        aoff[t] = a_t;
+        long long sumG = 0, sum_d0 = 0;
+        double qerr = 0.0, sumabs = 0.0;
+        for (int k = 0; k < Q; k++) {
+            const double gk = g[k] * gain;
+            long long G = llround(ldexp(gk, shift));
+            qerr += fabs(gk - ldexp((double)G, -shift));
+            sumabs += fabs(gk);
+            sumG += G;
+            for (int p = 0; p < 5; p++) {
+                const int d = (int)(((G + 128) & 255) - 128);
+                dig[(size_t)p * Q + k] = (signed char)d;
+                if (p == 0) sum_d0 += d < 0 ? -d : d;
+                G = (G - d) / 256;
+            }
+            if (G != 0) ok = 0;
+        }
+        const double e = 2.0 * 32768.0 * (qerr + (double)(Q + 2) * ldexp(1.0, -52) * sumabs) + ldexp(1.0, -30) +
+                         ldexp(128.0 * (double)sum_d0 + 256.0, -shift);
+        if (e > eps) eps = e;
+        const long long bias = 128 * sumG, bqv = bias >= 0 ? bias / 256 : -((-bias + 255) / 256);      /* floor(bias / 256) */
+        bq[2 * f] = (int)(unsigned)((unsigned long long)bqv & 0xffffffffull);
+        bq[2 * f + 1] = (int)(bqv >> 32);
+        for (int s = 0; s < steps; s++)
+            for (int kq = 0; kq < 4; kq++)
+                for (int j = 0; j < 16; j++) {
+                    const int pos = a_t + 64 * s + 16 * (((kq & 1) << 1) | (kq >> 1)) + j;
+                    const int k = cf + Hp - pos;
+                    if (k < 0 || k >= Q) continue;
+                    for (int p = 0; p < 5; p++)
+                        atab[((((size_t)t * steps + s) * 5 + p) * 64 + (size_t)(16 * kq + row)) * 16 + j] = dig[(size_t)p * Q + k];
+                }
+    }
+    if (ok && eps < 0.0625) {
+        if (!r->d_scr_atab) r->d_scr_atab = (signed char *)llzs_malloc(abytes);
+        if (!r->d_scr_aoff) r->d_scr_aoff = (int *)llzs_malloc(sizeof(int) * (size_t)nt);
+        if (!r->d_scr_bq) r->d_scr_bq = (int *)llzs_malloc(sizeof(int) * (size_t)nt * 32);
+        ok = r->d_scr_atab && r->d_scr_aoff && r->d_scr_bq && llzs_h2d_table(r->d_scr_atab, atab, abytes) == LLZ_OK &&
+             llzs_h2d_table(r->d_scr_aoff, aoff, sizeof(int) * (size_t)nt) == LLZ_OK &&
+             llzs_h2d_table(r->d_scr_bq, bq, sizeof(int) * (size_t)nt * 32) == LLZ_OK;
+    } else {
+        ok = 0;
+    }
+    free(atab); free(dig); free(aoff); free(bq);
+    if (ok) {
+        r->screen_shift = shift;
+        r->screen_eps = eps;
+    }
+    return ok;
+}
+
 static int rsm_upload_matrix(rsm_t *r)
 {
     const size_t count = (size_t)r->L * r->Q;
     if (r->fmt == LLZ_PCM_I16) {
         const int rc = llzs_h2d_table(r->d_mat, r->taps.mat, sizeof(double) * count);
-        r->use_screen = rc == LLZ_OK && r->L == 1 && llzs_tune(LLZS_TUNE_RS_I16_PATH) != 1 && rsm_build_screen(r);
+        const int want = rc == LLZ_OK && llzs_tune(LLZS_TUNE_RS_I16_PATH) != 1;
+        r->use_screen = want && r->L == 1 && rsm_build_screen(r);
+        r->use_screen_lm = want && r->L >= 2 && rsm_build_screen_lm(r);
         return rc;
     }
     float *m32 = (float *)malloc(sizeof(float) * count);
@@ -573,6 +674,11 @@ static long rsm_process(rsm_t *r, unsigned long handle, const void *in, long n_i
                                           r->screen_shift, r->screen_bias, r->gain, r->screen_eps, r->stream)) !=
                      LLZ_ERR_RANGE)
             ;                                   /* (LLZ_ERR_RANGE: a frame too short or misaligned for the screened kernel) */
+        else if (r->fmt == LLZ_PCM_I16 && r->use_screen_lm && r->in_count % r->M == 0 && r->out_count % r->L == 0 &&
+                 r->channels <= 65535)
+            rc = llzs_resample_i16x((const short *)d_in, (short *)d_out, (const short *)hist, r->d_scr_atab, r->d_scr_aoff,
+                                    r->d_scr_bq, (const double *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->L, r->M,
+                                    r->Q, r->screen_shift, r->gain, r->screen_eps, r->stream);
         else if (r->fmt == LLZ_PCM_I16)
             rc = llzs_resample_i16((const short *)d_in, (short *)d_out, (const short *)hist,
                                    (const double *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->L, r->M,

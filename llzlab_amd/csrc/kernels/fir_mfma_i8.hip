@@ -31,7 +31,7 @@
 // owns 16 consecutive 16-output segments of a channel, D[m][n] = sum_t A[m][t] B[t][n] with A[m][t] = G[mM + tpad - t],
 // B[t][n] = sample t of segment n's window; persistent workgroups walk tiles, the next tile's samples prefetched into
 // registers), with 64 window samples per MFMA step and one-byte planes in LDS.
-#include "common.hpp"
+#include "screen_i8.hpp"
 #include <math.h>
 #include <type_traits>
 #include <stdlib.h>
@@ -90,39 +90,6 @@ __device__ __forceinline__ short mx_exact(const signed char *hi, const signed ch
     return (short)y;                                // :601, toward zero
 }
 
-// One output from its five accumulators, in exact 32-bit integer arithmetic (|acc| <= 2 T 2^14 < 2^22.7 for T <= 200):
-//   T' = a0 + 2^8 a1 + 2^16 a2 + 2^24 a3 + 2^32 a4 + Bq  as a 64-bit pair (hi, lo) with explicit carries;
-//   I = floor(T' / 2^(32 + rs)), F = the top 32 bits of the fraction below it.
-// Returns the reference's int16 when no integer lies within eps of the value (fraction outside [-e32, e32] of a step), and
-// sets `unsure` otherwise.  NEG selects rs < 0 (the handle's shift below 40).
-template <bool NEG>
-__device__ __forceinline__ int mx_decide(int a0, int a1, int a2, int a3, int a4, const mx_params &pr, int &I_out, bool &unsure)
-{
-    const int p = a0 + (a1 << 8);
-    const int q = a2 + (a3 << 8);
-    // T' = (p + Bq) + q 2^16 + a4 2^32 as two add-with-carry pairs (q 2^16 = (q >> 16) 2^32 + (q << 16) mod 2^32)
-    unsigned c1, c2;
-    const unsigned lo_w = __builtin_addc((unsigned)p, (unsigned)pr.bq_lo, 0u, &c1);
-    const unsigned hi_w = (unsigned)(p >> 31) + (unsigned)pr.bq_hi + c1;
-    const unsigned lo = __builtin_addc(lo_w, (unsigned)q << 16, 0u, &c2);
-    const int hi = (int)(hi_w + (unsigned)((q >> 16) + a4) + c2);
-    int I;
-    unsigned F;
-    if (NEG) {
-        I = (int)__builtin_amdgcn_alignbit((unsigned)hi, lo, (unsigned)(32 + pr.rs));
-        F = lo << (-pr.rs);
-    } else {
-        I = hi >> pr.rs;
-        F = __builtin_amdgcn_alignbit((unsigned)hi, lo, (unsigned)pr.rs);
-    }
-    unsure = F + pr.e32 <= 2u * pr.e32;                         // wrapping: the fraction is within e32 of 0 or of 1
-    I_out = I;
-    int t = I + (int)((unsigned)I >> 31);                       // toward zero: the value is not an integer here
-    t = t > 32767 ? 32767 : t;
-    t = t < -32768 ? -32768 : t;
-    return t;
-}
-
 // The sample prefetch is issued and awaited by hand.  Left to the compiler, every use of a prefetched register was preceded
 // by s_waitcnt vmcnt(0): that also waits for the previous tile's output STORES, once per tile.  Vector-memory operations
 // complete in issue order per wave, so a request issued `young` operations ago is complete once at most `young` operations
@@ -154,12 +121,8 @@ __device__ __forceinline__ void mx_pin(i16x8 (&v)[NV])
         asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
 }
 
-// lane n of a 16-lane row takes segment mx_seg(n) of the wave's 16, and quarter kq of the lanes takes the 16-byte chunk
-// mx_chunk(kq) of a 64-sample step: with an odd decimation M the sixteen lanes a ds_read_b128 serves together
-// ({0-3, 12-15} of one quarter with {4-11} of its neighbour) then read sixteen different 16-byte bank groups
-// (chunk index M seg + chunk: odd segments against even segments + 2) -- the natural order collides two by two
-__device__ __forceinline__ int mx_seg(int n) { return n < 4 ? 2 * n + 1 : (n < 12 ? 2 * (n - 4) : 2 * (n - 12) + 9); }
-__host__ __device__ __forceinline__ int mx_chunk(int kq) { return ((kq & 1) << 1) | (kq >> 1); }
+__device__ __forceinline__ int mx_seg(int n) { return scr_col(n); }          // (screen_i8.hpp: why this order)
+__host__ __device__ __forceinline__ int mx_chunk(int kq) { return scr_chunk(kq); }
 
 template <int NACC, int NV, bool NEG>
 __global__ void __launch_bounds__(MX_THREADS)
@@ -282,7 +245,7 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
             const int oo = ((wave * NACC + a) * 16 + seg) * 16 + 4 * kq;        // first of this lane's 4 outputs of block a
             i16x4 y;
 #pragma unroll
-            for (int j = 0; j < 4; j++) y[j] = (short)r4[j];
+            for (int j = 0; j < 4; j++) y[j] = scr_clamp(r4[j]);
             if (whole) {
                 *reinterpret_cast<i16x4 *>(otile + oo) = y;
             } else {
@@ -339,9 +302,9 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         for (int a = 0; a < NACC; a++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                int I;
                 bool unsure;
-                res[a][j] = mx_decide<NEG>(acc[a][0][j], acc[a][1][j], acc[a][2][j], acc[a][3][j], acc[a][4][j], pr, I, unsure);
+                res[a][j] = scr_decide<NEG>(acc[a][0][j], acc[a][1][j], acc[a][2][j], acc[a][3][j], acc[a][4][j], pr.bq_lo, pr.bq_hi,
+                                            pr.rs, pr.e32, unsure);
                 mine = mine + mine + (unsure ? 1u : 0u);            // slot 4 a + j ends up at bit 4 NACC - 1 - (4 a + j)
             }
         if (__ballot(mine != 0) != 0) {
@@ -357,7 +320,7 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
 #pragma unroll
                     for (int j = 0; j < 4; j++) cur = slot == 4 * a + j ? res[a][j] : cur;
                 // (a value far outside the clamp range needs no second look: its int16 is the rail either way)
-                if (o0 + oo < n_out && (unsigned)(cur + 32767) <= 65533u) {
+                if (o0 + oo < n_out && scr_in_reach(cur)) {
                     const int r = mx_exact(xs_hi, xs_lo, oo * sh.M + sh.tpad, gd_lds, sh.T, pr.gain);
 #pragma unroll
                     for (int a = 0; a < NACC; a++)

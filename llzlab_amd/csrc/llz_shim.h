@@ -198,6 +198,15 @@ int llzs_resample_dec_f32_fits(int M, int tp);     /* 1 when the fast path's LDS
 int llzs_resample_i16(const short *in, short *out, const short *hist, const double *g,
                       int channels, long n_in, long n_out, long in_pitch, long out_pitch,
                       int L, int M, int Q, double gain, long long i0, long long in0, void *stream);
+/* the same bit-exact int16 result for L >= 2, screened on the int8 matrix cores per phase (resample_i8.hip): atab [ceil(L/16)]
+ * [steps][5][64][16] tap digits in operand order (steps = llzs_resample_i16x_ksteps), aoff [ceil(L/16)] band starts, bqtab
+ * [16 ceil(L/16)][2] = floor(128 sum_k G_f[k] / 256) as (lo, hi), g the L x Q double taps, eps the largest per-phase bound.
+ * The call must start on a period boundary (input index % M == 0, output index % L == 0). */
+int llzs_resample_i16x(const short *in, short *out, const short *hist, const signed char *atab, const int *aoff,
+                       const int *bqtab, const double *g, int channels, long n_in, long n_out, long in_pitch, long out_pitch,
+                       int L, int M, int Q, int shift, double gain, double eps, void *stream);
+int llzs_resample_i16x_fits(int L, int M, int Q);
+int llzs_resample_i16x_ksteps(int L, int M, int Q);
 int llzs_tail_i16(const short *in, const short *hist_old, short *hist_new, int channels, long n, long in_pitch,
                   int keep, void *stream);
 /* llz_decimate (forward indexed polyphase sum over a history of n samples) and llz_interp (no history),

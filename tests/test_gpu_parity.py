@@ -1601,3 +1601,44 @@ def test_resample_i16_screened_large_batch(dev, oracle):
     ref = oracle.rs_batch_i16(x[sel].cpu().numpy(), 1, 3, 1.0, po.BLACKMAN)
     assert np.array_equal(y[sel].cpu().numpy(), ref)
     r.close()
+
+
+# ------------------------------------------------------------------------------------------------ int16 L/M resampler, screened per phase
+@pytest.mark.parametrize("L,M,win,gain", [(147, 160, po.BLACKMAN, 1.0), (160, 147, po.BLACKMAN, 1.0), (2, 3, po.HAMMING, 1.0),
+                                          (3, 2, po.KAISER, 1.0), (20, 147, po.BLACKMAN, 1.0), (147, 160, po.HAMMING, 2.5),
+                                          (160, 147, po.KAISER, 0.37), (7, 5, po.BLACKMAN, 1e-3)])
+def test_resample_i16_lm_screened_is_bit_exact(dev, oracle, L, M, win, gain):
+    """LLZ_PCM_I16 with L >= 2 runs the per-phase integer screen on the matrix cores (resample_i8.hip: the reference CLI's own
+    ratios 147:160 and 160:147 among them) and recomputes in the reference's double order only the outputs the screen cannot
+    decide.  Bit-exact against the oracle's llz_resample loop on random PCM, full-scale PCM on the clamp rails, digital silence,
+    DC (outputs ON truncation edges), silence -> signal inside a span, both rails and an alternating signal; streamed over two
+    calls (history in front of the second); and identical to the all-double kernel."""
+    info = oracle.rs_info(2, L, M, gain, win)
+    nin1 = info["bytes_in"] // 2
+    frames = max(2, min(12, 60000 // nin1))
+    nin = nin1 * frames
+    ch = 9
+    x = oracle.synth_i16(ch, nin, seed=L * 7 + M)
+    x[1] = (x[1].astype(np.int32) * 2).clip(-32768, 32767).astype(np.int16)     # clipping rails
+    x[2] = 0                                                                    # digital silence
+    x[3] = 12345                                                                # DC
+    x[4, : nin // 2] = 0                                                        # silence, then signal
+    x[5] = -32768
+    x[6] = 32767
+    x[7] = np.where(np.arange(nin) % 2 == 0, 1, -1) * 20000                     # alternating
+    ref = oracle.rs_batch_i16(x, L, M, gain, win)
+    outs, outs_plain = [], []
+    cut = (frames // 2) * nin1                                                  # whole reference frames: a period boundary
+    for tuned, dst in (({}, outs), ({"rs_i16_path": 1}, outs_plain)):
+        with capi.tuned(**tuned):
+            r = filters.ResampleMC(ch, L, M, gain, win, filters.PCM_I16)
+            for (o, e) in ((0, cut), (cut, nin)):
+                xi = torch.from_numpy(np.ascontiguousarray(x[:, o:e])).to(dev)
+                yi = torch.empty(ch, (e - o) // M * L, dtype=torch.int16, device=dev)
+                assert r.process(xi, yi) == yi.shape[1]
+                dst.append(yi.cpu().numpy())
+            r.close()
+    got, plain = np.concatenate(outs, axis=1), np.concatenate(outs_plain, axis=1)
+    assert np.array_equal(plain, ref), "all-double kernel vs oracle"
+    bad = np.argwhere(got != ref)
+    assert bad.size == 0, (L, M, len(bad), bad[:5].tolist(), got[tuple(bad[0])], ref[tuple(bad[0])])
