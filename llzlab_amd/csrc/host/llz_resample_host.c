@@ -269,7 +269,7 @@ typedef struct {
     int use_screen_lm;
     signed char *d_scr_atab;    /* [ceil(L/16)][steps][5][64][16] tap digits in matrix-core operand order */
     int *d_scr_aoff;            /* [ceil(L/16)] band starts */
-    int *d_scr_bq;              /* [16 ceil(L/16)][2] per-phase bias */
+    int *d_scr_bq;              /* [16 ceil(L/16)][4] per phase: bias (lo, hi), e32, exact flag */
     /* F32, L >= 5: the banded tap matrix in matrix-core operand order (resample_mfma.hip) */
     float *d_band;
     int *d_band_c0;
@@ -365,7 +365,7 @@ static int rsm_build_screen(rsm_t *r)
 /* The same screen for L >= 2 (resample_i8.hip): one tap row per phase f, g_f[k] = taps.mat[f][k]; ONE shift for all rows (from
  * the largest |gain g|), per-row digits, bias and error bound (the formulas of rsm_build_screen with the row's own sums), eps =
  * the largest row bound.  The digits go straight into matrix-core operand order: phase tile t = phases 16 t .. 16 t + 15; its
- * band starts at window position a_t = (c_{16t} + Hp - (Q-1)) & ~15 (Hp = Q-1 rounded up to 8, the position of a period's own
+ * band starts at window position a_t = c_{16t} + Hp - (Q-1) (Hp = Q-1 rounded up to 8, the position of a period's own
  * first sample; c_f = (f M) / L); lane (r = lane % 16, kq = lane / 16) of step s and digit plane p holds, in byte j, digit p of
  * the tap of phase f = 16 t + r that multiplies window position pos = a_t + 64 s + 16 chunk(kq) + j, i.e. tap k = c_f + Hp - pos
  * (chunk(kq) = ((kq & 1) << 1) | (kq >> 1): kernels/screen_i8.hpp). */
@@ -397,22 +397,29 @@ static int rsm_build_screen_lm(rsm_t *r)
     const size_t abytes = (size_t)nt * steps * 5 * 1024;
     signed char *atab = (signed char *)calloc(abytes, 1);
     signed char *dig = (signed char *)malloc((size_t)5 * Q);
-    int *aoff = (int *)calloc((size_t)nt, sizeof(int)), *bq = (int *)calloc((size_t)nt * 32, sizeof(int));
+    int *aoff = (int *)calloc((size_t)nt, sizeof(int)), *bq = (int *)calloc((size_t)nt * 64, sizeof(int));
     int ok = atab && dig && aoff && bq;
     double eps = 0.0;
     for (int f = 0; ok && f < L; f++) {
         const double *g = r->taps.mat + (size_t)f * Q;
         const int t = f / 16, row = f % 16, cf = (int)(((long)f * M) / L);
-        const int a_t = (int)((((long)16 * t * M) / L) + Hp - (Q - 1)) & ~15;
+        const int a_t = (int)(((long)16 * t * M) / L) + Hp - (Q - 1);
         aoff[t] = a_t;
         long long sumG = 0, sum_d0 = 0;
         double qerr = 0.0, sumabs = 0.0;
+        int nonzero = 0, unit = 0, kfirst = Q - 1, klast = 0;
         for (int k = 0; k < Q; k++) {
             const double gk = g[k] * gain;
             long long G = llround(ldexp(gk, shift));
             qerr += fabs(gk - ldexp((double)G, -shift));
             sumabs += fabs(gk);
             sumG += G;
+            nonzero += g[k] != 0.0;
+            unit += g[k] == 1.0;
+            if (g[k] != 0.0) {
+                if (k < kfirst) kfirst = k;
+                if (k > klast) klast = k;
+            }
             for (int p = 0; p < 5; p++) {
                 const int d = (int)(((G + 128) & 255) - 128);
                 dig[(size_t)p * Q + k] = (signed char)d;
@@ -425,8 +432,16 @@ static int rsm_build_screen_lm(rsm_t *r)
                          ldexp(128.0 * (double)sum_d0 + 256.0, -shift);
         if (e > eps) eps = e;
         const long long bias = 128 * sumG, bqv = bias >= 0 ? bias / 256 : -((-bias + 255) / 256);      /* floor(bias / 256) */
-        bq[2 * f] = (int)(unsigned)((unsigned long long)bqv & 0xffffffffull);
-        bq[2 * f + 1] = (int)(bqv >> 32);
+        bq[4 * f] = (int)(unsigned)((unsigned long long)bqv & 0xffffffffull);
+        bq[4 * f + 1] = (int)(bqv >> 32);
+        bq[4 * f + 2] = (int)((unsigned)ceil(ldexp(e, 32)) + 2u);
+        /* a phase whose only non-zero tap is exactly 1.0, at gain 1.0 (phase 0 whenever fc = 1/L: the windowed sinc is zero at
+         * the other multiples of L): the reference's y is the sample itself, an integer, and so is the screen's value -- bit
+         * for bit (G = 2^shift, every digit product exact, lowest digit and bias remainder zero).  Every such output would
+         * otherwise take the recompute path: one lane row in 16 of that phase tile, 47 double steps each. */
+        if (nonzero == 0) kfirst = klast = 0;
+        /* (the recompute path runs taps kfirst .. klast only: zero taps in front and behind add +-0 to the reference's sum) */
+        bq[4 * f + 3] = kfirst | (klast << 8) | ((nonzero == 1 && unit == 1 && gain == 1.0) ? 1 << 16 : 0);
         for (int s = 0; s < steps; s++)
             for (int kq = 0; kq < 4; kq++)
                 for (int j = 0; j < 16; j++) {
@@ -440,10 +455,10 @@ static int rsm_build_screen_lm(rsm_t *r)
     if (ok && eps < 0.0625) {
         if (!r->d_scr_atab) r->d_scr_atab = (signed char *)llzs_malloc(abytes);
         if (!r->d_scr_aoff) r->d_scr_aoff = (int *)llzs_malloc(sizeof(int) * (size_t)nt);
-        if (!r->d_scr_bq) r->d_scr_bq = (int *)llzs_malloc(sizeof(int) * (size_t)nt * 32);
+        if (!r->d_scr_bq) r->d_scr_bq = (int *)llzs_malloc(sizeof(int) * (size_t)nt * 64);
         ok = r->d_scr_atab && r->d_scr_aoff && r->d_scr_bq && llzs_h2d_table(r->d_scr_atab, atab, abytes) == LLZ_OK &&
              llzs_h2d_table(r->d_scr_aoff, aoff, sizeof(int) * (size_t)nt) == LLZ_OK &&
-             llzs_h2d_table(r->d_scr_bq, bq, sizeof(int) * (size_t)nt * 32) == LLZ_OK;
+             llzs_h2d_table(r->d_scr_bq, bq, sizeof(int) * (size_t)nt * 64) == LLZ_OK;
     } else {
         ok = 0;
     }

@@ -12,13 +12,16 @@
 //
 // Mapping.  For ONE period every phase reads inside the same window of the input, and the taps do not depend on the period:
 // Y[f][m] = sum_u W[f][u] X[u][m] with a FIXED banded matrix.  A tile is 16 phases x 16 periods: D[r][n] = output (phase 16 t + r,
-// period n).  The band of a phase tile starts at window position a_t (aligned down to 16 bytes) and is walked 64 samples per
-// step; A (the tile's tap digits, [step][plane] in operand order, built on the host) stays in the wave's registers while it
-// walks the period tiles of a span.  The LDS image holds one COLUMN per period: the period's whole window as two byte planes
-// (low digit (x & 255) - 128, high digit x >> 8), column stride an odd number of 16-byte chunks, so that a B operand is one
-// aligned ds_read_b128 at column base + a_t + 64 s + 16 chunk(kq), conflict-free (screen_i8.hpp).  Neighbouring columns
-// overlap (a sample is stored in every column whose window holds it: ~1.7 copies at 147:160).  Results go to an LDS image of
-// the output in memory order and leave in 8-byte pieces; the next span's samples are requested one span ahead into registers.
+// period n).  The band of a phase tile starts at window position a_t = c_{16t} + Hp - (Q-1) (Hp = Q-1 rounded up to 8 = the
+// position of a period's own first sample) and is walked 64 samples per step -- ONE step at 147:160 and 160:147, where 16
+// phases drift by at most 17 samples and Q = 47; A (the tile's tap digits, [step][plane] in operand order, built on the host)
+// stays in the wave's registers while it walks the period tiles of a span.  The LDS image is the span's samples as two
+// CONTIGUOUS byte planes (low digit (x & 255) - 128, high digit x >> 8; written 8 samples at a time): period n's window starts
+// M n bytes into a plane, so a B operand is ONE ds_read_b128 at an arbitrary byte address -- unaligned 16-byte LDS reads are
+// legal on gfx950 (it is what hipcc itself emits for an under-aligned load), and no second copy of any sample is needed (a
+// first version kept one aligned column per period: 1.7 copies of every sample, byte stores when M is odd -- 3.6 ms against
+// 1.2 ms at 160:147 / 147:160).  Results go to an LDS image of the output in memory order and leave in 8-byte pieces; the next
+// span's samples are requested one span ahead into registers.
 #include "screen_i8.hpp"
 #include <math.h>
 
@@ -34,28 +37,27 @@ constexpr int RI_NG = 4;                    // 16-byte sample groups a thread ho
 struct ri_shape {
     int L, M, Q, nt;        // nt = ceil(L / 16) phase tiles
     int Hp;                 // window position of the period's own first sample (u = 0): Q - 1 rounded up to 8
-    int clen;               // window positions a column holds (bytes per plane actually used)
-    int cstride;            // bytes between columns of a plane: >= clen, an odd multiple of 16
     int pt, P;              // period tiles per span, periods per span = 16 pt
-    int count;              // samples a span touches: M (P - 1) + clen
-    int plane;              // bytes per plane: P cstride
-    int ngroups;            // 16-byte groups per span (count + 7 alignment slack, / 8, rounded up)
-    unsigned m_magic;       // ceil(2^32 / M)
+    int plane;              // bytes per plane (multiple of 16): 8 ngroups
+    int ngroups;            // 16-byte sample groups per span
     long spans;             // spans of a channel
     int spans_per_wg;
     int rs;                 // shift - 40
-    unsigned e32;
     double gain;
 };
 
-// the reference's loop for one output from the column's planes: sample at window position p is 256 hi[p] + lo[p] + 128
-__device__ __forceinline__ short ri_exact(const signed char *hi, const signed char *lo, int p0, const double *__restrict__ g, int Q,
-                                          double gain)
+struct __attribute__((packed, aligned(1))) ri_b128 { scr_i32x4 v; };      // a 16-byte LDS read at any byte address
+
+// the reference's loop for one output from the planes: the sample at image position p is 256 hi[p] + lo[p] + 128
+// (taps k < k0 and k > k1 are zero: adding x * 0 = +-0 to the running sum changes nothing, bit for bit -- phase 0 of an
+//  interpolating ratio has ONE non-zero tap, and every output of it lands within 1e-12 of an integer)
+__device__ __forceinline__ short ri_exact(const signed char *hi, const signed char *lo, int p0, const double *__restrict__ g, int k0,
+                                          int k1, double gain)
 {
 #pragma clang fp contract(off)
     double y = 0.0;
 #pragma unroll 1
-    for (int k = 0; k < Q; k++) {
+    for (int k = k0; k <= k1; k++) {
         const int xv = 256 * (int)hi[p0 - k] + (int)lo[p0 - k] + 128;
         const double prod = (double)xv * g[k];
         y = y + prod;
@@ -70,7 +72,7 @@ template <int KS, bool NEG, bool RELOAD>
 __global__ void __launch_bounds__(512)
 k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const short *__restrict__ hist,
                const signed char *__restrict__ atab /* [nt][KS][5][64][16] */, const int *__restrict__ aoff /* [nt] */,
-               const int *__restrict__ bqtab /* [16 nt][2] */, const double *__restrict__ g /* [L][Q] */, long n_in, long n_out,
+               const int *__restrict__ bqtab /* [16 nt][4]: bias lo, hi; e32; first | last << 8 non-zero tap | exact << 16 */, const double *__restrict__ g /* [L][Q] */, long n_in, long n_out,
                long in_pitch, long out_pitch, ri_shape sh)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -87,10 +89,8 @@ k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
     short *orow = out + (size_t)c * out_pitch;
     const bool vec_in = (in_pitch & 7) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
     const bool vec_out = (out_pitch & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0;
-    const bool m8 = (sh.M & 7) == 0;
 
-    // a span's samples: absolute indices [M m0 - Hp, M m0 - Hp + count), requested in 16-byte groups from the 8-aligned index
-    // at or below the start
+    // a span's samples: from absolute index M m0 - Hp on, requested in 16-byte groups starting at the 8-aligned index at or below it
     i16x8 v[RI_NG];
     auto request = [&](long m0s) {
         const long s0 = m0s * sh.M - sh.Hp;
@@ -145,8 +145,10 @@ k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
     for (long sp = span0; sp < span1; sp++) {
         const long m0 = sp * P;
         const long s0 = m0 * sh.M - sh.Hp;
-        const int lead = (int)(s0 - (s0 >= 0 ? (s0 & ~7L) : -((-s0 + 7) & ~7L)));        // samples of the first group in front of s0
-        // ---- the requested groups into the column image (the previous span's readers passed the barrier at its end) ----
+        // the image starts at the 8-aligned sample index at or below s0: window position pos of period q sits `lead + M q + pos`
+        // bytes into a plane
+        const int lead = (int)(s0 - (s0 >= 0 ? (s0 & ~7L) : -((-s0 + 7) & ~7L)));
+        // ---- the requested groups into the planes (the previous span's readers passed the barrier at its end) ----
 #pragma unroll
         for (int k = 0; k < RI_NG; k++) {
             const int gi = k * threads + tid;
@@ -157,36 +159,8 @@ k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
                 lo[1] = __builtin_amdgcn_perm(d[3], d[2], 0x06040200u) ^ 0x80808080u;
                 hi[0] = __builtin_amdgcn_perm(d[1], d[0], 0x07050301u);
                 hi[1] = __builtin_amdgcn_perm(d[3], d[2], 0x07050301u);
-                const int e0 = 8 * gi - lead;                                   // span-relative index of the group's first sample
-                if (m8) {
-                    // M, Hp and the group starts are multiples of 8: a group stays together in every column that holds it
-                    if (e0 >= 0 && e0 < sh.count) {
-                        int q = (int)__umulhi((unsigned)e0, sh.m_magic);
-                        int pos = e0 - q * sh.M;
-                        for (; q >= 0 && pos < sh.clen; q--, pos += sh.M)
-                            if (q < P) {
-                                *reinterpret_cast<u32x2 *>(&xs_lo[q * sh.cstride + pos]) = lo;
-                                *reinterpret_cast<u32x2 *>(&xs_hi[q * sh.cstride + pos]) = hi;
-                            }
-                    }
-                } else {
-#pragma unroll 1
-                    for (int e = 0; e < 8; e++) {
-                        const int ee = e0 + e;
-                        if (ee >= 0 && ee < sh.count) {
-                            const int sft = 8 * (e & 3);
-                            const signed char bl = (signed char)((e < 4 ? lo[0] : lo[1]) >> sft);
-                            const signed char bh = (signed char)((e < 4 ? hi[0] : hi[1]) >> sft);
-                            int q = (int)__umulhi((unsigned)ee, sh.m_magic);
-                            int pos = ee - q * sh.M;
-                            for (; q >= 0 && pos < sh.clen; q--, pos += sh.M)
-                                if (q < P) {
-                                    xs_lo[q * sh.cstride + pos] = bl;
-                                    xs_hi[q * sh.cstride + pos] = bh;
-                                }
-                        }
-                    }
-                }
+                *reinterpret_cast<u32x2 *>(&xs_lo[8 * gi]) = lo;
+                *reinterpret_cast<u32x2 *>(&xs_hi[8 * gi]) = hi;
             }
         }
         if (sp + 1 < span1) request(m0 + P);
@@ -199,20 +173,26 @@ k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
             const int a_t = aoff[t];
             const int f0 = 16 * t + 4 * kq;                                       // the lane's first phase (row 4 kq) of the tile
             int bql[4], bqh[4];
+            unsigned e32[4], never = 0;                                            // never: slots of phases that cannot be unsure
+            int krange[4];                                                         // first | last << 8 non-zero tap of the phase
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                bql[j] = bqtab[2 * (f0 + j)];
-                bqh[j] = bqtab[2 * (f0 + j) + 1];
+                const scr_i32x4 row4 = *reinterpret_cast<const scr_i32x4 *>(bqtab + 4 * (f0 + j));
+                bql[j] = row4[0];
+                bqh[j] = row4[1];
+                e32[j] = (unsigned)row4[2];
+                krange[j] = row4[3] & 0xffff;
+                never |= (row4[3] >> 16) ? 1u << (3 - j) : 0u;
             }
 #pragma unroll 1
             for (int p = 0; p < sh.pt; p++) {
                 const int col = 16 * p + col16;
-                const signed char *bp = xs_lo + col * sh.cstride + a_t + 16 * ck;
+                const signed char *bp = xs_lo + lead + col * sh.M + a_t + 16 * ck;
                 scr_i32x4 acc[5];
 #pragma unroll
                 for (int s = 0; s < KS; s++) {
-                    const scr_i32x4 b_lo = *reinterpret_cast<const scr_i32x4 *>(bp + 64 * s);
-                    const scr_i32x4 b_hi = *reinterpret_cast<const scr_i32x4 *>(bp + sh.plane + 64 * s);
+                    const scr_i32x4 b_lo = reinterpret_cast<const ri_b128 *>(bp + 64 * s)->v;
+                    const scr_i32x4 b_hi = reinterpret_cast<const ri_b128 *>(bp + sh.plane + 64 * s)->v;
                     if (s == 0) scr_step<true>(acc, ad[s], b_lo, b_hi);
                     else scr_step<false>(acc, ad[s], b_lo, b_hi);
                 }
@@ -221,10 +201,11 @@ k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     bool unsure;
-                    res[j] = scr_decide<NEG>(acc[0][j], acc[1][j], acc[2][j], acc[3][j], acc[4][j], bql[j], bqh[j], sh.rs, sh.e32,
-                                             unsure);
+                    res[j] = scr_decide<NEG>(acc[0][j], acc[1][j], acc[2][j], acc[3][j], acc[4][j], bql[j], bqh[j], sh.rs, e32[j],
+                                             unsure, (never >> (3 - j)) & 1);
                     mine = mine + mine + (unsure ? 1u : 0u);                      // slot j at bit 3 - j
                 }
+                mine &= ~never;
                 if (__ballot(mine != 0) != 0) {
 #pragma unroll 1
                     while (mine != 0) {
@@ -232,14 +213,17 @@ k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
                         const int j = 3 - __builtin_ctz(mine);
                         mine &= mine - 1;
                         const int f = f0 + j;
-                        int cur = 0;
+                        int cur = 0, kr = 0;
 #pragma unroll
-                        for (int u = 0; u < 4; u++) cur = j == u ? res[u] : cur;
+                        for (int u = 0; u < 4; u++) {
+                            cur = j == u ? res[u] : cur;
+                            kr = j == u ? krange[u] : kr;
+                        }
                         // (a value far outside the clamp range needs no second look, nor does a row or period that does not exist)
                         if (f < sh.L && col < periods_left && scr_in_reach(cur)) {
                             const int cf = (int)(((long)f * sh.M) / sh.L);
-                            const int r = ri_exact(xs_hi + col * sh.cstride, xs_lo + col * sh.cstride, cf + sh.Hp, g + (size_t)f * sh.Q,
-                                                   sh.Q, sh.gain);
+                            const int r = ri_exact(xs_hi, xs_lo, lead + col * sh.M + cf + sh.Hp, g + (size_t)f * sh.Q, kr & 255, kr >> 8,
+                                                   sh.gain);
 #pragma unroll
                             for (int u = 0; u < 4; u++) res[u] = j == u ? r : res[u];
                         }
@@ -270,54 +254,49 @@ k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
     }
 }
 
-int ri_ksteps(int L, int M, int Q, int *clen_out)
+// steps of 64 window samples the widest band needs: the band of tile t spans positions a_t .. c_{last phase} + Hp
+int ri_ksteps(int L, int M, int Q)
 {
-    const int Hp = (Q - 1 + 7) & ~7, nt = (L + 15) / 16;
-    int ks = 1, amax = 0;
+    const int nt = (L + 15) / 16;
+    int ks = 1;
     for (int t = 0; t < nt; t++) {
         const int flast = 16 * t + 15 < L ? 16 * t + 15 : L - 1;
-        const int a = (int)(((long)16 * t * M) / L + Hp - (Q - 1)) & ~15;
-        const int top = (int)(((long)flast * M) / L) + Hp;                    // highest position the tile reads (k = 0)
-        const int need = (top - a + 1 + 63) / 64;
+        const int width = (int)(((long)flast * M) / L - ((long)16 * t * M) / L) + Q;
+        const int need = (width + 63) / 64;
         if (need > ks) ks = need;
-        if (a > amax) amax = a;
     }
-    if (clen_out) *clen_out = amax + 64 * ks;
     return ks;
 }
 
 } // namespace
 
-extern "C" int llzs_resample_i16x_ksteps(int L, int M, int Q) { return ri_ksteps(L, M, Q, nullptr); }
+extern "C" int llzs_resample_i16x_ksteps(int L, int M, int Q) { return ri_ksteps(L, M, Q); }
 
-// geometry of the launch (also used by the host to size nothing: all tables depend on L, M, Q only)
+// geometry of the launch
 static bool ri_make_shape(int L, int M, int Q, long n_out, int channels, ri_shape *sh, int *waves, size_t *lds)
 {
     sh->L = L; sh->M = M; sh->Q = Q;
     sh->nt = (L + 15) / 16;
     sh->Hp = (Q - 1 + 7) & ~7;
-    const int ks = ri_ksteps(L, M, Q, &sh->clen);
+    const int ks = ri_ksteps(L, M, Q);
     if (ks > 4) return false;
-    int chunks = (sh->clen + 15) / 16;
-    if ((chunks & 1) == 0) chunks++;
-    sh->cstride = 16 * chunks;
     // waves: the phase tiles dealt evenly over at most 8 waves (147 phases: 10 tiles -> 5 waves x 2 tiles)
     const int rounds = (sh->nt + 7) / 8;
     int w = (sh->nt + rounds - 1) / rounds;
     if (w < 2) w = 2;
     *waves = w;
-    for (int pt = 4; pt >= 1; pt--) {
+    bool ok = false;
+    for (int pt = 4; pt >= 1 && !ok; pt--) {
         sh->pt = pt; sh->P = 16 * pt;
-        sh->plane = sh->P * sh->cstride;
-        sh->count = M * (sh->P - 1) + sh->clen;
-        sh->ngroups = (sh->count + 7 + 7) / 8;
+        // the last period's last band ends at most M - 1 + Hp + 64 ks positions into its window; + 7 of alignment slack in front
+        const long bytes = 7 + (long)M * (sh->P - 1) + (M - 1) + sh->Hp + 64 * ks + 16;
+        sh->ngroups = (int)((bytes + 7) / 8);
+        sh->plane = (8 * sh->ngroups + 15) & ~15;
         *lds = 2 * (size_t)sh->plane + sizeof(short) * (size_t)sh->P * L;
         while (*waves < 8 && sh->ngroups > RI_NG * 64 * *waves) (*waves)++;
-        if (*lds <= 52 * 1024 && sh->ngroups <= RI_NG * 64 * *waves) break;
-        if (pt == 1) return *lds <= 160 * 1024 && sh->ngroups <= RI_NG * 64 * *waves;
+        ok = sh->ngroups <= RI_NG * 64 * *waves && (*lds <= 40 * 1024 || (pt == 1 && *lds <= 160 * 1024));
     }
-    sh->m_magic = (unsigned)((0x100000000ull + (unsigned)M - 1) / (unsigned)M);
-    if ((unsigned long long)sh->count >= 0x100000000ull / (unsigned)M) return false;
+    if (!ok) return false;
     const long periods = (n_out + L - 1) / L;
     sh->spans = (periods + sh->P - 1) / sh->P;
     // consecutive spans per workgroup: the walk length that minimises rounds x (length + 1) over ~3 resident workgroups per CU
@@ -341,8 +320,11 @@ extern "C" int llzs_resample_i16x_fits(int L, int M, int Q)
     return ri_make_shape(L, M, Q, L, 1, &sh, &waves, &lds) ? 1 : 0;
 }
 
-// atab: [ceil(L/16)][ksteps][5][64][16] tap digits in operand order; aoff: [ceil(L/16)] band starts; bqtab: [16 ceil(L/16)][2]
-// floor(128 sum_k G_f[k] / 256) as (lo, hi); g: the L x Q double taps; shift / eps as in llzs_fir_mfma_i16x.  The call must
+// atab: [ceil(L/16)][ksteps][5][64][16] tap digits in operand order; aoff: [ceil(L/16)] band starts; bqtab: [16 ceil(L/16)][4]
+// per phase: floor(128 sum_k G_f[k] / 256) as (lo, hi), e32 = ceil(eps_f 2^32) + 2, and first | last << 8 non-zero tap | flag << 16
+// with flag = 1 when the phase's outputs are exact integers the screen itself reproduces (a single tap 1.0 at gain 1.0: no
+// second look); g: the L x Q double taps; shift as
+// in llzs_fir_mfma_i16x; eps = the largest per-phase bound (checked only).  The call must
 // start on a period boundary (input index % M == 0, output index % L == 0).
 extern "C" int llzs_resample_i16x(const short *in, short *out, const short *hist, const signed char *atab, const int *aoff,
                                   const int *bqtab, const double *g, int channels, long n_in, long n_out, long in_pitch,
@@ -358,9 +340,8 @@ extern "C" int llzs_resample_i16x(const short *in, short *out, const short *hist
         return LLZ_ERR_ARG;
     }
     sh.rs = shift - 40;
-    sh.e32 = (unsigned)ceil(ldexp(eps, 32)) + 2u;
     sh.gain = gain;
-    const int ks = ri_ksteps(L, M, Q, nullptr);
+    const int ks = ri_ksteps(L, M, Q);
     const bool neg = sh.rs < 0, reload = sh.nt > waves;
     const dim3 grid((unsigned)((sh.spans + sh.spans_per_wg - 1) / sh.spans_per_wg), (unsigned)channels), block(64 * waves);
 #define RI_GO3(K, N, R)                                                                                               \

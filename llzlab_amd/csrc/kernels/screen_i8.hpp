@@ -22,7 +22,7 @@ __host__ __device__ __forceinline__ int scr_chunk(int kq) { return ((kq & 1) << 
 // no integer lies within eps of the value -- F farther than e32 from both ends -- and sets `unsure` otherwise.  NEG selects rs < 0.  rs in [-8, 6]; e32 = ceil(eps 2^32) + 2.
 template <bool NEG>
 __device__ __forceinline__ int scr_decide(int a0, int a1, int a2, int a3, int a4, int bq_lo, int bq_hi, int rs, unsigned e32,
-                                          bool &unsure)
+                                          bool &unsure, bool integer_valued = false)
 {
     const int p = a0 + (a1 << 8);
     const int q = a2 + (a3 << 8);
@@ -42,7 +42,8 @@ __device__ __forceinline__ int scr_decide(int a0, int a1, int a2, int a3, int a4
         F = __builtin_amdgcn_alignbit((unsigned)hi, lo, (unsigned)rs);
     }
     unsure = F + e32 <= 2u * e32;                               // wrapping: the fraction is within e32 of 0 or of 1
-    return I + (int)((unsigned)I >> 31);                        // toward zero: the value is not an integer here
+    // toward zero: the value is not an integer here (unless the caller knows the output IS one: then it is I itself)
+    return integer_valued ? I : I + (int)((unsigned)I >> 31);
 }
 
 // the reference's clamp (llz_resample.c:596-599) on the truncated value

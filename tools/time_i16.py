@@ -20,11 +20,11 @@ x = torch.empty(ch, n, dtype=torch.int16, device=dev)
 y = torch.empty(ch, n * L_ // M_, dtype=torch.int16, device=dev)
 filters.synth_i16(x, 1, stream=stream)
 r = filters.ResampleMC(ch, L_, M_, 1.0, filters.BLACKMAN, filters.PCM_I16, stream=stream)
-for _ in range(3):
+for _ in range(3 if ch >= 4096 else 60):           # (short kernels: tens of ms of work before the clocks have settled)
     r.process(x, y)
 torch.cuda.synchronize()
 t = Lb.llz_hip_timer_new()
-reps = 5 if ch >= 4096 else 20
+reps = 5 if ch >= 4096 else 40
 Lb.llz_hip_timer_start(t, stream.cuda_stream)
 for _ in range(reps):
     r.process(x, y)
