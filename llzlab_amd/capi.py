@@ -206,6 +206,11 @@ def lib():
     sig("llz_stft_mc_set_stream", i, ul, vp)
     sig("llz_stft_mc_analysis", i, ul, vp, vp, vp, i)
     sig("llz_stft_mc_synthesis", i, ul, vp, vp, vp, i)
+    sig("llz_iir_mc_init", ul, i, i, dp, i, dp)
+    sig("llz_iir_mc_uninit", None, ul)
+    sig("llz_iir_mc", i, ul, vp, vp, i)
+    sig("llz_iir_mc_flush", i, ul, vp)
+    sig("llz_iir_mc_set_stream", i, ul, vp)
     sig("llz_mdct_frames_mc_init", ul, i, i, i)
     sig("llz_mdct_frames_mc_uninit", None, ul)
     sig("llz_mdct_frames_mc_set_stream", i, ul, vp)

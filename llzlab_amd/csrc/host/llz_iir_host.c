@@ -543,3 +543,173 @@ static int iirm_process(iirm_t *f, const float *x, float *y, int frame_len)
     if (rc == LLZ_OK && !out_dev) rc = llzs_d2h(y, d_out, bytes, f->stream);
     return rc == LLZ_OK ? frame_len : rc;
 }
+
+
+/* =====================================================================================================
+ * Part 3: multi-channel GENERAL direct form I (any orders M, N up to llzs_iir_df1_mc_max_order()): the batch form of
+ * llz_iir_filter itself (reference llz_iir.c:103-156), float32 in / out, double arithmetic in the reference's order.
+ * ===================================================================================================== */
+#define LLZ_TAG_IIRG 0x4c5a4947
+
+typedef struct {
+    int tag, device, channels, M, N, ord;
+    int warm;                       /* samples after which the filter has forgotten its state to 1e-13 (0: never split time) */
+    double *d_ab;                   /* a[0..ord], b[0..ord], zero padded */
+    double *d_state[2];             /* [channels][2][ord + 1] delay lines, ping-pong */
+    int cur;
+    float *d_zero;                  /* N zeros per channel for the flush */
+    llz_stage_t st_in, st_out;
+    void *stream;
+} iirg_t;
+
+static void iirg_destroy(iirg_t *f)
+{
+    if (!f) return;
+    llzs_free(f->d_ab); llzs_free(f->d_state[0]); llzs_free(f->d_state[1]); llzs_free(f->d_zero);
+    llz_stage_release(&f->st_in); llz_stage_release(&f->st_out);
+    f->tag = 0;
+    free(f);
+}
+
+/* how long the recurrence remembers: run 1/A(z) on the host from the worst unit state (every y delay = 1) with zero input
+ * and find the last sample whose magnitude exceeds 1e-13 of the largest seen; 0 when it has not died out within `limit` */
+static int iirg_probe_memory(int M, const double *a, int limit)
+{
+    if (M == 0) return 1;
+    double y[64];
+    for (int k = 0; k < M; k++) y[k] = 1.0;
+    double peak = 1.0;
+    int last = 0;
+    for (int t = 0; t < limit; t++) {
+        double acc = 0.0;
+        for (int k = 1; k <= M; k++) acc -= a[k] * y[k - 1];
+        for (int k = M - 1; k >= 1; k--) y[k] = y[k - 1];
+        y[0] = acc;
+        const double m = fabs(acc);
+        if (!(m < 1e300)) return 0;                                 /* unstable */
+        if (m > peak) peak = m;
+        if (m > 1e-13 * peak) last = t;
+    }
+    return last < limit - limit / 8 ? last + 1 : 0;
+}
+
+unsigned long llz_iir_mc_init(int channels, int M, const double *a, int N, const double *b)
+{
+    const int ord = llzs_iir_df1_mc_max_order();
+    if (channels < 1 || M < 0 || N < 0 || M > ord || N > ord || !a) {
+        llzs_set_error("llz_iir_mc_init: channels %d M %d N %d (orders 0..%d) or NULL a", channels, M, N, ord);
+        return LLZ_BAD_HANDLE;
+    }
+    iirg_t *f = (iirg_t *)calloc(1, sizeof(*f));
+    double *ab = (double *)calloc(2 * ((size_t)ord + 1), sizeof(double));
+    int rc = (f && ab) ? LLZ_OK : LLZ_ERR_NOMEM;
+    if (rc == LLZ_OK) {
+        f->tag = LLZ_TAG_IIRG; f->device = llzs_device_get(); f->channels = channels; f->M = M; f->N = N; f->ord = ord;
+        for (int k = 0; k <= M; k++) ab[k] = a[k];
+        for (int k = 0; b && k <= N; k++) ab[ord + 1 + k] = b[k];                  /* b == NULL -> zeros (llz_iir.c:54-59) */
+        const int mem = iirg_probe_memory(M, a, 1 << 16);
+        f->warm = mem ? mem + N : 0;
+        const size_t sbytes = sizeof(double) * (size_t)channels * 2 * ((size_t)ord + 1);
+        f->d_ab = (double *)llzs_malloc(sizeof(double) * 2 * ((size_t)ord + 1));
+        f->d_state[0] = (double *)llzs_malloc(sbytes);
+        f->d_state[1] = (double *)llzs_malloc(sbytes);
+        f->d_zero = (float *)llzs_malloc(sizeof(float) * (size_t)channels * (size_t)(N > 0 ? N : 1));
+        if (!f->d_ab || !f->d_state[0] || !f->d_state[1] || !f->d_zero || f->device < 0) rc = LLZ_ERR_NOMEM;
+        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_ab, ab, sizeof(double) * 2 * ((size_t)ord + 1));
+        if (rc == LLZ_OK) rc = llzs_memset(f->d_state[0], 0, sbytes, NULL);
+        if (rc == LLZ_OK) rc = llzs_memset(f->d_state[1], 0, sbytes, NULL);
+        if (rc == LLZ_OK) rc = llzs_memset(f->d_zero, 0, sizeof(float) * (size_t)channels * (size_t)(N > 0 ? N : 1), NULL);
+        if (rc == LLZ_OK) rc = llzs_sync(NULL);
+    }
+    free(ab);
+    if (rc != LLZ_OK) {
+        if (f && f->tag) iirg_destroy(f); else free(f);
+        return LLZ_BAD_HANDLE;
+    }
+    return (unsigned long)f;
+}
+
+void llz_iir_mc_uninit(unsigned long handle)
+{
+    if (!LLZ_HANDLE_OK(handle, iirg_t, LLZ_TAG_IIRG)) return;
+    iirg_t *f = (iirg_t *)handle;
+    const int prev = llzs_device_enter(f->device);
+    llzs_sync(f->stream);
+    iirg_destroy(f);
+    llzs_device_leave(prev);
+}
+
+int llz_iir_mc_set_stream(unsigned long handle, void *stream)
+{
+    if (!LLZ_HANDLE_OK(handle, iirg_t, LLZ_TAG_IIRG)) return LLZ_ERR_ARG;
+    ((iirg_t *)handle)->stream = stream;
+    return LLZ_OK;
+}
+
+static int iirg_launch(iirg_t *f, const float *d_in, float *d_out, int n)
+{
+    /* time segments: enough (channel, segment) lanes to fill the chip (~64 K), each at least 8 x the filter's memory long */
+    int segs = 1;
+    if (f->warm > 0) {
+        const int tune = llzs_tune(LLZS_TUNE_IIR_SEGS);
+        const long want = tune > 0 ? tune : (65536 + f->channels - 1) / f->channels;
+        const long most = (long)n / (8L * f->warm);
+        segs = (int)(want < most ? want : most);
+        if (segs < 1) segs = 1;
+    }
+    const int rc = llzs_iir_df1_mc_f32(d_in, d_out, f->d_ab, f->d_state[f->cur], f->d_state[f->cur ^ 1], f->channels, n, n, n,
+                                       f->M, f->N, segs, f->warm, f->stream);
+    if (rc == LLZ_OK) f->cur ^= 1;
+    return rc;
+}
+
+int llz_iir_mc(unsigned long handle, const float *x, float *y, int frame_len)
+{
+    if (!LLZ_HANDLE_OK(handle, iirg_t, LLZ_TAG_IIRG) || !x || !y || frame_len < 1 || x == y) {
+        llzs_set_error("llz_iir_mc: bad handle, NULL buffer, in-place call or frame_len %d", frame_len);
+        return LLZ_ERR_ARG;
+    }
+    iirg_t *f = (iirg_t *)handle;
+    const int prev = llzs_device_enter(f->device);
+    const size_t bytes = sizeof(float) * (size_t)f->channels * (size_t)frame_len;
+    const int in_dev = llzs_is_device_ptr(x), out_dev = llzs_is_device_ptr(y);
+    const float *d_in = x;
+    float *d_out = y;
+    int rc = (in_dev < 0 || out_dev < 0) ? LLZ_ERR_ARG : LLZ_OK;
+    if (rc == LLZ_OK && !in_dev) {
+        d_in = (const float *)llz_stage_reserve(&f->st_in, bytes);
+        rc = d_in ? llzs_h2d((void *)d_in, x, bytes, f->stream) : LLZ_ERR_NOMEM;
+    }
+    if (rc == LLZ_OK && !out_dev) {
+        d_out = (float *)llz_stage_reserve(&f->st_out, bytes);
+        if (!d_out) rc = LLZ_ERR_NOMEM;
+    }
+    if (rc == LLZ_OK) rc = iirg_launch(f, d_in, d_out, frame_len);
+    if (rc == LLZ_OK && !out_dev) rc = llzs_d2h(y, d_out, bytes, f->stream);
+    llzs_device_leave(prev);
+    return rc == LLZ_OK ? frame_len : rc;
+}
+
+/* N more samples of x = 0 per channel (llz_iir.c:147-156); returns N */
+int llz_iir_mc_flush(unsigned long handle, float *y)
+{
+    if (!LLZ_HANDLE_OK(handle, iirg_t, LLZ_TAG_IIRG) || !y) {
+        llzs_set_error("llz_iir_mc_flush: bad handle or buffer");
+        return LLZ_ERR_ARG;
+    }
+    iirg_t *f = (iirg_t *)handle;
+    if (f->N == 0) return 0;
+    const int prev = llzs_device_enter(f->device);
+    const size_t bytes = sizeof(float) * (size_t)f->channels * (size_t)f->N;
+    const int out_dev = llzs_is_device_ptr(y);
+    float *d_out = y;
+    int rc = out_dev < 0 ? LLZ_ERR_ARG : LLZ_OK;
+    if (rc == LLZ_OK && !out_dev) {
+        d_out = (float *)llz_stage_reserve(&f->st_out, bytes);
+        if (!d_out) rc = LLZ_ERR_NOMEM;
+    }
+    if (rc == LLZ_OK) rc = iirg_launch(f, f->d_zero, d_out, f->N);
+    if (rc == LLZ_OK && !out_dev) rc = llzs_d2h(y, d_out, bytes, f->stream);
+    llzs_device_leave(prev);
+    return rc == LLZ_OK ? f->N : rc;
+}

@@ -172,6 +172,13 @@ int llzs_iir_cascade_wave_f64(const float *in, float *out, const double *coef, c
                               int warm_chunks, void *stream);
 int llzs_iir_df1_f64(const double *in, double *out, const double *a, const double *b, double *xs, double *ys,
                      int M, int N, int n, void *stream);
+/* the same recurrence for many channels (iir_df1.hip): float32 in / out, double arithmetic in the reference's order; ab =
+ * a[0..ord] then b[0..ord] zero padded (ord = llzs_iir_df1_mc_max_order()); state [channels][2][ord + 1] = the reference's x[]
+ * then y[] delay lines, read from state_in and written to state_out (two buffers); segs time segments per channel, later ones
+ * warmed up over `warm` samples from zero delay lines */
+int llzs_iir_df1_mc_f32(const float *in, float *out, const double *ab, const double *state_in, double *state_out, int channels,
+                        long n, long in_pitch, long out_pitch, int M, int N, int segs, int warm, void *stream);
+int llzs_iir_df1_mc_max_order(void);
 
 /* ---- resample ---- */
 /* y[c][i] = gain * sum_{k<Q} x[c][(i0+i)*M/L - k - in0] * g[(i0+i)%L][k], x before the call start comes from

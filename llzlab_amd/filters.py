@@ -230,6 +230,38 @@ class IirCascadeMC:
 
 
 # ------------------------------------------------------------------------------------------ resample
+class IirMC:
+    """llz_iir_mc_* (include/llz_iir.h part 3): the general direct-form-I filter for many channels, float32 in / out."""
+
+    def __init__(self, channels, a, b, stream=None):
+        self._L = capi.lib()
+        a, b = _f64(a), _f64(b)
+        self.channels, self.M, self.N = channels, len(a) - 1, len(b) - 1
+        self.handle = check_handle(self._L.llz_iir_mc_init(channels, self.M, a.ctypes.data_as(_dp), self.N, b.ctypes.data_as(_dp)),
+                                   "llz_iir_mc_init")
+        if stream is not None:
+            check(self._L.llz_iir_mc_set_stream(self.handle, _stream_ptr(stream)), "llz_iir_mc_set_stream")
+
+    def filter(self, x, out):
+        n = int(x.shape[-1])
+        check(self._L.llz_iir_mc(self.handle, _typed(x, "float32", self.channels * n, "x"), _typed(out, "float32", self.channels * n, "y"), n),
+              "llz_iir_mc")
+        return out
+
+    def flush(self, out):
+        """N more outputs per channel into out [channels][N] (N = 0: nothing to flush, out is not touched)"""
+        if self.N == 0:
+            return check(self._L.llz_iir_mc_flush(self.handle, _ptr(out)), "llz_iir_mc_flush")
+        return check(self._L.llz_iir_mc_flush(self.handle, _typed(out, "float32", self.channels * self.N, "y")), "llz_iir_mc_flush")
+
+    def close(self):
+        if getattr(self, "handle", 0):
+            self._L.llz_iir_mc_uninit(self.handle)
+            self.handle = 0
+
+    __del__ = close
+
+
 class _Resample1:
     """int16 single channel, host buffers: llz_{decimate,interp,resample}."""
     _init = _run = _uninit = None

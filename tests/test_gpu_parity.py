@@ -1642,3 +1642,41 @@ def test_resample_i16_lm_screened_is_bit_exact(dev, oracle, L, M, win, gain):
     assert np.array_equal(plain, ref), "all-double kernel vs oracle"
     bad = np.argwhere(got != ref)
     assert bad.size == 0, (L, M, len(bad), bad[:5].tolist(), got[tuple(bad[0])], ref[tuple(bad[0])])
+
+
+# ------------------------------------------------------------------------------------------------ general direct form I, many channels
+@pytest.mark.parametrize("a,b", [
+    ([1.0, -0.3695, 0.1958, 0.0], [1.0, 0.2066, 0.4131, 0.2066]),        # the reference's own order-3 call (llz_musicpitch.c:1277-1285)
+    ([1.0, -1.2, 0.9, -0.35, 0.12, -0.02], [0.05, 0.1, 0.05]),            # M = 5, N = 2
+    ([1.0], [0.25, 0.5, -0.125, 0.0625, 0.3]),                            # M = 0: feed-forward only
+    ([1.0, -1.8 * 0.99 * 0.95, 0.99 * 0.99], [0.01]),                     # M = 2, N = 0, pole radius 0.99: long memory
+])
+def test_iir_mc_general_orders(dev, oracle, a, b):
+    """llz_iir_mc_*: the reference's general direct-form-I filter (any orders) for 1024 channels at once, float32 in / out.
+    (1) one time segment per channel: the reference's own double sequence rounded once to float32 -- equal to the oracle's
+    llz_iir_filter bit for bit; (2) the default launch (channels split along time, later segments warmed up from zero delay
+    lines): within 1e-5 RMS, streamed over two calls + flush."""
+    channels, n = 1024, 24000
+    x = oracle.synth_f32(channels, 2 * n, seed=len(a) * 10 + len(b))
+    sel = [0, 1, 511, 1023]
+    ref = np.stack([np.concatenate(oracle.iir_stream(np.array(a), np.array(b), x[c].astype(np.float64), flush=True)) for c in sel])
+    xd = torch.from_numpy(x).to(dev)
+    for segs in (1, -1):
+        with capi.tuned(iir_segs=segs):
+            f = filters.IirMC(channels, a, b)
+            outs = []
+            for o in (0, n):
+                y = torch.empty(channels, n, dtype=torch.float32, device=dev)
+                f.filter(xd[:, o:o + n].contiguous(), y)
+                outs.append(y.cpu().numpy())
+            N = len(b) - 1
+            tail = np.zeros((channels, max(N, 1)), dtype=np.float32) if N == 0 else np.zeros((channels, N), dtype=np.float32)
+            assert f.flush(tail) == N
+            f.close()
+        got = np.concatenate(outs + ([tail[:, :N]] if N else []), axis=1)[sel]
+        if segs == 1:
+            assert np.array_equal(got, ref.astype(np.float32)), (a, b)
+        else:
+            rms_check(got, ref, f"iir_mc M={len(a) - 1} N={len(b) - 1} (time segments)")
+    with pytest.raises(capi.LlzError):
+        filters.IirMC(4, [1.0] + [0.01] * 9, [1.0])                       # order 9: refused
