@@ -368,6 +368,30 @@ def main():
             # ranks (strong scaling): that curve is this entry's Msamples_in_s per N, not `value` (weak-scaled FIR)
             "strong_scaling_metric": "also.resample_1to3_f32_8192ch_sharded.Msamples_in_s",
         }
+        # measured HBM traffic over algorithmic bytes of the kernels behind the 'also' entries (profiles/pmc_traffic.json:
+        # FETCH_SIZE x 2 + WRITE_SIZE per launch of tools/run_path.py traffic_set), reported while the kernel sources still match
+        try:
+            recs = json.load(open(tpath)).get("kernels", {}) if os.path.exists(tpath) else {}
+        except Exception:
+            recs = {}
+        for key, kern in (("resample_1to3_f32_8192ch_sharded", "k_fir_mfma_bf16x3#0"), ("resample_1to3_i16_exact_8192ch_sharded", "k_fir_mfma_i8x#0"),
+                          ("resample_1to3_i16_fast_8192ch_sharded", "k_fir_mfma_i16#0"), ("iir8_1024ch_sharded", "k_iir_cascade_wave_pk32#0"),
+                          ("iir8_r099_1024ch_sharded", "k_iir_cascade_wave_pf64w#0"), ("resample_147to160_f32_256ch", "k_resample_mfma_pt_f32#0"),
+                          ("resample_160to147_f32_256ch", "k_resample_mfma_pt_f32#1"), ("resample_147to160_i16_256ch", "k_resample_i8x#0"),
+                          ("resample_160to147_i16_256ch", "k_resample_i8x#1")):
+            rec = recs.get(kern)
+            if rec and key in also and "error" not in also[key]:
+                files = {"k_iir": ["iir.hip"], "k_fir_mfma_bf16x3": ["fir_mfma.hip"], "k_fir_mfma_i16": ["fir_mfma.hip"],
+                         "k_fir_mfma_i8x": ["fir_mfma_i8.hip", "screen_i8.hpp"], "k_resample_mfma": ["resample_mfma.hip"],
+                         "k_resample_i8x": ["resample_i8.hip", "screen_i8.hpp"]}
+                src = next(v for p_, v in files.items() if kern.startswith(p_))
+                import hashlib
+                h = hashlib.sha256()
+                for fn in src:
+                    h.update(open(os.path.join(ROOT, "llzlab_amd", "csrc", "kernels", fn), "rb").read())
+                also[key]["kernel"] = kern.split("#")[0]
+                also[key]["traffic_over_algorithmic"] = (rec["traffic_over_algorithmic"]
+                                                         if rec.get("kernel_source_sha256") == h.hexdigest() else None)
         if also:
             line["also"] = also
         print(json.dumps(line), flush=True)

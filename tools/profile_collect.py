@@ -60,6 +60,7 @@ def counters(sub):
         if (key, r["Dispatch_Id"]) not in seen:
             seen.add((key, r["Dispatch_Id"]))
             agg[key]["_ms"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+            agg[key]["_id"].append(int(r["Dispatch_Id"]))
     return agg
 
 
@@ -159,16 +160,79 @@ for name, v in mf.items():
     if not busy or sum(busy) == 0:
         continue
     ns = 1e6 * sum(v["_ms"]) / len(v["_ms"])                 # this pass's own dispatch durations
-    g2 = sq2.get(name, {})
-    gui = g2.get("GRBM_GUI_ACTIVE")
-    clock_ghz = (sum(gui) / len(gui) / 8) / (1e6 * sum(g2["_ms"]) / len(g2["_ms"])) if gui else None
+    gui = v.get("GRBM_GUI_ACTIVE") or sq2.get(name, {}).get("GRBM_GUI_ACTIVE")
+    clock_ghz = (sum(gui) / len(gui) / 8) / ns if gui else None
     simd_cycles = ns * clock_ghz * 1024 if clock_ghz else None
     util[name[:90]] = {"mfma_busy_cycles_per_launch": sum(busy) / len(busy),
                        "mfma_instructions_per_launch": sum(v["SQ_INSTS_MFMA"]) / len(v["SQ_INSTS_MFMA"]),
                        "avg_ms": ns / 1e6 if ns else None, "shader_clock_GHz": clock_ghz,
                        "mfma_busy_fraction_of_simd_cycles": (sum(busy) / len(busy)) / simd_cycles if simd_cycles else None}
-json.dump({"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA ... -- python3 bench.py --steps 3 --warmup 1 --no-cpu",
+json.dump({"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA ... GRBM_GUI_ACTIVE -- python3 tools/run_path.py traffic_set 3",
            "kernels": util}, open(os.path.join(dst, f"{tag}_mfma_utilisation.json"), "w"), indent=1)
+# ---- the other kernels of the path: tools/run_path.py traffic_set under FETCH_SIZE / WRITE_SIZE / SQ passes ----------------
+N5 = 3 * (((1 << 22) // 3) // 256 * 256)
+ALGO = [   # (kernel name part, occurrence in dispatch order, workload, algorithmic bytes per launch)
+    ("k_iir_cascade_wave_pk32", 0, "config 4: 1024 ch x 8 sections x 2^20, radius 0.44 (float32 arithmetic)", 8 * 1024 * (1 << 20)),
+    ("k_iir_cascade_wave_pf64w", 0, "config 4: 1024 ch x 8 sections x 2^20, radius 0.99 (double arithmetic)", 8 * 1024 * (1 << 20)),
+    ("k_fir_mfma_bf16x3", 0, "config 5 float32, 2048 of its 8192 ch x 4 Mi, 1:3", (4 + 4 / 3) * 2048 * N5),
+    ("k_fir_mfma_i8x", 0, "config 5 int16 bit-exact, 2048 ch x 4 Mi, 1:3", (2 + 2 / 3) * 2048 * N5),
+    ("k_fir_mfma_i16", 0, "config 5 int16 fast (1 LSB), 2048 ch x 4 Mi, 1:3", (2 + 2 / 3) * 2048 * N5),
+    ("k_resample_mfma_pt_f32", 0, "147:160 float32, 256 ch x 160 x 8192", (4 + 4 * 147 / 160) * 256 * 160 * 8192),
+    ("k_resample_mfma_pt_f32", 1, "160:147 float32, 256 ch x 147 x 8192", (4 + 4 * 160 / 147) * 256 * 147 * 8192),
+    ("k_resample_i8x", 0, "147:160 int16 bit-exact, 256 ch x 160 x 8192", (2 + 2 * 147 / 160) * 256 * 160 * 8192),
+    ("k_resample_i8x", 1, "160:147 int16 bit-exact, 256 ch x 147 x 8192", (2 + 2 * 160 / 147) * 256 * 147 * 8192),
+]
+
+
+def occurrence(agg, part, k):
+    """the k-th (name, grid) group, in dispatch order, whose kernel name contains `part`"""
+    groups = sorted(((min(v["_id"]), key, v) for key, v in agg.items() if part in key[0]), key=lambda g: g[0])
+    return (groups[k][1], groups[k][2]) if k < len(groups) else (None, None)
+
+
+def mean(x):
+    return sum(x) / len(x)
+
+
+def sha_of(files):
+    import hashlib
+    h = hashlib.sha256()
+    for fn in files:
+        h.update(open(os.path.join(root, "llzlab_amd", "csrc", "kernels", fn), "rb").read())
+    return h.hexdigest()
+
+
+SRC = {"k_iir": ["iir.hip"], "k_fir_mfma_bf16x3": ["fir_mfma.hip"], "k_fir_mfma_i16": ["fir_mfma.hip"],
+       "k_fir_mfma_i8x": ["fir_mfma_i8.hip", "screen_i8.hpp"], "k_resample_mfma": ["resample_mfma.hip"],
+       "k_resample_i8x": ["resample_i8.hip", "screen_i8.hpp"]}
+if os.path.isdir(os.path.join(src, "set_fetch")):
+    sf, sw, ssq = counters("set_fetch"), counters("set_write"), counters("set_sq")
+    kernels = {}
+    for part, k, what, algo in ALGO:
+        (kf, vf), (kw, vw), (ks, vs) = occurrence(sf, part, k), occurrence(sw, part, k), occurrence(ssq, part, k)
+        if vf is None or vw is None:
+            continue
+        fetch, write = 2 * mean(vf["FETCH_SIZE"]) * 1024, mean(vw["WRITE_SIZE"]) * 1024
+        e = {"workload": what, "grid": int(kf[1]), "launches": len(vf["FETCH_SIZE"]),
+             "fetch_bytes_x2": fetch, "write_bytes": write, "traffic_bytes_per_launch": fetch + write,
+             "algorithmic_bytes_per_launch": algo, "traffic_over_algorithmic": (fetch + write) / algo,
+             "launch_ms_in_fetch_pass": mean(vf["_ms"]),
+             "kernel_source_sha256": sha_of(next(v for p_, v in SRC.items() if part.startswith(p_)))}
+        if vs is not None and "GRBM_GUI_ACTIVE" in vs:
+            cyc, ms = mean(vs["GRBM_GUI_ACTIVE"]) / 8, mean(vs["_ms"])
+            e["sq"] = {"launch_ms": ms, "shader_clock_GHz": cyc / (ms * 1e6),
+                       "valu_wave_instructions_per_simd": mean(vs["SQ_INSTS_VALU"]) / 1024,
+                       "shader_cycles_per_valu_instruction_per_simd": cyc / (mean(vs["SQ_INSTS_VALU"]) / 1024),
+                       "salu_per_valu": mean(vs["SQ_INSTS_SALU"]) / mean(vs["SQ_INSTS_VALU"]),
+                       "lds_bank_conflict_fraction": (mean(vs["SQ_LDS_BANK_CONFLICT"]) / mean(vs["SQ_LDS_IDX_ACTIVE"])
+                                                      if mean(vs["SQ_LDS_IDX_ACTIVE"]) else 0.0),
+                       "wave_cycles_fraction_issuing": mean(vs["SQ_ACTIVE_INST_ANY"]) / mean(vs["SQ_WAVE_CYCLES"]),
+                       "wave_cycles_fraction_issue_stalled": mean(vs["SQ_WAIT_INST_ANY"]) / mean(vs["SQ_WAVE_CYCLES"])}
+        kernels[f"{part}#{k}"] = e
+    out["kernels"] = kernels
+    out["kernels_command"] = ("rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | <SQ set> -- python3 tools/run_path.py traffic_set 3 "
+                              "(separate passes; FETCH_SIZE doubled as for the headline)")
+    json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 print(json.dumps(sq, indent=1))
 print(json.dumps(util, indent=1))

@@ -74,5 +74,52 @@ elif what == "iir":
     q = filters.IirCascadeMC(ch, coef)
     for _ in range(steps):
         q.filter(x, y)
+elif what == "traffic_set":
+    # every kernel whose HBM traffic profiles/pmc_traffic.json records, a few launches each, one process (tools/profile_round.sh)
+    def go(fn, k=steps):
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+    ch, n = 1024, 1 << 20                                           # BASELINE config 4, both coefficient sets
+    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    filters.synth_f32(x, 1)
+    for row in ([0.2066, 0.4131, 0.2066, 1.0, -0.3695, 0.1958], [0.01, 0.0, -0.01, 1.0, -2 * 0.99 * np.cos(0.3), 0.99 ** 2]):
+        q = filters.IirCascadeMC(ch, np.tile(np.array(row), (8, 1)))
+        go(lambda: q.filter(x, y))
+        q.close()
+    del x, y
+    ch = 2048                                                       # BASELINE config 5 (a quarter of its channels), three formats
+    n = 3 * (((1 << 22) // 3) // 256 * 256)
+    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+    y = torch.empty(ch, n // 3, dtype=torch.float32, device=dev)
+    filters.synth_f32(x, 1)
+    r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, filters.PCM_F32)
+    go(lambda: r.process(x, y))
+    r.close()
+    del x, y
+    xi = torch.empty(ch, n, dtype=torch.int16, device=dev)
+    yi = torch.empty(ch, n // 3, dtype=torch.int16, device=dev)
+    filters.synth_i16(xi, 1)
+    for fmt in (filters.PCM_I16, filters.PCM_I16_FAST):
+        r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, fmt)
+        go(lambda: r.process(xi, yi))
+        r.close()
+    del xi, yi
+    for (L_, M_) in ((147, 160), (160, 147)):                       # the reference CLI's ratios, float32 and int16
+        ch, n = 256, M_ * 8192
+        x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+        y = torch.empty(ch, n * L_ // M_, dtype=torch.float32, device=dev)
+        filters.synth_f32(x, 1)
+        r = filters.ResampleMC(ch, L_, M_, 1.0, filters.BLACKMAN, filters.PCM_F32)
+        go(lambda: r.process(x, y))
+        r.close()
+        xi = torch.empty(ch, n, dtype=torch.int16, device=dev)
+        yi = torch.empty(ch, n * L_ // M_, dtype=torch.int16, device=dev)
+        filters.synth_i16(xi, 1)
+        r = filters.ResampleMC(ch, L_, M_, 1.0, filters.BLACKMAN, filters.PCM_I16)
+        go(lambda: r.process(xi, yi))
+        r.close()
+        del x, y, xi, yi
 torch.cuda.synchronize()
 print("done", what)
