@@ -348,139 +348,6 @@ k_iir_cascade_pipe(const float *__restrict__ in, float *__restrict__ out, const 
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_iir_cascade_wave<R, S> (first version; shipped paths: k_iir_cascade_wave_pk / _pf64 below; kept for LLZ_IIR_UNPACKED
-// A/B runs and checked by tests/test_gpu_parity.py::test_iir_wave_first_version_kernels).
-// Cascades whose memory is short (the host has measured both: the rounding-noise gain of
-// every section and the number of chunks after which a state error has died out).  Same lanes-along-time section step as
-// the pipelined kernel, but a WAVE owns a (channel, time segment) and runs ALL sections of a chunk back to back in
-// registers: no LDS hand-over between sections, no barriers, no conversions in between.  Parallelism comes from the time
-// segments (a later segment starts `warm` chunks early from the zero state, as in the pipelined kernel).
-// Per-lane powers P^lane, P^(lane%16+1), P^(lane%32+1) of every section sit in LDS ([S][64][12] floats, conflict-free
-// 16-byte reads); section coefficients and the scan powers are wave-uniform and come through the scalar cache.
-template <typename R, int S>
-__global__ void __launch_bounds__(256)
-k_iir_cascade_wave(const float *__restrict__ in, float *__restrict__ out, const R *__restrict__ coef32,
-                   const R *__restrict__ pd32 /* [S][pd_stride], P^(2^d) d < 4 first */, const R *__restrict__ pl32 /* [S][64][12] */,
-                   const double *__restrict__ state_in, double *__restrict__ state, int nchunks_total, long in_pitch,
-                   long out_pitch, int stages, int segs, int seg_chunks, int warm, long items, int pd_stride)
-{
-    __shared__ __attribute__((aligned(16))) R s_pl[S * 64 * 12];
-    for (int e = threadIdx.x; e < stages * 768; e += 256) s_pl[e] = pl32[e];
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= items) return;
-    const int c = (int)(item / segs), seg = (int)(item - (long)c * segs);
-    const int skip = seg > 0 ? warm : 0;
-    const int chunk0 = seg * seg_chunks - skip;
-    const int nchunks = min(nchunks_total, (seg + 1) * seg_chunks) - chunk0;
-
-    R su1[S], su2[S], sy1[S], sy2[S];
-#pragma unroll
-    for (int s = 0; s < S; s++) {
-        su1[s] = su2[s] = sy1[s] = sy2[s] = 0;
-        if (s < stages && seg == 0) {
-            const double *st = state_in + ((size_t)c * stages + s) * 4;
-            su1[s] = (R)st[0]; su2[s] = (R)st[1]; sy1[s] = (R)st[2]; sy2[s] = (R)st[3];
-        }
-    }
-    const float *row = in + (size_t)c * in_pitch + (size_t)chunk0 * 1024 + lane * 16;
-    float *orow = out + (size_t)c * out_pitch + (size_t)chunk0 * 1024 + lane * 16;
-    float4 pre[4];
-    if (nchunks > 0) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) pre[q] = *reinterpret_cast<const float4 *>(row + 4 * q);
-    }
-    for (int chunk = 0; chunk < nchunks; chunk++) {
-        const R *tabs = s_pl;    // (the compiler hoists these reads out of the chunk loop: 171 VGPRs, two waves per
-                                     //  SIMD; forcing them back inside measured 6 % slower and no fewer registers)
-        R u[16];
-#pragma unroll
-        for (int q = 0; q < 4; q++) { u[4 * q] = (R)pre[q].x; u[4 * q + 1] = (R)pre[q].y; u[4 * q + 2] = (R)pre[q].z; u[4 * q + 3] = (R)pre[q].w; }
-        if (chunk + 1 < nchunks) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) pre[q] = *reinterpret_cast<const float4 *>(row + (size_t)(chunk + 1) * 1024 + 4 * q);
-        }
-#pragma unroll
-        for (int s = 0; s < S; s++) {
-            if (s < stages) {
-                const R b0 = coef32[5 * s], b1 = coef32[5 * s + 1], b2 = coef32[5 * s + 2];
-                const R a1 = coef32[5 * s + 3], a2 = coef32[5 * s + 4];
-                const R *P = pd32 + pd_stride * s;                     // P^(2^d), d = 0..3, row major 2x2 each (uniform)
-                const R *tl = tabs + (s * 64 + lane) * 12;
-                struct q4 { R x, y, z, w; };
-                const q4 t0 = {tl[0], tl[1], tl[2], tl[3]}, t1 = {tl[4], tl[5], tl[6], tl[7]}, t2 = {tl[8], tl[9], tl[10], tl[11]};
-                R um1 = dpp_<DPP_WAVE_SHR1, 0xF>(u[15]), um2 = dpp_<DPP_WAVE_SHR1, 0xF>(u[14]);
-                if (lane == 0) { um1 = su1[s]; um2 = su2[s]; }
-                const R nu1 = lane63_(u[15]), nu2 = lane63_(u[14]);
-                {
-                    R p1 = um1, p2 = um2;
-#pragma unroll
-                    for (int k = 0; k < 16; k++) {
-                        const R x = u[k];
-                        R acc = b0 * x;
-                        acc = fma_(b1, p1, acc);
-                        acc = fma_(b2, p2, acc);
-                        u[k] = acc;
-                        p2 = p1; p1 = x;
-                    }
-                }
-                R z1 = 0.f, z2 = 0.f;
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const R y = fma_(-a1, z1, fma_(-a2, z2, u[k]));
-                    z2 = z1; z1 = y;
-                }
-#define LLZ_ROW_STEP(D, SH)                                                                               \
-                {                                                                                             \
-                    const R q1 = dpp_<DPP_ROW_SHR + SH, 0xF>(z1), q2 = dpp_<DPP_ROW_SHR + SH, 0xF>(z2);   \
-                    z1 = fma_(P[4 * D], q1, fma_(P[4 * D + 1], q2, z1));                                      \
-                    z2 = fma_(P[4 * D + 2], q1, fma_(P[4 * D + 3], q2, z2));                                  \
-                }
-                LLZ_ROW_STEP(0, 1) LLZ_ROW_STEP(1, 2) LLZ_ROW_STEP(2, 4) LLZ_ROW_STEP(3, 8)
-#undef LLZ_ROW_STEP
-                {
-                    const R q1 = dpp_<DPP_BCAST15, 0xA>(z1), q2 = dpp_<DPP_BCAST15, 0xA>(z2);
-                    z1 = fma_(t1.x, q1, fma_(t1.y, q2, z1));
-                    z2 = fma_(t1.z, q1, fma_(t1.w, q2, z2));
-                }
-                {
-                    const R q1 = dpp_<DPP_BCAST31, 0xC>(z1), q2 = dpp_<DPP_BCAST31, 0xC>(z2);
-                    z1 = fma_(t2.x, q1, fma_(t2.y, q2, z1));
-                    z2 = fma_(t2.z, q1, fma_(t2.w, q2, z2));
-                }
-                const R e1 = dpp_<DPP_WAVE_SHR1, 0xF>(z1), e2 = dpp_<DPP_WAVE_SHR1, 0xF>(z2);
-                R y1 = fma_(t0.x, sy1[s], fma_(t0.y, sy2[s], e1));
-                R y2 = fma_(t0.z, sy1[s], fma_(t0.w, sy2[s], e2));
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const R y = fma_(-a1, y1, fma_(-a2, y2, u[k]));
-                    u[k] = y;
-                    y2 = y1; y1 = y;
-                }
-                su1[s] = nu1; su2[s] = nu2;
-                sy1[s] = lane63_(y1); sy2[s] = lane63_(y2);
-            }
-        }
-        if (chunk >= skip) {
-            float *dst = orow + (size_t)chunk * 1024;
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                *reinterpret_cast<float4 *>(dst + 4 * q) = make_float4((float)u[4 * q], (float)u[4 * q + 1], (float)u[4 * q + 2], (float)u[4 * q + 3]);
-        }
-    }
-    if (lane == 0 && seg == segs - 1) {
-#pragma unroll
-        for (int s = 0; s < S; s++) {
-            if (s < stages) {
-                double *st = state + ((size_t)c * stages + s) * 4;
-                st[0] = (double)su1[s]; st[1] = (double)su2[s]; st[2] = (double)sy1[s]; st[3] = (double)sy2[s];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // k_iir_cascade_wave_pk: the float32 wave-autonomous cascade on PACKED float32 arithmetic (v_pk_fma_f32: two FMAs per
 // lane and issue slot).  The kernel above is bound by VALU issue (about 160 instructions per section and 1024-sample
 // chunk), so the lane's 16 samples are held as 8 pairs U[j] = (u[j], u[j+8]) and every part of the section step is
@@ -1311,6 +1178,7 @@ extern "C" int llzs_iir_cascade_pipe_f32(const float *in, float *out, const doub
         while (segs > 1 && nchunks / segs < 8 * warm) segs--;
     }
     if (const int v = llzs_tune(LLZS_TUNE_IIR_SEGS); v >= 1 && v <= 64 && (v == 1 || warm_chunks > 0)) segs = v;
+    while (segs > 1 && nchunks / segs < warm_chunks) segs--;        // (a forced count too must leave room for the warm-up)
     const int seg_chunks = (nchunks + segs - 1) / segs;
     segs = (nchunks + seg_chunks - 1) / seg_chunks;
     if (float32)
@@ -1342,28 +1210,25 @@ static int launch_iir_wave(const float *in, float *out, const R *coef, const R *
     // on 128 channels: about three rounds of items are best while a segment stays long (>= 64 chunks: the per-item cost
     // of warm-up and table load, ~1.4 chunks, stays small and the hardware balances the rounds), otherwise exactly one
     // round; segments at least 8 x the warm-up.
-    // the one-section-ahead kernels (packed float32 / double); LLZ_IIR_UNPACKED=1 keeps the first wave kernels for A/B
-    const bool first_version = llzs_tune(LLZS_TUNE_IIR_UNPACKED) == 1;
-    const bool ahead = !first_version && (std::is_same<R, double>::value || ph32 != nullptr);
-    const void *kfn = nullptr;
-    if (ahead) {
-        if constexpr (std::is_same<R, float>::value) {
-            static const void *const tab[8] = {
-                (const void *)k_iir_cascade_wave_pk<1>, (const void *)k_iir_cascade_wave_pk<2>, (const void *)k_iir_cascade_wave_pk<3>,
-                (const void *)k_iir_cascade_wave_pk<4>, (const void *)k_iir_cascade_wave_pk<5>, (const void *)k_iir_cascade_wave_pk<6>,
-                (const void *)k_iir_cascade_wave_pk<7>, (const void *)k_iir_cascade_wave_pk<8>};
-            kfn = tab[stages - 1];
-        } else {
-            static const void *const tab[8] = {
-                (const void *)k_iir_cascade_wave_pf64<1>, (const void *)k_iir_cascade_wave_pf64<2>, (const void *)k_iir_cascade_wave_pf64<3>,
-                (const void *)k_iir_cascade_wave_pf64<4>, (const void *)k_iir_cascade_wave_pf64<5>, (const void *)k_iir_cascade_wave_pf64<6>,
-                (const void *)k_iir_cascade_wave_pf64<7>, (const void *)k_iir_cascade_wave_pf64<8>};
-            kfn = tab[stages - 1];
-        }
+    // the one-section-ahead kernels: packed float32 (needs the h table) or double
+    if (std::is_same<R, float>::value && ph32 == nullptr) {
+        llzs_set_error("iir_cascade_wave: the float32 form needs its h table");
+        return LLZ_ERR_ARG;
     }
-    if (!kfn)
-        kfn = stages <= 2 ? (const void *)k_iir_cascade_wave<R, 2> : stages <= 4 ? (const void *)k_iir_cascade_wave<R, 4>
-                                                                                  : (const void *)k_iir_cascade_wave<R, 8>;
+    const void *kfn = nullptr;
+    if constexpr (std::is_same<R, float>::value) {
+        static const void *const tab[8] = {
+            (const void *)k_iir_cascade_wave_pk<1>, (const void *)k_iir_cascade_wave_pk<2>, (const void *)k_iir_cascade_wave_pk<3>,
+            (const void *)k_iir_cascade_wave_pk<4>, (const void *)k_iir_cascade_wave_pk<5>, (const void *)k_iir_cascade_wave_pk<6>,
+            (const void *)k_iir_cascade_wave_pk<7>, (const void *)k_iir_cascade_wave_pk<8>};
+        kfn = tab[stages - 1];
+    } else {
+        static const void *const tab[8] = {
+            (const void *)k_iir_cascade_wave_pf64<1>, (const void *)k_iir_cascade_wave_pf64<2>, (const void *)k_iir_cascade_wave_pf64<3>,
+            (const void *)k_iir_cascade_wave_pf64<4>, (const void *)k_iir_cascade_wave_pf64<5>, (const void *)k_iir_cascade_wave_pf64<6>,
+            (const void *)k_iir_cascade_wave_pf64<7>, (const void *)k_iir_cascade_wave_pf64<8>};
+        kfn = tab[stages - 1];
+    }
     // (queried once per kernel and process: same answer on every device of a node)
     static struct { const void *fn; long slots; } seen[24];
     static int nseen = 0;
@@ -1396,11 +1261,13 @@ static int launch_iir_wave(const float *in, float *out, const R *coef, const R *
     }
     while (segs > 1 && nchunks / segs < 8 * warm_chunks) segs--;
     if (const int v = llzs_tune(LLZS_TUNE_IIR_SEGS); v >= 1 && v <= 64) segs = v;
+    while (segs > 1 && nchunks / segs < warm_chunks) segs--;        // (a forced count too: a segment must hold its own warm-up,
+                                                                    //  or its first chunk would lie in front of the row)
     const int seg_chunks = (nchunks + segs - 1) / segs;
     segs = (nchunks + seg_chunks - 1) / seg_chunks;
     const long items = (long)channels * segs;
     const dim3 grid((unsigned)((items + 3) / 4));
-    if (ahead) {
+    {
         if constexpr (std::is_same<R, float>::value) {
 #define LLZ_AHEAD_LAUNCH(S)                                                                                          \
     hipLaunchKernelGGL((k_iir_cascade_wave_pk<S>), grid, dim3(256), 0, as_stream(stream), in, out, pd, pl, ph32, state_in, state, \
@@ -1427,15 +1294,6 @@ static int launch_iir_wave(const float *in, float *out, const R *coef, const R *
         LLZ_LAUNCH_CHECK("k_iir_cascade_wave (one section ahead)");
         return LLZ_OK;
     }
-#define LLZ_WAVE_LAUNCH(S)                                                                                           \
-    hipLaunchKernelGGL((k_iir_cascade_wave<R, S>), grid, dim3(256), 0, as_stream(stream), in, out, coef, pd, pl,        \
-                       state_in, state, nchunks, in_pitch, out_pitch, stages, segs, seg_chunks, warm_chunks, items, pd_stride)
-    if (stages <= 2) LLZ_WAVE_LAUNCH(2);
-    else if (stages <= 4) LLZ_WAVE_LAUNCH(4);
-    else LLZ_WAVE_LAUNCH(8);
-#undef LLZ_WAVE_LAUNCH
-    LLZ_LAUNCH_CHECK("k_iir_cascade_wave");
-    return LLZ_OK;
 }
 
 extern "C" int llzs_iir_cascade_wave_f32(const float *in, float *out, const float *coef32, const float *pd32,
@@ -1498,6 +1356,8 @@ extern "C" int llzs_iir_cascade_wave32_f32(const float *in, float *out, const fl
     }
     while (segs > 1 && nchunks / segs < 8 * warm) segs--;
     if (const int v = llzs_tune(LLZS_TUNE_IIR_SEGS); v >= 1 && v <= 64) segs = v;
+    while (segs > 1 && nchunks / segs < warm_chunks) segs--;        // (a forced count too: a segment must hold its own warm-up,
+                                                                    //  or its first chunk would lie in front of the row)
     const int seg_chunks = (nchunks + segs - 1) / segs;
     segs = (nchunks + seg_chunks - 1) / seg_chunks;
     const long items = (long)channels * segs;
@@ -1555,6 +1415,8 @@ extern "C" int llzs_iir_cascade_wave32_f64(const float *in, float *out, const do
     }
     while (segs > 1 && nchunks / segs < 8 * warm) segs--;
     if (const int v = llzs_tune(LLZS_TUNE_IIR_SEGS); v >= 1 && v <= 64) segs = v;
+    while (segs > 1 && nchunks / segs < warm_chunks) segs--;        // (a forced count too: a segment must hold its own warm-up,
+                                                                    //  or its first chunk would lie in front of the row)
     const int seg_chunks = (nchunks + segs - 1) / segs;
     segs = (nchunks + seg_chunks - 1) / seg_chunks;
     const long items = (long)channels * segs;

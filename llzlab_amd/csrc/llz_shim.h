@@ -39,8 +39,9 @@ enum {
     LLZS_TUNE_MFMA_WG_PER_CU,
     LLZS_TUNE_FFT_GENERIC,          /* 1: staged LDS passes instead of the register transforms */
     LLZS_TUNE_IIR_SEGS,             /* time segments per channel */
-    LLZS_TUNE_IIR_UNPACKED,         /* 1: first wave-autonomous kernels (no packed arithmetic, no fetch-ahead); 2: the fetch-ahead
-                                     * kernels with 16 samples per lane only (no 32-sample forms) */
+    LLZS_TUNE_IIR_UNPACKED,         /* 2: the fetch-ahead kernels with 16 samples per lane only (no 32-sample forms); (1 selected
+                                     * the first wave-autonomous kernels, retired in round 3: profiles/r02/time_iir.txt keeps
+                                     * their numbers) */
     LLZS_TUNE_IIR_F64,              /* 1: double arithmetic whatever the noise-gain check says */
     LLZS_TUNE_IIR_PIPE,             /* 1: stage pipeline even where the wave form would be taken */
     LLZS_TUNE_IIR_WAVE_MIN_ITEMS,   /* crossover (channel, segment) item count of the wave form */

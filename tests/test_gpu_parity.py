@@ -1222,33 +1222,29 @@ def test_resample_config5_full_size_f32(dev, oracle):
     assert err <= TOL and err / float(np.sqrt(np.mean(ref ** 2))) <= TOL, err
 
 
-def test_iir_wave_first_version_kernels(dev, oracle):
-    """llz_hip_tune("iir_unpacked", 1) keeps the first wave-autonomous kernels (no one-section-ahead fetch, no packed
-    arithmetic) for A/B runs; they stay checked here"""
-    with capi.tuned(iir_unpacked=1):
-        for stages, radius, prec in ((8, 0.44, 32), (3, 0.7, 32), (8, 0.99, 64), (5, 0.97, 64)):
-            rows = []
-            for k in range(stages):
-                r, th = radius - 0.01 * k, 0.3 + 0.2 * k
-                a1, a2 = -2 * r * np.cos(th), r * r
-                rows.append([(1 + a1 + a2) / 4, (1 + a1 + a2) / 2, (1 + a1 + a2) / 4, 1.0, a1, a2])
-            coef = np.array(rows)
-            channels, n = 2048, 1024 * (256 if prec == 64 else 24) + 52
+def test_iir_forced_segment_count_is_clamped(dev, oracle):
+    """llz_hip_tune("iir_segs", n) forces the time-segment count for A/B runs; a count that would leave a segment shorter than
+    its own warm-up (its first chunk would lie in front of the row) is reduced by every launcher"""
+    rows = []
+    for k in range(8):
+        r, th = 0.99 - 0.002 * k, 0.3 + 0.2 * k
+        a1, a2 = -2 * r * np.cos(th), r * r
+        rows.append([(1 + a1 + a2) / 4, (1 + a1 + a2) / 2, (1 + a1 + a2) / 4, 1.0, a1, a2])
+    coef = np.array(rows)
+    channels, n = 2048, 1024 * 96
+    x = torch.empty(channels, n, dtype=torch.float32, device=dev)
+    filters.synth_f32(x, seed=11)
+    sel = [0, 1000, 2047]
+    ref = oracle.iir_cascade_batch_f32(x[sel].cpu().numpy(), coef)
+    for tuned in ({"iir_segs": 64}, {"iir_segs": 64, "iir_unpacked": 2}, {"iir_segs": 64, "iir_pipe": 1}):
+        with capi.tuned(**tuned):
             f = filters.IirCascadeMC(channels, coef)
-            assert f.precision == prec, (stages, radius, f.precision)
-            sel = [0, 1000, 2047]
-            xs, ys = [], []
-            for call in range(2):
-                x = torch.empty(channels, n, dtype=torch.float32, device=dev)
-                filters.synth_f32(x, seed=90 + call)
-                y = torch.empty_like(x)
-                f.filter(x, y)
-                xs.append(x[sel].cpu().numpy()); ys.append(y[sel].cpu().numpy())
+            y = torch.empty_like(x)
+            f.filter(x, y)
             f.close()
-            ref = oracle.iir_cascade_batch_f32(np.concatenate(xs, axis=1), coef)
-            got = np.concatenate(ys, axis=1).astype(np.float64)
-            err, scale = float(np.sqrt(np.mean((got - ref) ** 2))), float(np.sqrt(np.mean(ref ** 2)))
-            assert err <= 1e-5 * max(1.0, scale) and err / scale <= 1e-5, (stages, radius, err, scale)
+        got = y[sel].cpu().numpy().astype(np.float64)
+        err, scale = float(np.sqrt(np.mean((got - ref) ** 2))), float(np.sqrt(np.mean(ref ** 2)))
+        assert err <= TOL * max(1.0, scale) and err / scale <= TOL, (tuned, err, scale)
 
 
 @pytest.mark.parametrize("segs", [2, 5, 16])
