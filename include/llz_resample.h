@@ -39,12 +39,15 @@ enum { LLZ_PCM_F32 = 0, LLZ_PCM_I16 = 1, LLZ_PCM_I16_FAST = 2 };
 
 /* Same prototype design, tap matrix g[l][k] = L*h[kL + (lM mod L)] and indexing as llz_resample
  * (llz_resample.c:193-255, 583-603):  y[i] = gain * sum_{k<Q} x[(i*M)/L - k] * g[i mod L][k].
- * LLZ_PCM_I16: double accumulate, clamp, truncate (bit-exact with the reference per channel).
+ * LLZ_PCM_I16: the reference's own format and result, bit for bit per channel (double accumulate in its order, clamp,
+ *   truncate).  Computed by an exact integer screen on the int8 matrix cores that decides every output whose value does not
+ *   lie within ~1e-5 of an integer, and by the reference's double loop for the rest (any L/M; the all-double kernel where the
+ *   taps or the frame do not suit the screen).
  * LLZ_PCM_F32: float32 in/out, float accumulate, no clamp.
  * LLZ_PCM_I16_FAST: int16 in/out like LLZ_PCM_I16 (same clamp and truncation) but the sum runs in float32 on the matrix
  *   cores: a sample differs from the reference by at most one LSB (when its exact value lies within ~0.01 of an integer),
- *   RMS deviation <= 1e-5 of full scale; about 9x the throughput of the exact form.  Decimators only (L == 1); init
- *   fails otherwise. */
+ *   RMS deviation <= 1e-5 of full scale.  Decimators only (L == 1); init fails otherwise.  (Since round 3 the bit-exact
+ *   LLZ_PCM_I16 form is the faster of the two on BASELINE config 5.) */
 unsigned long llz_resample_mc_init(int channels, int L, int M, double gain, win_t win_type, int pcm_format);
 void          llz_resample_mc_uninit(unsigned long handle);
 int  llz_resample_mc_sub_len(unsigned long handle);                 /* Q */
