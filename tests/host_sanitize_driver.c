@@ -74,6 +74,17 @@ int main(void)
     CHECK(llz_iir_cascade_mc(h, fx, fy, 1) == 1);
     llz_iir_cascade_mc_uninit(h);
     CHECK(llz_iir_cascade_mc_init(5, 0, &coef[0][0]) == BAD);
+    {   /* general direct form I for many channels: orders 3 / 3, streamed, flush; order 9 refused */
+        double a3[4] = {1, -0.3695, 0.1958, 0}, b3[4] = {1.0, 0.2066, 0.4131, 0.2066};
+        h = llz_iir_mc_init(6, 3, a3, 3, b3); CHECK(h != BAD);
+        CHECK(llz_iir_mc(h, fx, fy, 2000) == 2000 && llz_iir_mc(h, fx, fy, 17) == 17);
+        CHECK(llz_iir_mc_flush(h, fy) == 3);
+        CHECK(llz_iir_mc(h, fx, fx, 10) < 0);
+        llz_iir_mc_uninit(h);
+        double a9[10] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0.1};
+        CHECK(llz_iir_mc_init(2, 9, a9, 0, b3) == BAD);
+        h = llz_iir_mc_init(2, 2, a3, 0, NULL); CHECK(h != BAD); CHECK(llz_iir_mc_flush(h, fy) == 0); llz_iir_mc_uninit(h);
+    }
     {   /* eight high-Q sections: double arithmetic with the folded-gain tables of the 32-sample kernel; a zero b0: no folding */
         double hq[8][6];
         for (int s = 0; s < 8; s++) { hq[s][0] = 0.01; hq[s][1] = 0; hq[s][2] = -0.01; hq[s][3] = 1; hq[s][4] = -1.89 + 0.01 * s; hq[s][5] = 0.9801; }

@@ -52,6 +52,7 @@ int llzs_tables_broadcast(llzs_table_ref *const *t, int nt, int ns, const int *d
 }
 int llzs_resample_mfma_f32_table_steps(int L, int M, int Q) { (void)L; (void)M; (void)Q; return 16; }
 int llzs_resample_i16x_ksteps(int L, int M, int Q) { (void)L; (void)M; (void)Q; return 4; }
+int llzs_iir_df1_mc_max_order(void) { return 8; }
 '''
 
 
