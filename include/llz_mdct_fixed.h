@@ -26,7 +26,7 @@ void          llz_mdct_fixed_uninit(unsigned long handle);
 void          llz_mdct_fixed(unsigned long handle, int *x, int *X);      /* x: len -> X: len/2 */
 void          llz_imdct_fixed(unsigned long handle, int *X, int *x);     /* X: len/2 -> x: len */
 
-/* ---- batch extension: `count` frames per call (1..65535), rows contiguous: x [count][len], X [count][len/2].
+/* ---- batch extension: `count` frames per call, rows contiguous: x [count][len], X [count][len/2].
  * Host or device pointers (device pointers are used in place, asynchronously on the handle's stream); out of place.
  * Returns count, or a negative LLZ_ERR_* code. ---- */
 int           llz_mdct_fixed_batch(unsigned long handle, const int *x, int *X, int count);

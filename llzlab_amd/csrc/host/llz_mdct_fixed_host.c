@@ -211,8 +211,8 @@ static int mdcx_on_device(mdcx_t *f, const int *d_src, int *d_dst, int count, in
 
 static int mdcx_run(unsigned long handle, const int *in, int *out, int count, int inverse, const char *who)
 {
-    if (!LLZ_HANDLE_OK(handle, mdcx_t, LLZ_TAG_MDCX) || !in || !out || in == out || count < 1 || count > 65535) {
-        llzs_set_error("%s: bad handle or arguments (1..65535 frames per call, out of place)", who);
+    if (!LLZ_HANDLE_OK(handle, mdcx_t, LLZ_TAG_MDCX) || !in || !out || in == out || count < 1) {
+        llzs_set_error("%s: bad handle or arguments (at least one frame, out of place)", who);
         return LLZ_ERR_ARG;
     }
     mdcx_t *f = (mdcx_t *)handle;
@@ -231,7 +231,12 @@ static int mdcx_run(unsigned long handle, const int *in, int *out, int count, in
         d_out = (int *)llz_stage_reserve(inverse ? &f->time : &f->bins, ob);
         if (!d_out) rc = LLZ_ERR_NOMEM;
     }
-    if (rc == LLZ_OK) rc = mdcx_on_device(f, d_in, d_out, count, inverse);
+    /* (a launch takes at most 65535 frames: the frame index is the grid's second dimension) */
+    for (int done = 0; rc == LLZ_OK && done < count; done += 65535) {
+        const int part = count - done < 65535 ? count - done : 65535;
+        const size_t n_in = inverse ? (size_t)f->length / 2 : (size_t)f->length, n_out = inverse ? (size_t)f->length : (size_t)f->length / 2;
+        rc = mdcx_on_device(f, d_in + (size_t)done * n_in, d_out + (size_t)done * n_out, part, inverse);
+    }
     if (rc == LLZ_OK && !out_dev) rc = llzs_d2h(out, d_out, ob, f->stream);
     llzs_device_leave(prev);
     return rc == LLZ_OK ? count : rc;

@@ -206,3 +206,18 @@ if "mdct" in which:
               f"synthesis {ms_s:.3f} ms {gb / ms_s / 1e6:.0f} GB/s ({gb / ms_s / 1e6 / 80:.1f} %)")
         q.close()
         del x, X
+
+if "mdctq" in which:
+    # fixed-point MDCT batch (int32 data, Q15 tables, bit-exact): 4 B per sample in + 2 B per sample out forward, the reverse inverse
+    for t, n, count in ((2, 256, 1 << 16), (2, 2048, 1 << 15), (2, 8192, 1 << 13), (1, 2048, 1 << 14)):
+        x = torch.randint(-(1 << 20), 1 << 20, (count, n), dtype=torch.int32, device=dev)
+        X = torch.empty(count, n // 2, dtype=torch.int32, device=dev)
+        q = filters.MdctFixed(t, n)
+        q.set_stream(stream)
+        ms_f = timeit(lambda: q.forward_batch(x, X), 5)
+        ms_i = timeit(lambda: q.inverse_batch(X, x), 5)
+        gb = 6 * count * n
+        print(f"mdct fixed type {t} N={n} x {count}: forward {ms_f:.3f} ms {gb / ms_f / 1e6:.0f} GB/s ({gb / ms_f / 1e6 / 80:.1f} %), "
+              f"inverse {ms_i:.3f} ms {gb / ms_i / 1e6:.0f} GB/s ({gb / ms_i / 1e6 / 80:.1f} %)")
+        q.close()
+        del x, X
