@@ -195,6 +195,9 @@ static int mdcx_on_device(mdcx_t *f, const int *d_src, int *d_dst, int count, in
         return inverse ? llzs_mdctq_sums(f->d_sum_inv, d_src, d_dst, count, N, K, N, f->stream)
                        : llzs_mdctq_sums(f->d_sum_fwd, d_src, d_dst, count, K, N, 0, f->stream);
     const int quarter = f->form == MDCT_FIXED_FFT4;
+    if (quarter && N >= 8 && N <= 16384 && llzs_tune(LLZS_TUNE_MDCTQ_STEPS) < 1)   /* one launch, the frame in and out of HBM once */
+        return llzs_mdct4_q15(d_src, d_dst, count, N, f->d_step[inverse ? STEP_INV_PRE : STEP_FWD_PRE],
+                              f->d_step[inverse ? STEP_INV_POST : STEP_FWD_POST], f->d_fft_cs, inverse, f->cof, f->stream);
     int *d_work = (int *)llz_stage_reserve(&f->work, sizeof(int) * 2 * (size_t)f->fft_size * (size_t)count);
     if (!d_work) return LLZ_ERR_NOMEM;
     /* the N-point form inverts with the inverse transform (llz_mdct_fixed.c:190); the N/4-point form runs the FORWARD

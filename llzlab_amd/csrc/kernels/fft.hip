@@ -1294,10 +1294,12 @@ struct mdct_fr {
     float *state_out;          // [channels][F], not the same buffer
     int frames;                // frames per channel in this call
     int first, step;           // this launch: frames first, first + step, ...
-    int per_channel;           // how many of them per channel
+    int per_channel;           // how many of them (FR = 2: how many runs) per channel
+    int run;                   // FR = 2: output segments per group
 };
 
-template <int E, bool TWO, bool INVERSE, bool FRAMES>
+// FR: 0 plain batch, 1 frames (a group per frame), 2 frames, inverse only: a group per RUN of consecutive segments
+template <int E, bool TWO, bool INVERSE, int FR>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((E == 32 && TWO && !INVERSE) ? 2 : 1)))
 k_mdct_reg_f32(const float *__restrict__ in, float *__restrict__ out, int count, const float *__restrict__ tc,
                const float *__restrict__ ts, const float2 *__restrict__ tw2d, const float2 *__restrict__ tw1,
@@ -1306,6 +1308,9 @@ k_mdct_reg_f32(const float *__restrict__ in, float *__restrict__ out, int count,
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int H = E * E, N4 = TWO ? 2 * H : H, N = 4 * N4, N2 = N / 2, GROUPS = 256 / E, PITCH = E + 1;
+    constexpr bool FRAMES = FR != 0, RUN = FR == 2;
+    constexpr int VW = TWO ? 4 : 2;                                 // floats per lane and store of the inverse's output
+    static_assert(!RUN || INVERSE, "runs of segments are a synthesis form");
     __shared__ float bufs[GROUPS][E * PITCH];
     // FRAMES: the window in LDS, one copy for the workgroup's frames (through the vector memory path it was one load per
     // signal load)
@@ -1320,9 +1325,27 @@ k_mdct_reg_f32(const float *__restrict__ in, float *__restrict__ out, int count,
     const float *x;
     float *y;
     int fc = 0, ff = 0;                                            // FRAMES: channel and frame of this block
-    if constexpr (FRAMES) {
+    int s0 = 0, f_end = 0;                                         // RUN: segments s0 .. f_end - 1 are this group's
+    float tail[RUN ? N2 / E : 1];                                  // RUN: the previous frame's windowed second half, in the
+                                                                   // lane's own store layout (VW floats per VW E outputs)
+    if constexpr (RUN) {
         fc = (int)(t / fr.per_channel);
-        ff = fr.first + fr.step * (int)(t - (long)fc * fr.per_channel);
+        s0 = fr.run * (int)(t - (long)fc * fr.per_channel);
+        f_end = min(s0 + fr.run, fr.frames);
+        ff = s0 ? s0 - 1 : 0;                                      // the frame in front is transformed again for its tail
+        const float *prev = fr.state_in + (size_t)fc * N2;         // segment 0 starts from the previous call's tail
+#pragma unroll
+        for (int i = 0; i < N2 / E; i += VW) {
+#pragma unroll
+            for (int c = 0; c < VW; c++) tail[i + c] = s0 ? 0.f : prev[i * E + VW * lg + c];
+        }
+    }
+    for (;;) {                                                      // (one trip unless RUN)
+    if constexpr (FRAMES) {
+        if constexpr (!RUN) {
+            fc = (int)(t / fr.per_channel);
+            ff = fr.first + fr.step * (int)(t - (long)fc * fr.per_channel);
+        }
         const size_t sig = (size_t)fc * fr.frames * N2;            // the channel's signal: frames * F samples, F = N2
         if (!INVERSE) {
             x = in + sig + (long)(ff - 1) * N2;                    // xbuf[i] = x[i] (frame 0: i < F comes from the state)
@@ -1428,7 +1451,23 @@ k_mdct_reg_f32(const float *__restrict__ in, float *__restrict__ out, int count,
     auto put = [&](int jb, int lane_off, auto v) {
         typedef decltype(v) vec;
         const int j = jb + lane_off;
-        if constexpr (FRAMES && INVERSE) {
+        if constexpr (RUN) {
+            // first halves are finished with the tail of the frame before; second halves become the tail.  (The caller puts
+            // j < N/2 before j + N/2: they share the tail's slot.)
+            constexpr int W = sizeof(vec) / sizeof(float);
+            v *= *reinterpret_cast<const vec *>(s_win + j);
+            const int slot = (jb & (N2 - 1)) / E;                    // = (jb / (W E)) W: a constant after unrolling
+            if (jb >= N2) {
+                if (last) *reinterpret_cast<vec *>(st_out + j - N2) = v;
+#pragma unroll
+                for (int c = 0; c < W; c++) tail[slot + c] = v[c];
+            } else if (ff >= s0) {
+#pragma unroll
+                for (int c = 0; c < W; c++) v[c] += tail[slot + c];
+                *reinterpret_cast<vec *>(y + j) = v;
+            }
+            return;
+        } else if constexpr (FRAMES && INVERSE) {
             v *= *reinterpret_cast<const vec *>(s_win + j);
             if (jb >= N2) {
                 if (last) {
@@ -1450,6 +1489,15 @@ k_mdct_reg_f32(const float *__restrict__ in, float *__restrict__ out, int count,
     auto unrot4 = [&](int rb, int lane_off, float v0, float v1, float v2, float v3) {
         if (rb >= N4) put(rb - N4, lane_off, (f32x4){v0, v1, v2, v3} * sqrt_cof);
         else put(rb + 3 * N4, lane_off, (f32x4){v0, v1, v2, v3} * -sqrt_cof);
+    };
+    // rot[b ...] and rot[N/2 + b ...] land half a frame apart: RUN needs the one in the first half put first
+    auto both2 = [&](int b, float a0, float a1, float c0, float c1) {
+        if (RUN && b < N4) { unrot2(N2 + b, 2 * lg, c0, c1); unrot2(b, 2 * lg, a0, a1); }
+        else { unrot2(b, 2 * lg, a0, a1); unrot2(N2 + b, 2 * lg, c0, c1); }
+    };
+    auto both4 = [&](int b, f32x4 a, f32x4 c) {
+        if (RUN && b < N4) { unrot4(N2 + b, 4 * lg, c.x, c.y, c.z, c.w); unrot4(b, 4 * lg, a.x, a.y, a.z, a.w); }
+        else { unrot4(b, 4 * lg, a.x, a.y, a.z, a.w); unrot4(N2 + b, 4 * lg, c.x, c.y, c.z, c.w); }
     };
 #pragma unroll
     for (int q = 0; q < E; q++) {
@@ -1477,21 +1525,20 @@ k_mdct_reg_f32(const float *__restrict__ in, float *__restrict__ out, int count,
                 const cf pa = post(kq, s[q]), pb = post(km, s[qm]);
                 const float ia = mir(pb.y), ra = mir(pb.x), ib = mir(pa.y), rb = mir(pa.x);
                 const int bq = 2 * E * brevE<E>(q), bm = 2 * E * brevE<E>(qm);    // constants after unrolling
-                unrot2(bq, 2 * lg, g * pa.x, -g * ia);
-                unrot2(N2 + bq, 2 * lg, g * pa.y, -g * ra);
-                unrot2(bm, 2 * lg, g * pb.x, -g * ib);
-                unrot2(N2 + bm, 2 * lg, g * pb.y, -g * rb);
+                both2(bq, g * pa.x, -g * ia, g * pa.y, -g * ra);
+                both2(bm, g * pb.x, -g * ib, g * pb.y, -g * rb);
             } else {
                 const cf sa = post(2 * kq, s[q]), da = post(2 * kq + 1, d[q]), sb = post(2 * km, s[qm]), db = post(2 * km + 1, d[qm]);
                 const float dbi = mir(db.y), dbr = mir(db.x), sbi = mir(sb.y), sbr = mir(sb.x);
                 const float dai = mir(da.y), dar = mir(da.x), sai = mir(sa.y), sar = mir(sa.x);
                 const int bq = 4 * E * brevE<E>(q), bm = 4 * E * brevE<E>(qm);
-                unrot4(bq, 4 * lg, g * sa.x, -g * dbi, g * da.x, -g * sbi);
-                unrot4(N2 + bq, 4 * lg, g * sa.y, -g * dbr, g * da.y, -g * sbr);
-                unrot4(bm, 4 * lg, g * sb.x, -g * dai, g * db.x, -g * sai);
-                unrot4(N2 + bm, 4 * lg, g * sb.y, -g * dar, g * db.y, -g * sar);
+                both4(bq, (f32x4){g * sa.x, -g * dbi, g * da.x, -g * sbi}, (f32x4){g * sa.y, -g * dbr, g * da.y, -g * sbr});
+                both4(bm, (f32x4){g * sb.x, -g * dai, g * db.x, -g * sai}, (f32x4){g * sb.y, -g * dar, g * db.y, -g * sar});
             }
         }
+    }
+    if constexpr (!RUN) break;
+    else if (++ff >= f_end) break;
     }
 }
 
@@ -1691,9 +1738,12 @@ static int mdct_reg_launch(const float *in, float *out, int count, int N, const 
     const mdct_fr fr = frp ? *frp : mdct_fr{};
 #define LLZ_MDCT_LAUNCH(EE, TT, II)                                                                                  \
     do {                                                                                                             \
-        if (frp) hipLaunchKernelGGL((k_mdct_reg_f32<EE, TT, II, true>), dim3(blocks), dim3(256), 0, as_stream(stream), in, \
-                                    out, count, tc, ts, tw2d, tw1, sqrt_cof, fr);                                    \
-        else hipLaunchKernelGGL((k_mdct_reg_f32<EE, TT, II, false>), dim3(blocks), dim3(256), 0, as_stream(stream), in, \
+        if (frp && frp->run > 0)                                                                                     \
+            hipLaunchKernelGGL((k_mdct_reg_f32<EE, TT, II, (II && (EE == 8 || (EE == 16 && !TT))) ? 2 : 1>), dim3(blocks), dim3(256), 0,        \
+                               as_stream(stream), in, out, count, tc, ts, tw2d, tw1, sqrt_cof, fr);                  \
+        else if (frp) hipLaunchKernelGGL((k_mdct_reg_f32<EE, TT, II, 1>), dim3(blocks), dim3(256), 0, as_stream(stream), in, \
+                                         out, count, tc, ts, tw2d, tw1, sqrt_cof, fr);                               \
+        else hipLaunchKernelGGL((k_mdct_reg_f32<EE, TT, II, 0>), dim3(blocks), dim3(256), 0, as_stream(stream), in,    \
                                 out, count, tc, ts, tw2d, tw1, sqrt_cof, fr);                                        \
     } while (0)
 #define LLZ_MDCT_PICK(EE)                                                                                            \
@@ -1728,10 +1778,23 @@ extern "C" int llzs_mdct4_frames_f32(const float *in, float *out, int channels, 
         return LLZ_ERR_ARG;
     }
     mdct_fr fr;
-    fr.win = win; fr.state_in = state_in; fr.state_out = state_out; fr.frames = frames;
+    fr.win = win; fr.state_in = state_in; fr.state_out = state_out; fr.frames = frames; fr.run = 0;
     if (!inverse) {
         fr.first = 0; fr.step = 1; fr.per_channel = frames;
         return mdct_reg_launch(in, out, channels * frames, N, tc, ts, cs, 0, stream, &fr);
+    }
+    // A group per run of consecutive segments (frame lengths up to 512: the tail lives in registers; at 1024 the kernel needs
+    // all 256 VGPRs and loses to the two launches, 1.03 against 0.92 ms): every output is written
+    // once, finished; the frame in front of a run is transformed a second time for its tail, so runs are as long as the
+    // machine stays filled with (about 64 K groups), at most 16.  Short problems keep the two launches below.
+    int run = llzs_tune(LLZS_TUNE_MDCT_RUN);
+    if (run < 0) {
+        const long all = (long)channels * frames;
+        run = all >= 4 * 65536 ? (int)(all / 65536 > 16 ? 16 : all / 65536) : 0;
+    }
+    if (run > 0 && N <= 1024) {
+        fr.first = 0; fr.step = 1; fr.run = run; fr.per_channel = (frames + run - 1) / run;
+        return mdct_reg_launch(in, out, channels * fr.per_channel, N, tc, ts, cs, 1, stream, &fr);
     }
     fr.first = 0; fr.step = 2; fr.per_channel = (frames + 1) / 2;
     int rc = mdct_reg_launch(in, out, channels * fr.per_channel, N, tc, ts, cs, 1, stream, &fr);

@@ -236,6 +236,16 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         return any;
     };
 
+    // start values of the accumulators (screen_i8.hpp: the bias and the 2^31 offset ride along in the first products)
+    i32x4 start[3];
+    {
+        int s0, s2, s4;
+        scr_start(pr.bq_lo, pr.bq_hi, s0, s2, s4);
+        start[0] = (i32x4){s0, s0, s0, s0};
+        start[1] = (i32x4){s2, s2, s2, s2};
+        start[2] = (i32x4){s4, s4, s4, s4};
+    }
+
     // back half: products, decisions, stores; returns the number of store instructions issued per lane (for the wait count)
     auto finish = [&](int t, long ooff, int any) {
         const long o0 = (long)t * TILE_OUT;
@@ -243,9 +253,7 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         const bool whole = aligned_out && o0 + TILE_OUT <= n_out;
         auto store4 = [&](int a, const int (&r4)[4]) {
             const int oo = ((wave * NACC + a) * 16 + seg) * 16 + 4 * kq;        // first of this lane's 4 outputs of block a
-            i16x4 y;
-#pragma unroll
-            for (int j = 0; j < 4; j++) y[j] = scr_clamp(r4[j]);
+            const i16x4 y = scr_clamp4(r4);
             if (whole) {
                 *reinterpret_cast<i16x4 *>(otile + oo) = y;
             } else {
@@ -285,8 +293,9 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
                         for (int a = 0; a < NACC; a++) {
                             if (d == 0 && p == 0) continue;          // low sample digit x lowest tap digit: not formed (inside eps)
                             // accumulator p + d - 1; in this order (p, d = 1) is always its first visitor
+                            // (and starts it: from scr_start's values for accumulators 0, 2, 4, from the constant 0 otherwise)
                             const bool fresh = decltype(first_step)::value && d == 1;
-                            const i32x4 c0 = fresh ? (i32x4){0, 0, 0, 0} : acc[a][p + d - 1];
+                            const i32x4 c0 = !fresh ? acc[a][p + d - 1] : ((p & 1) ? (i32x4){0, 0, 0, 0} : start[p >> 1]);
                             acc[a][p + d - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ad[p], bd[a][d], c0, 0, 0, 0);
                         }
             };
@@ -297,17 +306,22 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         // every output decided without a branch; a lane notes the slots it could not decide in a bit mask, and the rare lanes
         // that have any (about 2 eps of all outputs: most tiles have none) work them off one by one afterwards
         int res[NACC][4];
-        unsigned mine = 0;
+        bool unsure[NACC][4];
+        unsigned long long open = 0;                                // lanes with an undecided slot (a scalar mask)
 #pragma unroll
         for (int a = 0; a < NACC; a++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                bool unsure;
-                res[a][j] = scr_decide<NEG>(acc[a][0][j], acc[a][1][j], acc[a][2][j], acc[a][3][j], acc[a][4][j], pr.bq_lo, pr.bq_hi,
-                                            pr.rs, pr.e32, unsure);
-                mine = mine + mine + (unsure ? 1u : 0u);            // slot 4 a + j ends up at bit 4 NACC - 1 - (4 a + j)
+                res[a][j] = scr_decide<NEG>(acc[a][0][j], acc[a][1][j], acc[a][2][j], acc[a][3][j], acc[a][4][j], pr.rs, pr.e32,
+                                            unsure[a][j]);
+                open |= __ballot(unsure[a][j]);
             }
-        if (__ballot(mine != 0) != 0) {
+        if (open != 0) {
+            unsigned mine = 0;
+#pragma unroll
+            for (int a = 0; a < NACC; a++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) mine = mine + mine + (unsure[a][j] ? 1u : 0u);    // slot 4 a + j at bit 4 NACC - 1 - (4 a + j)
 #pragma unroll 1
             while (mine != 0) {
                 // an integer within eps of the value: the reference's own arithmetic decides, in the lane that found it

@@ -12,11 +12,13 @@
 //  k_mdctq_demodulate  MDCT_FIXED_FFT, behind it: rotate a bin, keep the real part
 //  k_mdctq_fold        MDCT_FIXED_FFT4, in front of the N/4-point transform: fold the frame to N/4 points, rotate, halve
 //  k_mdctq_unfold      MDCT_FIXED_FFT4, behind it: rotate and scatter (forward) / rebuild the time frame (inverse)
+//  k_mdct4_q15         MDCT_FIXED_FFT4 in ONE launch: fold, the N/4-point Q15 transform and unfold in LDS (rows in, rows out)
 #include "common.hpp"
+#include "fft_core.hpp"
 
 namespace {
 
-__device__ __forceinline__ int q15(int a, int b) { return (int)(((long long)a * (long long)b) >> 15); }
+__device__ __forceinline__ int q15(int a, int b) { return arith_q15::mul15(a, (short)b); }     // (b: a Q15 table value)
 __device__ __forceinline__ int wrap_add(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
 __device__ __forceinline__ int wrap_sub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
 __device__ __forceinline__ int wrap_neg(int a) { return (int)(0u - (unsigned)a); }
@@ -127,7 +129,149 @@ k_mdctq_unfold(const int *__restrict__ z, int *__restrict__ out, const short2 *_
     out[(size_t)blockIdx.y * N + t] = t < 3 * N4 ? q15(r_at(N4 + t), cof) : q15(wrap_neg(r_at(t - 3 * N4)), cof);
 }
 
+// MDCT_FIXED_FFT4 whole (llz_mdct_fixed.c:200-283): a workgroup takes tpw frames, brings their rows into LDS with full-line
+// reads, folds and rotates them into the transform's LDS image (k_mdctq_fold's expressions), runs the radix-2 passes of the
+// bit-exact Q15 transform (fft_core.hpp: every butterfly is the reference's butterfly), rotates the bins and scatters them
+// into output rows in LDS (k_mdctq_unfold's expressions, one rotation per bin instead of one per output), and writes the rows
+// with full-line stores.  HBM sees the frame once in and the result once out: 6 B per sample against 14 with three launches.
+//   forward: in = x [count][N], out = X [count][N/2];   inverse: in = X [count][N/2], out = x [count][N]
+// pre / post: the two rotation tables of this direction (N/4 short2 each); cs: the transform's table (N/4 cos, N/4 sin).
+template <bool INVERSE>
+__global__ void __launch_bounds__(FFT_THREADS)
+k_mdct4_q15(const int *__restrict__ in, int *__restrict__ out, int count, int N, int log2n4,
+            const short2 *__restrict__ pre, const short2 *__restrict__ post, const short *__restrict__ cs, int tpw,
+            unsigned groups, int cof)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int N2 = N >> 1, N4 = N >> 2;
+    const int tstride = fft_phys(N4) + 1;
+    cpx<int> *s = reinterpret_cast<cpx<int> *>(smem_raw);
+    cpx<short> *tw = reinterpret_cast<cpx<short> *>(s + (size_t)tpw * tstride);
+    int *buf = reinterpret_cast<int *>(tw + tw_entries(N4) + (tw_entries(N4) & 1));      // [tpw][N] rows
+    const int tid = threadIdx.x;
+    const int tr0 = blockIdx.x * tpw;
+    const int ntr = min(tpw, count - tr0);
+    const int in_len = INVERSE ? N2 : N, out_len = INVERSE ? N : N2;
+    fft_load_twiddles(tw, cs, N4, tid);
+    {
+        const int *src = in + (size_t)tr0 * in_len;                       // the workgroup's rows are one contiguous range
+        const int total = ntr * in_len;
+        if (in_len == N) {
+            for (int e = tid; e < total; e += FFT_THREADS) buf[e] = src[e];
+        } else {
+            for (int e = tid; e < total; e += FFT_THREADS) buf[((e >> (log2n4 + 1)) << (log2n4 + 2)) + (e & (N2 - 1))] = src[e];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < ntr * N4; e += FFT_THREADS) {
+        const int tr = e >> log2n4, k = e & (N4 - 1);
+        const int *x = buf + tr * N;
+        int re, im;
+        if (!INVERSE) {
+            auto turned = [&](int i) { return i < N4 ? wrap_neg(x[i + 3 * N4]) : x[i - N4]; };
+            re = wrap_sub(turned(2 * k), turned(N - 1 - 2 * k));
+            im = wrap_sub(turned(N2 - 1 - 2 * k), turned(N2 + 2 * k));
+        } else {
+            re = x[2 * k];
+            im = x[N2 - 1 - 2 * k];
+        }
+        int zr, zi;
+        q15_rotate(re, im, pre[k], &zr, &zi);
+        cpx<int> z;
+        z.re = zr >> 1;
+        z.im = zi >> 1;
+        s[tr * tstride + fft_phys(k)] = z;
+    }
+    __syncthreads();
+    {
+        int done = 0;                                                     // (both directions run the FORWARD transform)
+#pragma unroll 1
+        for (int p = 0; p < 4; p++) {
+            const int G = (groups >> (4 * p)) & 15;
+            if (G == 0) break;
+            const int log2step = log2n4 - done - G;
+            switch (G) {
+            case 1: fft_pass<arith_q15, 1, false>(s, ntr, N4, log2n4, log2step, tstride, tw, tid); break;
+            case 2: fft_pass<arith_q15, 2, false>(s, ntr, N4, log2n4, log2step, tstride, tw, tid); break;
+            case 3: fft_pass<arith_q15, 3, false>(s, ntr, N4, log2n4, log2step, tstride, tw, tid); break;
+            default: fft_pass<arith_q15, 4, false>(s, ntr, N4, log2n4, log2step, tstride, tw, tid); break;
+            }
+            done += G;
+        }
+    }
+    for (int e = tid; e < ntr * N4; e += FFT_THREADS) {
+        const int tr = e >> log2n4, m = e & (N4 - 1);
+        const cpx<int> v = s[tr * tstride + fft_phys((int)(__brev((unsigned)m) >> (32 - log2n4)))];   // bin m
+        int zr, zi;
+        q15_rotate(v.re, v.im, post[m], &zr, &zi);
+        int *y = buf + tr * N;
+        if (!INVERSE) {
+            y[2 * m] = wrap_scale(zr, 2);
+            y[N2 - 1 - 2 * m] = wrap_scale(zi, -2);
+        } else {
+            // the turned sequence r of k_mdctq_unfold: r[2m] = re8, r[N/2 + 2m] = im8, odd entries mirror the even ones with
+            // the sign flipped; x[i] = q15(r[N/4 + i], cof) for i < 3N/4, q15(-r[i - 3N/4], cof) behind
+            const int re8 = wrap_scale(q15(zr, cof), 8), im8 = wrap_scale(q15(zi, cof), 8);
+            auto put = [&](int ri, int val) {
+                if (ri >= N4) y[ri - N4] = q15(val, cof);
+                else y[ri + 3 * N4] = q15(wrap_neg(val), cof);
+            };
+            put(2 * m, re8);
+            put(N - 1 - 2 * m, wrap_neg(re8));
+            put(N2 + 2 * m, im8);
+            put(N2 - 1 - 2 * m, wrap_neg(im8));
+        }
+    }
+    __syncthreads();
+    {
+        int *dst = out + (size_t)tr0 * out_len;
+        const int total = ntr * out_len;
+        if (out_len == N) {
+            for (int e = tid; e < total; e += FFT_THREADS) dst[e] = buf[e];
+        } else {
+            for (int e = tid; e < total; e += FFT_THREADS) dst[e] = buf[((e >> (log2n4 + 1)) << (log2n4 + 2)) + (e & (N2 - 1))];
+        }
+    }
+}
+
 } // namespace
+
+// MDCT_FIXED_FFT4 in one launch; N a power of two in 8..16384; pre / post: N/4 (cos, sin) Q15 pairs; cs: the N/4-point
+// transform's table
+extern "C" int llzs_mdct4_q15(const int *in, int *out, int count, int N, const short *pre, const short *post,
+                              const short *cs, int inverse, int cof, void *stream)
+{
+    int log2n = 0;
+    while ((1 << log2n) < N) log2n++;
+    if (!in || !out || !pre || !post || !cs || count < 1 || N < 8 || N > 16384 || (1 << log2n) != N) {
+        llzs_set_error("mdct4_q15: bad arguments (N=%d must be a power of two in 8..16384, count=%d)", N, count);
+        return LLZ_ERR_ARG;
+    }
+    const int N4 = N >> 2, log2n4 = log2n - 2;
+    int tpw = 2048 / N4;
+    if (tpw < 1) tpw = 1;
+    if (tpw > count) tpw = count;
+    const int tstride = N4 + (N4 >> 5) + 1;
+    const int twe = tw_entries(N4) + (tw_entries(N4) & 1);
+    const size_t lds = (size_t)tpw * tstride * 2 * sizeof(int) + (size_t)twe * 2 * sizeof(short) + (size_t)tpw * N * sizeof(int);
+    const unsigned blocks = (unsigned)((count + tpw - 1) / tpw);
+    const short2 *p2 = reinterpret_cast<const short2 *>(pre), *q2 = reinterpret_cast<const short2 *>(post);
+    if (inverse) {
+        if (lds >= 64 * 1024)
+            LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mdct4_q15<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_mdct4_q15<true>, dim3(blocks), dim3(FFT_THREADS), lds, as_stream(stream), in, out, count, N,
+                           log2n4, p2, q2, cs, tpw, fft_groups(log2n4), cof);
+    } else {
+        if (lds >= 64 * 1024)
+            LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mdct4_q15<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_mdct4_q15<false>, dim3(blocks), dim3(FFT_THREADS), lds, as_stream(stream), in, out, count, N,
+                           log2n4, p2, q2, cs, tpw, fft_groups(log2n4), cof);
+    }
+    LLZ_LAUNCH_CHECK("k_mdct4_q15");
+    return LLZ_OK;
+}
 
 extern "C" int llzs_mdctq_sums(const short *A, const int *x, int *y, int count, int rows, int cols, int quarter_over_n,
                                void *stream)

@@ -25,6 +25,20 @@
 #include "screen_i8.hpp"
 #include <math.h>
 
+// RI_TRACE (a measurement build only: tools/ubench/Makefile): shader-clock time of each phase of the span loop, summed per wave
+#ifdef RI_TRACE
+__device__ unsigned long long ri_trace_buf[65536 * 10];
+#define RI_T0() unsigned long long ri_t = __builtin_readcyclecounter(), ri_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned ri_cnt[2] = {0, 0}
+#define RI_MARK(i) do { const unsigned long long now = __builtin_readcyclecounter(); ri_acc[i] += now - ri_t; ri_t = now; } while (0)
+#define RI_DUMP() do { if ((threadIdx.x & 63) == 0) { const unsigned w = ((blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 65535u; \
+    for (int i = 0; i < 10; i++) ri_trace_buf[w * 10 + i] = ri_acc[i]; } \
+    { unsigned total = 0; for (int l = 0; l < 64; l++) total += __shfl(ri_cnt[1], l); if ((threadIdx.x & 63) == 0) { const unsigned w = ((blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 65535u; ri_trace_buf[w * 10 + 3] = ((unsigned long long)ri_cnt[0] << 32) | total; } } } while (0)
+#else
+#define RI_T0() do { } while (0)
+#define RI_MARK(i) do { } while (0)
+#define RI_DUMP() do { } while (0)
+#endif
+
 namespace {
 
 typedef short i16x8 __attribute__((ext_vector_type(8)));
@@ -43,10 +57,12 @@ struct ri_shape {
     long spans;             // spans of a channel
     int spans_per_wg;
     int rs;                 // shift - 40
+    unsigned e32;           // ceil(eps 2^32) + 2, eps = the largest phase's bound
     double gain;
 };
 
 struct __attribute__((packed, aligned(1))) ri_b128 { scr_i32x4 v; };      // a 16-byte LDS read at any byte address
+struct __attribute__((packed, aligned(2))) ri_o64 { scr_i16x4 v; };        // an 8-byte LDS write at any even byte address
 
 // the reference's loop for one output from the planes: the sample at image position p is 256 hi[p] + lo[p] + 128
 // (taps k < k0 and k > k1 are zero: adding x * 0 = +-0 to the running sum changes nothing, bit for bit -- phase 0 of an
@@ -69,7 +85,7 @@ __device__ __forceinline__ short ri_exact(const signed char *hi, const signed ch
 }
 
 template <int KS, bool NEG, bool RELOAD>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(KS == 1 ? 1024 : 512)
 k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const short *__restrict__ hist,
                const signed char *__restrict__ atab /* [nt][KS][5][64][16] */, const int *__restrict__ aoff /* [nt] */,
                const int *__restrict__ bqtab /* [16 nt][4]: bias lo, hi; e32; first | last << 8 non-zero tap | exact << 16 */, const double *__restrict__ g /* [L][Q] */, long n_in, long n_out,
@@ -142,6 +158,7 @@ k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
     const long span0 = (long)blockIdx.x * sh.spans_per_wg;
     const long span1 = min(span0 + sh.spans_per_wg, sh.spans);
     if (span0 < span1) request(span0 * P);
+    RI_T0();
     for (long sp = span0; sp < span1; sp++) {
         const long m0 = sp * P;
         const long s0 = m0 * sh.M - sh.Hp;
@@ -163,8 +180,11 @@ k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
                 *reinterpret_cast<u32x2 *>(&xs_hi[8 * gi]) = hi;
             }
         }
+        RI_MARK(0);                                    // planes written
         if (sp + 1 < span1) request(m0 + P);
+        RI_MARK(1);                                    // next span requested
         __syncthreads();
+        RI_MARK(2);                                    // staging barrier
 
         // ---- products and decisions: this wave's phase tile(s) x the span's period tiles ----
         const long periods_left = (n_out - m0 * sh.L + sh.L - 1) / sh.L;          // periods of this span that exist
@@ -172,18 +192,22 @@ k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
             if (RELOAD) load_a(t);
             const int a_t = aoff[t];
             const int f0 = 16 * t + 4 * kq;                                       // the lane's first phase (row 4 kq) of the tile
-            int bql[4], bqh[4];
-            unsigned e32[4], never = 0;                                            // never: slots of phases that cannot be unsure
-            int krange[4];                                                         // first | last << 8 non-zero tap of the phase
+            // scr_start of the lane's four phases; lane masks of the EXACT phases, one per slot (a phase whose only tap is 1.0:
+            // its outputs are integers -- always "unsure", and not to be moved toward zero)
+            scr_i32x4 start[3];
+            unsigned long long exact[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const scr_i32x4 row4 = *reinterpret_cast<const scr_i32x4 *>(bqtab + 4 * (f0 + j));
-                bql[j] = row4[0];
-                bqh[j] = row4[1];
-                e32[j] = (unsigned)row4[2];
-                krange[j] = row4[3] & 0xffff;
-                never |= (row4[3] >> 16) ? 1u << (3 - j) : 0u;
+                int s0, s2, s4;
+                scr_start(row4[0], row4[1], s0, s2, s4);
+                start[0][j] = s0;
+                start[1][j] = s2;
+                start[2][j] = s4;
+                exact[j] = __ballot((row4[3] >> 16) != 0);
             }
+            const bool some_exact = (exact[0] | exact[1] | exact[2] | exact[3]) != 0;        // (wave-uniform)
+            RI_MARK(6);                                // per-tile constants
 #pragma unroll 1
             for (int p = 0; p < sh.pt; p++) {
                 const int col = 16 * p + col16;
@@ -193,35 +217,57 @@ k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
                 for (int s = 0; s < KS; s++) {
                     const scr_i32x4 b_lo = reinterpret_cast<const ri_b128 *>(bp + 64 * s)->v;
                     const scr_i32x4 b_hi = reinterpret_cast<const ri_b128 *>(bp + sh.plane + 64 * s)->v;
-                    if (s == 0) scr_step<true>(acc, ad[s], b_lo, b_hi);
-                    else scr_step<false>(acc, ad[s], b_lo, b_hi);
+                    if (s == 0) scr_step<true>(acc, ad[s], b_lo, b_hi, start);
+                    else scr_step<false>(acc, ad[s], b_lo, b_hi, start);
                 }
                 int res[4];
-                unsigned mine = 0;
+                bool unsure[4];
+                unsigned long long open = 0;                                      // lanes with an undecided slot (a scalar mask)
+#ifdef RI_TRACE
+                asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[4][0]));         // (the products have landed)
+#endif
+                RI_MARK(7);                            // operand reads and products
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    bool unsure;
-                    res[j] = scr_decide<NEG>(acc[0][j], acc[1][j], acc[2][j], acc[3][j], acc[4][j], bql[j], bqh[j], sh.rs, e32[j],
-                                             unsure, (never >> (3 - j)) & 1);
-                    mine = mine + mine + (unsure ? 1u : 0u);                      // slot j at bit 3 - j
+                    res[j] = scr_decide<NEG>(acc[0][j], acc[1][j], acc[2][j], acc[3][j], acc[4][j], sh.rs, sh.e32, unsure[j]);
+                    open |= __ballot(unsure[j]) & ~exact[j];
                 }
-                mine &= ~never;
-                if (__ballot(mine != 0) != 0) {
+#ifdef RI_TRACE
+                asm volatile("s_nop 0" ::"v"(res[0]), "v"(res[3]), "s"(open));
+#endif
+                RI_MARK(8);                            // decisions
+                if (some_exact) {                                                 // (the wave of phase tile 0, as a rule)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        bool dummy;
+                        const int whole = scr_decide<NEG>(acc[0][j], acc[1][j], acc[2][j], acc[3][j], acc[4][j], sh.rs, sh.e32, dummy, 0u);
+                        res[j] = ((exact[j] >> lane) & 1ull) ? whole : res[j];
+                    }
+                }
+#ifdef RI_TRACE
+                ri_cnt[0] += open != 0 ? 1 : 0;
+#endif
+                if (open != 0) {
+                    unsigned mine = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        mine = mine + mine + ((unsure[j] && !((exact[j] >> lane) & 1ull)) ? 1u : 0u);    // slot j at bit 3 - j
 #pragma unroll 1
                     while (mine != 0) {
                         // an integer within eps of the value: the reference's own arithmetic decides, in the lane that found it
                         const int j = 3 - __builtin_ctz(mine);
                         mine &= mine - 1;
                         const int f = f0 + j;
-                        int cur = 0, kr = 0;
+                        int cur = 0;
 #pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            cur = j == u ? res[u] : cur;
-                            kr = j == u ? krange[u] : kr;
-                        }
+                        for (int u = 0; u < 4; u++) cur = j == u ? res[u] : cur;
                         // (a value far outside the clamp range needs no second look, nor does a row or period that does not exist)
                         if (f < sh.L && col < periods_left && scr_in_reach(cur)) {
                             const int cf = (int)(((long)f * sh.M) / sh.L);
+                            const int kr = bqtab[4 * f + 3] & 0xffff;             // first | last << 8 non-zero tap of the phase
+#ifdef RI_TRACE
+                            ri_cnt[1] += 1;
+#endif
                             const int r = ri_exact(xs_hi, xs_lo, lead + col * sh.M + cf + sh.Hp, g + (size_t)f * sh.Q, kr & 255, kr >> 8,
                                                    sh.gain);
 #pragma unroll
@@ -229,13 +275,22 @@ k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
                         }
                     }
                 }
+                // four consecutive phases of one period: 8 bytes of the output image (at any even byte address)
                 short *op = oimg + col * sh.L + f0;
+                const scr_i16x4 y = scr_clamp4(res);
+                if (f0 + 3 < sh.L) {
+                    reinterpret_cast<ri_o64 *>(op)->v = y;
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (f0 + j < sh.L) op[j] = scr_clamp(res[j]);
+                    for (int j = 0; j < 3; j++)
+                        if (f0 + j < sh.L) op[j] = y[j];
+                }
+                RI_MARK(9);                            // second looks, output image
             }
         }
+        RI_MARK(3);                                    // products and decisions
         __syncthreads();
+        RI_MARK(4);                                    // second barrier
 
         // ---- the output image leaves in memory order ----
         short *ospan = orow + m0 * sh.L;
@@ -251,7 +306,9 @@ k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         }
         // (the next span's image is written by threads that have passed the barrier above: nobody reads the planes any more;
         //  the output image is next written behind the next span's staging barrier)
+        RI_MARK(5);                                    // output image stored
     }
+    RI_DUMP();
 }
 
 // steps of 64 window samples the widest band needs: the band of tile t spans positions a_t .. c_{last phase} + Hp
@@ -272,43 +329,101 @@ int ri_ksteps(int L, int M, int Q)
 
 extern "C" int llzs_resample_i16x_ksteps(int L, int M, int Q) { return ri_ksteps(L, M, Q); }
 
-// geometry of the launch
-static bool ri_make_shape(int L, int M, int Q, long n_out, int channels, ri_shape *sh, int *waves, size_t *lds)
+// geometry of the launch (without the walk length: ri_pick_walk)
+static bool ri_make_shape(int L, int M, int Q, long n_out, ri_shape *sh, int *waves, size_t *lds)
 {
     sh->L = L; sh->M = M; sh->Q = Q;
     sh->nt = (L + 15) / 16;
     sh->Hp = (Q - 1 + 7) & ~7;
     const int ks = ri_ksteps(L, M, Q);
     if (ks > 4) return false;
-    // waves: the phase tiles dealt evenly over at most 8 waves (147 phases: 10 tiles -> 5 waves x 2 tiles)
-    const int rounds = (sh->nt + 7) / 8;
+    // waves: the phase tiles dealt evenly over at most 8 waves (147 phases: 10 tiles -> 5 waves x 2 tiles).  The span is the
+    // largest number of period tiles (at most 4) whose samples those waves can hold in flight (RI_NG groups a thread) and
+    // whose planes and output image stay within 40 KB -- at 147:160 four tiles need 1297 groups against 1280, and a sixth wave
+    // that only stages costs a resident workgroup per CU (16 waves: 3 x 5, but 2 x 6): three tiles then.  Only a single
+    // period tile may add staging waves or take more LDS.
+    const int wmax = ks == 1 ? 16 : 8;                  // (one step: 128 VGPRs, sixteen waves fit; more steps: up to 205, eight)
+    const int rounds = (sh->nt + wmax - 1) / wmax;
     int w = (sh->nt + rounds - 1) / rounds;
     if (w < 2) w = 2;
-    *waves = w;
     bool ok = false;
-    for (int pt = 4; pt >= 1 && !ok; pt--) {
+    const int pt_forced = llzs_tune(LLZS_TUNE_RS_I16_TILES);
+    for (int pt = (pt_forced >= 1 && pt_forced <= 4) ? pt_forced : 4; pt >= 1 && !ok; pt--) {
         sh->pt = pt; sh->P = 16 * pt;
         // the last period's last band ends at most M - 1 + Hp + 64 ks positions into its window; + 7 of alignment slack in front
         const long bytes = 7 + (long)M * (sh->P - 1) + (M - 1) + sh->Hp + 64 * ks + 16;
         sh->ngroups = (int)((bytes + 7) / 8);
         sh->plane = (8 * sh->ngroups + 15) & ~15;
         *lds = 2 * (size_t)sh->plane + sizeof(short) * (size_t)sh->P * L;
-        while (*waves < 8 && sh->ngroups > RI_NG * 64 * *waves) (*waves)++;
+        *waves = w;
+        if (pt == 1)
+            while (*waves < wmax && sh->ngroups > RI_NG * 64 * *waves) (*waves)++;
         ok = sh->ngroups <= RI_NG * 64 * *waves && (*lds <= 40 * 1024 || (pt == 1 && *lds <= 160 * 1024));
     }
     if (!ok) return false;
     const long periods = (n_out + L - 1) / L;
     sh->spans = (periods + sh->P - 1) / sh->P;
-    // consecutive spans per workgroup: the walk length that minimises rounds x (length + 1) over ~3 resident workgroups per CU
+    sh->spans_per_wg = 1;
+    return true;
+}
+
+// consecutive spans per workgroup: the walk length that minimises rounds x (length + 1) when `resident` workgroups run at a time
+// (every walk pays about one span of fill: its first request has nothing to hide behind)
+static void ri_pick_walk(ri_shape *sh, int channels, long resident)
+{
     long spw = sh->spans < 4 ? sh->spans : 4;
     double best = 1e300;
     for (long cnt = spw; cnt <= sh->spans; cnt++) {
         const long wgs = ((sh->spans + cnt - 1) / cnt) * (long)channels;
-        const double cost = (double)((wgs + 767) / 768) * (double)(cnt + 1);
+        const double cost = (double)((wgs + resident - 1) / resident) * (double)(cnt + 1);
         if (cost < best * 0.999) { best = cost; spw = cnt; }
     }
+    const long forced = llzs_tune(LLZS_TUNE_RS_I16_WALK);
+    if (forced >= 1) spw = forced < sh->spans ? forced : sh->spans;
     sh->spans_per_wg = (int)spw;
-    return true;
+}
+
+// the kernel instance of a shape, the workgroups of it a CU holds at a time (registers, LDS and waves of THAT instance), and the
+// walk length that follows
+static int ri_plan(int ks, bool neg, bool reload, int waves, size_t lds, int channels, ri_shape *sh, const void **fn, int *per_cu)
+{
+#define RI_FN3(K, N, R) reinterpret_cast<const void *>(k_resample_i8x<K, N, R>)
+#define RI_FN2(K, N) (reload ? RI_FN3(K, N, true) : RI_FN3(K, N, false))
+#define RI_FN(K) (neg ? RI_FN2(K, true) : RI_FN2(K, false))
+    *fn = ks == 1 ? RI_FN(1) : ks == 2 ? RI_FN(2) : ks == 3 ? RI_FN(3) : RI_FN(4);
+#undef RI_FN
+#undef RI_FN2
+#undef RI_FN3
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus < 1) {
+        llzs_set_error("resample_i16x: cannot query the device");
+        return LLZ_ERR_DEVICE;
+    }
+    if (lds > 64 * 1024) LLZ_HIP_CHECK(hipFuncSetAttribute(*fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, *fn, 64 * waves, lds) != hipSuccess || *per_cu < 1) *per_cu = 1;
+    ri_pick_walk(sh, channels, (long)*per_cu * cus);
+    return LLZ_OK;
+}
+
+// the launch a call would make (measurement and documentation): plan[0..5] = waves per workgroup, periods per span, spans per
+// workgroup, workgroups, workgroups resident per CU, LDS bytes per workgroup
+extern "C" int llzs_resample_i16x_plan(int L, int M, int Q, int channels, long n_out, int shift, int *plan)
+{
+    ri_shape sh;
+    int waves, per_cu = 0;
+    size_t lds;
+    const void *fn = nullptr;
+    if (!plan || channels < 1 || n_out < 1 || !ri_make_shape(L, M, Q, n_out, &sh, &waves, &lds)) {
+        llzs_set_error("resample_i16x_plan: bad arguments");
+        return LLZ_ERR_ARG;
+    }
+    const int rc = ri_plan(ri_ksteps(L, M, Q), shift - 40 < 0, sh.nt > waves, waves, lds, channels, &sh, &fn, &per_cu);
+    if (rc != LLZ_OK) return rc;
+    plan[0] = waves; plan[1] = sh.P; plan[2] = sh.spans_per_wg;
+    plan[3] = (int)((sh.spans + sh.spans_per_wg - 1) / sh.spans_per_wg) * channels;
+    plan[4] = per_cu; plan[5] = (int)lds;
+    return LLZ_OK;
 }
 
 extern "C" int llzs_resample_i16x_fits(int L, int M, int Q)
@@ -317,7 +432,7 @@ extern "C" int llzs_resample_i16x_fits(int L, int M, int Q)
     ri_shape sh;
     int waves;
     size_t lds;
-    return ri_make_shape(L, M, Q, L, 1, &sh, &waves, &lds) ? 1 : 0;
+    return ri_make_shape(L, M, Q, L, &sh, &waves, &lds) ? 1 : 0;
 }
 
 // atab: [ceil(L/16)][ksteps][5][64][16] tap digits in operand order; aoff: [ceil(L/16)] band starts; bqtab: [16 ceil(L/16)][4]
@@ -335,32 +450,31 @@ extern "C" int llzs_resample_i16x(const short *in, short *out, const short *hist
     size_t lds;
     if (!in || !out || !atab || !aoff || !bqtab || !g || channels <= 0 || channels > 65535 || n_in <= 0 || n_out <= 0 ||
         in_pitch < n_in || out_pitch < n_out || shift < 32 || shift > 46 || !(eps > 0.0) || !(eps < 0.0625) ||
-        !llzs_resample_i16x_fits(L, M, Q) || !ri_make_shape(L, M, Q, n_out, channels, &sh, &waves, &lds)) {
+        !llzs_resample_i16x_fits(L, M, Q) || !ri_make_shape(L, M, Q, n_out, &sh, &waves, &lds)) {
         llzs_set_error("resample_i16x: bad arguments (channels=%d L=%d M=%d Q=%d shift=%d eps=%g)", channels, L, M, Q, shift, eps);
         return LLZ_ERR_ARG;
     }
     sh.rs = shift - 40;
+    sh.e32 = (unsigned)ceil(ldexp(eps, 32)) + 2u;
     sh.gain = gain;
     const int ks = ri_ksteps(L, M, Q);
     const bool neg = sh.rs < 0, reload = sh.nt > waves;
+    int per_cu = 0;
+    const void *fn = nullptr;
+    const int prc = ri_plan(ks, neg, reload, waves, lds, channels, &sh, &fn, &per_cu);
+    if (prc != LLZ_OK) return prc;
     const dim3 grid((unsigned)((sh.spans + sh.spans_per_wg - 1) / sh.spans_per_wg), (unsigned)channels), block(64 * waves);
-#define RI_GO3(K, N, R)                                                                                               \
-    do {                                                                                                              \
-        if (lds > 64 * 1024)                                                                                          \
-            LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_resample_i8x<K, N, R>),                \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
-        hipLaunchKernelGGL((k_resample_i8x<K, N, R>), grid, block, lds, as_stream(stream), in, out, hist, atab, aoff, \
-                           bqtab, g, n_in, n_out, in_pitch, out_pitch, sh);                                           \
-    } while (0)
-#define RI_GO2(K, N) do { if (reload) RI_GO3(K, N, true); else RI_GO3(K, N, false); } while (0)
-#define RI_GO(K) do { if (neg) RI_GO2(K, true); else RI_GO2(K, false); } while (0)
-    if (ks == 1) RI_GO(1);
-    else if (ks == 2) RI_GO(2);
-    else if (ks == 3) RI_GO(3);
-    else RI_GO(4);
-#undef RI_GO
-#undef RI_GO2
-#undef RI_GO3
+    void *args[] = {&in, &out, &hist, &atab, &aoff, &bqtab, &g, &n_in, &n_out, &in_pitch, &out_pitch, &sh};
+    LLZ_HIP_CHECK(hipLaunchKernel(fn, grid, block, args, lds, as_stream(stream)));
     LLZ_LAUNCH_CHECK("k_resample_i8x");
     return LLZ_OK;
 }
+
+#ifdef RI_TRACE
+extern "C" int llzs_ri_trace_read(unsigned long long *dst, int count)
+{
+    LLZ_HIP_CHECK(hipDeviceSynchronize());
+    LLZ_HIP_CHECK(hipMemcpyFromSymbol(dst, HIP_SYMBOL(ri_trace_buf), sizeof(unsigned long long) * (size_t)count));
+    return LLZ_OK;
+}
+#endif

@@ -16,22 +16,35 @@ typedef int scr_i32x4 __attribute__((ext_vector_type(4)));
 __host__ __device__ __forceinline__ int scr_col(int n) { return n < 4 ? 2 * n + 1 : (n < 12 ? 2 * (n - 4) : 2 * (n - 12) + 9); }
 __host__ __device__ __forceinline__ int scr_chunk(int kq) { return ((kq & 1) << 1) | (kq >> 1); }
 
-// One output from its five accumulators in exact 32-bit integer arithmetic (|a_v| < 2^22.7: at most 200 taps per product
-// pair): T' as a 64-bit pair (hi, lo) by two add-with-carry steps, I = floor(T' / 2^(32 + rs)), F = the top 32 bits of the
-// fraction below it.  Returns the value truncated toward zero, NOT yet clamped (= the reference's result after scr_clamp) when
-// no integer lies within eps of the value -- F farther than e32 from both ends -- and sets `unsure` otherwise.  NEG selects rs < 0.  rs in [-8, 6]; e32 = ceil(eps 2^32) + 2.
-template <bool NEG>
-__device__ __forceinline__ int scr_decide(int a0, int a1, int a2, int a3, int a4, int bq_lo, int bq_hi, int rs, unsigned e32,
-                                          bool &unsure, bool integer_valued = false)
+// Start values of an output's accumulators.  The matrix cores add into whatever the accumulator registers hold, so the bias
+// Bq rides along for free, and so does an offset of 2^31 that makes the low pair a0 + 2^8 a1 a NON-NEGATIVE 32-bit number
+// (|a0 + 2^8 a1| < 2^30.7): with Bq - 2^31 = s0' + 2^16 s2 + 2^32 s4 (s0', s2 in 0 .. 65535), accumulator 0 starts from
+// 2^31 + s0' (as a wrapped int32), 2 from s2, 4 from s4, the other two from 0.  T' is then the plain 64-bit sum
+// (a4 : low pair) + (q << 16), q = a2 + 2^8 a3: no sign extension of the low pair, no separate bias addition, one carry.
+__device__ __forceinline__ void scr_start(int bq_lo, int bq_hi, int &s0, int &s2, int &s4)
 {
-    const int p = a0 + (a1 << 8);
+    const long long b = (long long)(((unsigned long long)(unsigned)bq_hi << 32) | (unsigned)bq_lo) - (1ll << 31);
+    s0 = (int)(0x80000000u + (unsigned)(b & 0xffff));
+    s2 = (int)((b >> 16) & 0xffff);
+    s4 = (int)(b >> 32);
+}
+
+// One output from its five accumulators (started as scr_start says) in exact integer arithmetic (|a_v| < 2^22.7 without the
+// start values: at most 200 taps per product pair): T' as a 64-bit pair (hi, lo), I = floor(T' / 2^(32 + rs)), F = the top 32
+// bits of the fraction below it.  Returns the value truncated toward zero, NOT yet clamped (= the reference's result after
+// scr_clamp) when no integer lies within eps of the value -- F farther than e32 from both ends -- and sets `unsure`
+// otherwise.  NEG selects rs < 0.  rs in [-8, 6]; e32 = ceil(eps 2^32) + 2.  not_integer = 0: the caller knows the output IS
+// an integer (then it is I itself, and `unsure` is always set: ignore it).
+template <bool NEG>
+__device__ __forceinline__ int scr_decide(int a0, int a1, int a2, int a3, int a4, int rs, unsigned e32, bool &unsure,
+                                          unsigned not_integer = 1u)
+{
+    const unsigned p = (unsigned)a0 + ((unsigned)a1 << 8);
     const int q = a2 + (a3 << 8);
-    // T' = (p + Bq) + q 2^16 + a4 2^32  (q 2^16 = (q >> 16) 2^32 + (q << 16) mod 2^32)
+    // (a4 : p) + (q << 16) as two 32-bit additions chained by the carry
     unsigned c1, c2;
-    const unsigned lo_w = __builtin_addc((unsigned)p, (unsigned)bq_lo, 0u, &c1);
-    const unsigned hi_w = (unsigned)(p >> 31) + (unsigned)bq_hi + c1;
-    const unsigned lo = __builtin_addc(lo_w, (unsigned)q << 16, 0u, &c2);
-    const int hi = (int)(hi_w + (unsigned)((q >> 16) + a4) + c2);
+    const unsigned lo = __builtin_addc(p, (unsigned)q << 16, 0u, &c1);
+    const int hi = (int)__builtin_addc((unsigned)a4, (unsigned)(q >> 16), c1, &c2);
     int I;
     unsigned F;
     if (NEG) {
@@ -42,8 +55,9 @@ __device__ __forceinline__ int scr_decide(int a0, int a1, int a2, int a3, int a4
         F = __builtin_amdgcn_alignbit((unsigned)hi, lo, (unsigned)rs);
     }
     unsure = F + e32 <= 2u * e32;                               // wrapping: the fraction is within e32 of 0 or of 1
-    // toward zero: the value is not an integer here (unless the caller knows the output IS one: then it is I itself)
-    return integer_valued ? I : I + (int)((unsigned)I >> 31);
+    // toward zero: the value is not an integer here, so a negative one moves up by one -- the sign bit, taken as a bit field
+    // of width not_integer (0 where the caller knows the output IS an integer: then it is I itself)
+    return I + (int)__builtin_amdgcn_ubfe((unsigned)I, 31u, not_integer);
 }
 
 // the reference's clamp (llz_resample.c:596-599) on the truncated value
@@ -58,14 +72,25 @@ __device__ __forceinline__ short scr_clamp(int t)
 __device__ __forceinline__ bool scr_in_reach(int t) { return (unsigned)(t + 32769) <= 65538u; }
 
 // nine products of one 64-sample step: tap digit planes 0..4 (ad) against the high sample plane (weights 1..5 -> accumulators
-// 0..4) and planes 1..4 against the low one (weights 1..4 -> accumulators 0..3); FIRST starts the accumulators from 0
+// 0..4) and planes 1..4 against the low one (weights 1..4 -> accumulators 0..3); FIRST starts the accumulators from their
+// start values (scr_start: accumulators 0, 2, 4; the constant 0 for 1 and 3)
 template <bool FIRST>
-__device__ __forceinline__ void scr_step(scr_i32x4 (&acc)[5], const scr_i32x4 (&ad)[5], const scr_i32x4 &b_lo, const scr_i32x4 &b_hi)
+__device__ __forceinline__ void scr_step(scr_i32x4 (&acc)[5], const scr_i32x4 (&ad)[5], const scr_i32x4 &b_lo, const scr_i32x4 &b_hi,
+                                         const scr_i32x4 (&start)[3])
 {
 #pragma unroll
     for (int p = 0; p < 5; p++) {
-        const scr_i32x4 c0 = FIRST ? (scr_i32x4){0, 0, 0, 0} : acc[p];
+        const scr_i32x4 c0 = !FIRST ? acc[p] : ((p & 1) ? (scr_i32x4){0, 0, 0, 0} : start[p >> 1]);
         acc[p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ad[p], b_hi, c0, 0, 0, 0);
         if (p > 0) acc[p - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ad[p], b_lo, acc[p - 1], 0, 0, 0);
     }
+}
+
+// four decided values of a lane, clamped (llz_resample.c:596-599: v_cvt_pk_i16_i32 saturates) and packed in memory order
+typedef short scr_i16x4 __attribute__((ext_vector_type(4)));
+typedef short scr_i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ scr_i16x4 scr_clamp4(const int (&r)[4])
+{
+    const scr_i16x2 a = __builtin_amdgcn_cvt_pk_i16(r[0], r[1]), b = __builtin_amdgcn_cvt_pk_i16(r[2], r[3]);
+    return (scr_i16x4){a[0], a[1], b[0], b[1]};
 }

@@ -48,6 +48,11 @@ enum {
     LLZS_TUNE_SHARD_RCCL,           /* 1: sharded handles broadcast their tables through RCCL even on a single device */
     LLZS_TUNE_RS_MFMA_FORM,         /* 1: matrix-core L/M resampler with a wave per PERIOD tile (first form) */
     LLZS_TUNE_OLS_SEG_LEN,          /* jobs per segment of the 1024-point overlap-save walk (1..16) */
+    LLZS_TUNE_MDCT_RUN,             /* MDCT-frames synthesis: output segments per group (0: a launch for the even and one for
+                                     * the odd frames) */
+    LLZS_TUNE_MDCTQ_STEPS,          /* 1: fixed-point N/4-point MDCT as three launches (step, transform, step) */
+    LLZS_TUNE_RS_I16_TILES,         /* bit-exact int16 L/M resampler: period tiles per span (1..4) */
+    LLZS_TUNE_RS_I16_WALK,          /* ... consecutive spans per workgroup */
     LLZS_TUNE_COUNT
 };
 int llzs_tune(int id);                                   /* current override or -1 */
@@ -215,6 +220,9 @@ int llzs_resample_i16x(const short *in, short *out, const short *hist, const sig
                        int L, int M, int Q, int shift, double gain, double eps, void *stream);
 int llzs_resample_i16x_fits(int L, int M, int Q);
 int llzs_resample_i16x_ksteps(int L, int M, int Q);
+/* the launch a call would make (measurement / documentation): plan[0..5] = waves per workgroup, periods per span, spans per
+ * workgroup, workgroups, workgroups resident per CU, LDS bytes per workgroup */
+int llzs_resample_i16x_plan(int L, int M, int Q, int channels, long n_out, int shift, int *plan);
 int llzs_tail_i16(const short *in, const short *hist_old, short *hist_new, int channels, long n, long in_pitch,
                   int keep, void *stream);
 /* llz_decimate (forward indexed polyphase sum over a history of n samples) and llz_interp (no history),
@@ -266,6 +274,10 @@ int llzs_mdct_rot_f64(int quarter, int post, const double *in, double *out, cons
 int llzs_mdctq_sums(const short *A, const int *x, int *y, int count, int rows, int cols, int quarter_over_n, void *stream);
 int llzs_mdctq_step(int quarter, int post, const int *in, int *out, const short *tw, int count, int N, int inverse,
                     int cof, void *stream);
+/* the N/4-point form whole in one launch (fold, transform, unfold in LDS): N a power of two in 8..16384; pre / post: the two
+ * step tables of this direction; cs: the N/4-point transform's table */
+int llzs_mdct4_q15(const int *in, int *out, int count, int N, const short *pre, const short *post, const short *cs,
+                   int inverse, int cof, void *stream);
 /* framing of the single-channel analysis / synthesis symbols in double, exact order (frames_f64.hip; llz_asmodel.c:177-462):
  * slide_window: held_next = (held << hop) ++ fresh, dst = held_next * window (interleaved complex with zero imaginary part
  * when as_complex); split / mirror: interleaved spectrum <-> planes [re 0..N/2 | im 0..N/2]; overlap_add: acc + src * window,

@@ -907,7 +907,7 @@ def test_mdct_reference_symbols_exact(dev):
 
 
 @pytest.mark.parametrize("t,n,count", [(0, 16, 7), (0, 256, 40), (1, 16, 3), (1, 256, 129), (1, 4096, 5), (2, 8, 4), (2, 64, 1000),
-                                       (2, 2048, 37), (2, 16384, 3)])
+                                       (2, 2048, 37), (2, 16384, 3), (2, 16, 1), (2, 32, 2049), (2, 512, 301), (2, 8192, 2)])
 def test_mdct_fixed_batch_vs_oracle(dev, oracle, t, n, count):
     """llz_mdct_fixed_batch / llz_imdct_fixed_batch: `count` frames per call on the device kernels (mdct_q15.hip + the Q15
     transform), device tensors in place and host arrays staged, against the oracle's frame-by-frame llz_mdct_fixed (itself
@@ -924,6 +924,13 @@ def test_mdct_fixed_batch_vs_oracle(dev, oracle, t, n, count):
     m.inverse_batch(Xd, yd)
     torch.cuda.synchronize()
     X, y = Xd.cpu().numpy(), yd.cpu().numpy()
+    if t == 2:
+        # the N/4-point form is one launch (k_mdct4_q15); as three launches it must give the same integers on every frame
+        with capi.tuned(mdctq_steps=1):
+            X3, y3 = torch.empty_like(Xd), torch.empty_like(yd)
+            m.forward_batch(xd, X3)
+            m.inverse_batch(Xd, y3)
+        assert torch.equal(X3, Xd) and torch.equal(y3, yd)
     for c in uniq:
         ref_X = oracle.mdct_fixed(t, x[c])
         assert np.array_equal(X[c], ref_X), (t, n, c)
@@ -1010,6 +1017,42 @@ def test_mdct_frames_mc_vs_oracle(dev, oracle, frame_len, win, channels, calls):
     m.close(); m2.close()
     with pytest.raises(capi.LlzError):
         filters.MdctFramesMC(2, 96, 0)
+
+
+@pytest.mark.parametrize("frame_len,run,channels,calls", [(128, 3, 5, (7, 1, 4, 2)), (256, 1, 3, (5, 1)), (512, 4, 9, (8, 3)),
+                                                          (1024, 2, 2, (5, 6)), (128, 16, 40, (33, 16))])
+def test_mdct_frames_synthesis_in_runs(dev, oracle, frame_len, run, channels, calls):
+    """the synthesis with a group per RUN of consecutive segments (k_mdct_reg_f32<..., 2>: the tail of the frame before stays
+    in registers, every output is written once; taken by itself for large batches, forced here): run lengths that divide the
+    frame count and that do not, a single segment per group, calls of one frame; the same coefficients through the
+    two-launch form give the same samples to float32 rounding, and both the oracle's"""
+    F = frame_len
+    total = sum(calls)
+    x = oracle.synth_f32(channels, total * F, seed=F + run)
+    a = filters.MdctFramesMC(channels, F, 0)
+    Xd = torch.empty(channels, total, F, dtype=torch.float32, device=dev)
+    a.analysis(torch.from_numpy(x).to(dev), Xd)
+    a.close()
+    outs = {}
+    for forced in (run, 0):
+        capi.tune("mdct_run", forced)
+        try:
+            m = filters.MdctFramesMC(channels, F, 0)
+            ys, o = [], 0
+            for frames in calls:
+                yd = torch.full((channels, frames * F), 7.0, dtype=torch.float32, device=dev)
+                m.synthesis(Xd[:, o:o + frames].contiguous(), yd)
+                ys.append(yd.cpu().numpy())
+                o += frames
+            m.close()
+        finally:
+            capi.tune("mdct_run", -1)
+        outs[forced] = np.concatenate(ys, axis=1)
+    # (two float32 kernels: the same sums, not the same roundings)
+    assert np.abs(outs[run] - outs[0]).max() <= 2e-6, "both forms add the same two windowed terms per sample"
+    for c in sorted({0, channels - 1}):
+        _, yr = oracle.mdct_frames(F, 0, x[c].astype(np.float64))
+        assert np.sqrt(np.mean((outs[run][c] - yr) ** 2)) <= TOL, (F, c)
 
 
 # ------------------------------------------------------------------------------------------------ overlap-save, 2048 points

@@ -32,3 +32,23 @@ Lb.llz_hip_timer_stop(t, stream.cuda_stream)
 ms = Lb.llz_hip_timer_ms(t) / reps
 gb = (2 + 2 * L_ / M_) * ch * n / ms / 1e6
 print(f"{os.path.basename(capi.LIB_PATH)}: resample {L_}:{M_} i16 exact {ch}ch x {n}: {ms:.3f} ms  {gb:.0f} GB/s ({gb / 80:.1f} %)")
+if L_ > 1 and len(sys.argv) > 4:
+    # sweep of the launch shape: period tiles per span x spans per workgroup
+    for tiles in (1, 2, 3, 4):
+        for walk in (2, 4, 8, 16, 32, 64, 128, 512):
+            capi.tune("rs_i16_tiles", tiles)
+            capi.tune("rs_i16_walk", walk)
+            for _ in range(10):
+                r.process(x, y)
+            Lb.llz_hip_timer_start(t, stream.cuda_stream)
+            for _ in range(20):
+                r.process(x, y)
+            Lb.llz_hip_timer_stop(t, stream.cuda_stream)
+            print(f"   tiles {tiles} walk {walk}: {Lb.llz_hip_timer_ms(t) / 20:.3f} ms")
+    capi.tune("rs_i16_tiles", -1)
+    capi.tune("rs_i16_walk", -1)
+if L_ > 1:
+    import ctypes
+    plan = (ctypes.c_int * 6)()
+    if Lb.llzs_resample_i16x_plan(L_, M_, r.Q, ch, ctypes.c_long(n * L_ // M_), 38, plan) == 0:
+        print("   plan: waves/wg %d, periods/span %d, spans/wg %d, workgroups %d, resident/CU %d, LDS %d B" % tuple(plan))

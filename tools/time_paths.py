@@ -195,13 +195,20 @@ if "mdct" in which:
         q.close()
         del x, X
     # windowed 50 %-overlap frames in batch: 4 B in + 4 B out per sample either way
-    for F, ch, frames in ((128, 1024, 2048), (1024, 1024, 256), (4096, 256, 256)):
+    for F, ch, frames in ((128, 1024, 2048), (256, 1024, 1024), (512, 1024, 512), (1024, 1024, 256), (4096, 256, 256)):
         x = torch.rand(ch, frames * F, dtype=torch.float32, device=dev) * 2 - 1
         X = torch.empty(ch, frames, F, dtype=torch.float32, device=dev)
         q = filters.MdctFramesMC(ch, F, capi.MDCT_SINE, stream=stream)
         ms_a = timeit(lambda: q.analysis(x, X), 5)
         ms_s = timeit(lambda: q.synthesis(X, x), 5)
         gb = 8 * ch * frames * F
+        if F <= 1024:
+            # the synthesis with a group per run of segments (the library's own choice here) against the two launches
+            for forced in (0, 2, 4, 8, 16, 32):
+                capi.tune("mdct_run", forced)
+                ms = timeit(lambda: q.synthesis(X, x), 5)
+                print(f"   synthesis, mdct_run = {forced}: {ms:.3f} ms ({gb / ms / 1e6 / 80:.1f} %)")
+            capi.tune("mdct_run", -1)
         print(f"mdct frames F={F} {ch}ch x {frames}: analysis {ms_a:.3f} ms {gb / ms_a / 1e6:.0f} GB/s ({gb / ms_a / 1e6 / 80:.1f} %), "
               f"synthesis {ms_s:.3f} ms {gb / ms_s / 1e6:.0f} GB/s ({gb / ms_s / 1e6 / 80:.1f} %)")
         q.close()
@@ -209,7 +216,7 @@ if "mdct" in which:
 
 if "mdctq" in which:
     # fixed-point MDCT batch (int32 data, Q15 tables, bit-exact): 4 B per sample in + 2 B per sample out forward, the reverse inverse
-    for t, n, count in ((2, 256, 1 << 16), (2, 2048, 1 << 15), (2, 8192, 1 << 13), (1, 2048, 1 << 14)):
+    for t, n, count in ((2, 256, 1 << 20), (2, 2048, 1 << 17), (2, 8192, 1 << 15), (1, 2048, 1 << 15)):
         x = torch.randint(-(1 << 20), 1 << 20, (count, n), dtype=torch.int32, device=dev)
         X = torch.empty(count, n // 2, dtype=torch.int32, device=dev)
         q = filters.MdctFixed(t, n)
@@ -219,5 +226,11 @@ if "mdctq" in which:
         gb = 6 * count * n
         print(f"mdct fixed type {t} N={n} x {count}: forward {ms_f:.3f} ms {gb / ms_f / 1e6:.0f} GB/s ({gb / ms_f / 1e6 / 80:.1f} %), "
               f"inverse {ms_i:.3f} ms {gb / ms_i / 1e6:.0f} GB/s ({gb / ms_i / 1e6 / 80:.1f} %)")
+        if t == 2:
+            with capi.tuned(mdctq_steps=1):
+                ms_f = timeit(lambda: q.forward_batch(x, X), 5)
+                ms_i = timeit(lambda: q.inverse_batch(X, x), 5)
+            print(f"   as three launches (step, transform, step): forward {ms_f:.3f} ms ({gb / ms_f / 1e6 / 80:.1f} %), "
+                  f"inverse {ms_i:.3f} ms ({gb / ms_i / 1e6 / 80:.1f} %)")
         q.close()
         del x, X
