@@ -264,6 +264,7 @@ typedef struct {
     int use_screen, screen_shift;
     long long screen_bias;
     double screen_eps;
+    int screen_any_exact;               /* general L/M: some phase is a single tap 1.0 at gain 1.0 (its outputs are integers) */
     signed char *d_digits;      /* [LLZS_MX_PLANES][Q] */
     /* I16, L >= 2: the same screen per phase, on the phase-tile mapping (resample_i8.hip) */
     int use_screen_lm;
@@ -400,6 +401,7 @@ static int rsm_build_screen_lm(rsm_t *r)
     int *aoff = (int *)calloc((size_t)nt, sizeof(int)), *bq = (int *)calloc((size_t)nt * 64, sizeof(int));
     int ok = atab && dig && aoff && bq;
     double eps = 0.0;
+    int any_exact = 0;
     for (int f = 0; ok && f < L; f++) {
         const double *g = r->taps.mat + (size_t)f * Q;
         const int t = f / 16, row = f % 16, cf = (int)(((long)f * M) / L);
@@ -441,7 +443,10 @@ static int rsm_build_screen_lm(rsm_t *r)
          * otherwise take the recompute path: one lane row in 16 of that phase tile, 47 double steps each. */
         if (nonzero == 0) kfirst = klast = 0;
         /* (the recompute path runs taps kfirst .. klast only: zero taps in front and behind add +-0 to the reference's sum) */
-        bq[4 * f + 3] = kfirst | (klast << 8) | ((nonzero == 1 && unit == 1 && gain == 1.0) ? 1 << 16 : 0);
+        /* (a phase without any tap: every output is the integer 0, whatever the gain) */
+        const int exact = nonzero == 0 || (nonzero == 1 && unit == 1 && gain == 1.0);
+        any_exact |= exact;
+        bq[4 * f + 3] = kfirst | (klast << 8) | (exact ? 1 << 16 : 0);
         for (int s = 0; s < steps; s++)
             for (int kq = 0; kq < 4; kq++)
                 for (int j = 0; j < 16; j++) {
@@ -466,6 +471,7 @@ static int rsm_build_screen_lm(rsm_t *r)
     if (ok) {
         r->screen_shift = shift;
         r->screen_eps = eps;
+        r->screen_any_exact = any_exact;
     }
     return ok;
 }
@@ -693,7 +699,7 @@ static long rsm_process(rsm_t *r, unsigned long handle, const void *in, long n_i
                  r->channels <= 65535)
             rc = llzs_resample_i16x((const short *)d_in, (short *)d_out, (const short *)hist, r->d_scr_atab, r->d_scr_aoff,
                                     r->d_scr_bq, (const double *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->L, r->M,
-                                    r->Q, r->screen_shift, r->gain, r->screen_eps, r->stream);
+                                    r->Q, r->screen_shift, r->gain, r->screen_eps, r->screen_any_exact, r->stream);
         else if (r->fmt == LLZ_PCM_I16)
             rc = llzs_resample_i16((const short *)d_in, (short *)d_out, (const short *)hist,
                                    (const double *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->L, r->M,

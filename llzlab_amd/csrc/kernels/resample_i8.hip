@@ -55,6 +55,7 @@ struct ri_shape {
     int plane;              // bytes per plane (multiple of 16): 8 ngroups
     int ngroups;            // 16-byte sample groups per span
     long spans;             // spans of a channel
+    long periods;           // periods of a channel (n_out / L, rounded up)
     int spans_per_wg;
     int rs;                 // shift - 40
     unsigned e32;           // ceil(eps 2^32) + 2, eps = the largest phase's bound
@@ -152,7 +153,34 @@ k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
 #pragma unroll
             for (int p = 0; p < 5; p++) ad[s][p] = *reinterpret_cast<const scr_i32x4 *>(ap + (s * 5 + p) * 1024);
     };
-    if (!RELOAD && wave < sh.nt) load_a(wave);
+    // Per phase tile: the band start, scr_start of the lane's four phases, and lane masks, one per slot, of the EXACT phases (a
+    // phase whose only tap is 1.0: its outputs are integers -- always "unsure", and not to be moved toward zero) and of the
+    // slots that never need a second look (those, and the rows past the last phase: all-zero taps, the value 0 exactly).  A
+    // wave that keeps its one tile sets these up once, like the tile's digits.
+    int a_t = 0;
+    scr_i32x4 start[3] = {};
+    unsigned long long exact[4] = {0, 0, 0, 0}, settled[4] = {0, 0, 0, 0};
+    bool some_exact = false;                                                          // (wave-uniform)
+    auto tile_setup = [&](int t) {
+        a_t = aoff[t];
+        const int f0 = 16 * t + 4 * kq;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const scr_i32x4 row4 = *reinterpret_cast<const scr_i32x4 *>(bqtab + 4 * (f0 + j));
+            int s0, s2, s4;
+            scr_start(row4[0], row4[1], s0, s2, s4);
+            start[0][j] = s0;
+            start[1][j] = s2;
+            start[2][j] = s4;
+            exact[j] = __ballot((row4[3] >> 16) != 0);
+            settled[j] = exact[j] | __ballot(f0 + j >= sh.L);
+        }
+        some_exact = (exact[0] | exact[1] | exact[2] | exact[3]) != 0;
+    };
+    if (!RELOAD && wave < sh.nt) {
+        load_a(wave);
+        tile_setup(wave);
+    }
 
     const int P = sh.P;
     const long span0 = (long)blockIdx.x * sh.spans_per_wg;
@@ -187,26 +215,13 @@ k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         RI_MARK(2);                                    // staging barrier
 
         // ---- products and decisions: this wave's phase tile(s) x the span's period tiles ----
-        const long periods_left = (n_out - m0 * sh.L + sh.L - 1) / sh.L;          // periods of this span that exist
+        const long periods_left = sh.periods - m0;                                // periods of this span that exist
         for (int t = wave; t < sh.nt; t += waves) {
-            if (RELOAD) load_a(t);
-            const int a_t = aoff[t];
-            const int f0 = 16 * t + 4 * kq;                                       // the lane's first phase (row 4 kq) of the tile
-            // scr_start of the lane's four phases; lane masks of the EXACT phases, one per slot (a phase whose only tap is 1.0:
-            // its outputs are integers -- always "unsure", and not to be moved toward zero)
-            scr_i32x4 start[3];
-            unsigned long long exact[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const scr_i32x4 row4 = *reinterpret_cast<const scr_i32x4 *>(bqtab + 4 * (f0 + j));
-                int s0, s2, s4;
-                scr_start(row4[0], row4[1], s0, s2, s4);
-                start[0][j] = s0;
-                start[1][j] = s2;
-                start[2][j] = s4;
-                exact[j] = __ballot((row4[3] >> 16) != 0);
+            if (RELOAD) {
+                load_a(t);
+                tile_setup(t);
             }
-            const bool some_exact = (exact[0] | exact[1] | exact[2] | exact[3]) != 0;        // (wave-uniform)
+            const int f0 = 16 * t + 4 * kq;                                       // the lane's first phase (row 4 kq) of the tile
             RI_MARK(6);                                // per-tile constants
 #pragma unroll 1
             for (int p = 0; p < sh.pt; p++) {
@@ -230,7 +245,7 @@ k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     res[j] = scr_decide<NEG>(acc[0][j], acc[1][j], acc[2][j], acc[3][j], acc[4][j], sh.rs, sh.e32, unsure[j]);
-                    open |= __ballot(unsure[j]) & ~exact[j];
+                    open |= __ballot(unsure[j]) & ~settled[j];
                 }
 #ifdef RI_TRACE
                 asm volatile("s_nop 0" ::"v"(res[0]), "v"(res[3]), "s"(open));
@@ -251,7 +266,7 @@ k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
                     unsigned mine = 0;
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        mine = mine + mine + ((unsure[j] && !((exact[j] >> lane) & 1ull)) ? 1u : 0u);    // slot j at bit 3 - j
+                        mine = mine + mine + ((unsure[j] && !((settled[j] >> lane) & 1ull)) ? 1u : 0u);    // slot j at bit 3 - j
 #pragma unroll 1
                     while (mine != 0) {
                         // an integer within eps of the value: the reference's own arithmetic decides, in the lane that found it
@@ -311,6 +326,290 @@ k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
     RI_DUMP();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same arithmetic with every wave on its own phase tile for the whole launch (up to 12 waves: L <= 192), the sample planes
+// DOUBLE-BUFFERED and the results stored straight from the registers:
+//   * a wave keeps its tile's digits, start values and masks in registers from the first span to the last (the first form
+//     fetched them again per span and tile: ~600 clocks of exposed latency per span);
+//   * four consecutive phases of one period are 8 contiguous bytes of the output row: one global store per lane and period
+//     tile at an even byte address -- no output image in LDS (its unaligned 8-byte LDS writes measured ~650 clocks per period
+//     tile), no copy-out phase, no second barrier.  The ten waves of a period fill its 2 L bytes within one span, so the lines
+//     leave L2 whole;
+//   * span i + 1 is written into the other pair of planes while slower waves still read span i: ONE barrier per span;
+//   * the next span's samples are requested by hand (global_load ... from an SGPR base, as in fir_mfma_i8.hip) and awaited
+//     with the exact count of younger stores, so staging does not wait for the previous span's stores to be acknowledged.
+//     Spans at a frame's edges (history in front, zeros behind) and the first span of a walk are staged sample by sample.
+// Measured per span of 64 periods at 147:160 (shader clocks, -DRI_TRACE build): 13.8 K for the first form.
+struct __attribute__((packed, aligned(2))) ri_g64 { scr_i16x4 v; };        // an 8-byte global store at any even byte address
+
+__device__ __forceinline__ i16x8 ri_load_nt(const short *base, int off)
+{
+    i16x8 r;
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(r) : "v"(off), "s"(base) : "memory");
+    return r;
+}
+// at most n vector-memory operations (the youngest) still in flight; n = 0 .. 8
+__device__ __forceinline__ void ri_wait_vm(int n)
+{
+    switch (n) {
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+__device__ __forceinline__ void ri_pin(i16x8 (&v)[RI_NG])
+{
+    static_assert(RI_NG == 4, "one operand per group");
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
+}
+
+constexpr int RI_D_THREADS = 768;           // twelve waves: 170 VGPRs a lane
+
+// EXACTS: some phase is exact (per-lane bit-field widths in the decision: four more registers)
+template <int KS, bool NEG, bool EXACTS>
+__global__ void __launch_bounds__(RI_D_THREADS)
+k_resample_i8d(const short *__restrict__ in, short *__restrict__ out, const short *__restrict__ hist,
+               const signed char *__restrict__ atab, const int *__restrict__ aoff, const int *__restrict__ bqtab,
+               const double *__restrict__ g, long n_in, long n_out, long in_pitch, long out_pitch, ri_shape sh)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    // planes of buffer b: low digits at 2 b plane, high digits one plane further
+    const int tid = threadIdx.x, lane = tid & 63, threads = (int)blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const int col16 = scr_col(n), ck = scr_chunk(kq);
+    const int c = blockIdx.y;
+    const short *row = in + (size_t)c * in_pitch;
+    const short *hrow = hist ? hist + (size_t)c * (sh.Q - 1) : nullptr;
+    short *orow = out + (size_t)c * out_pitch;
+    const bool aligned_in = (in_pitch & 7) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+    const int P = sh.P;
+
+    // the lane's groups of a span (8 samples = 16 bytes each): byte offset of group k; lanes past the last group re-read it and
+    // write nothing
+    auto goff = [&](int k) {
+        const int gi = k * threads + tid;
+        return 16 * (gi < sh.ngroups ? gi : sh.ngroups - 1);
+    };
+    // first sample index of a span's image: the 8-aligned index at or below M m0 - Hp
+    auto image_base = [&](long sp, int &lead) {
+        const long s0 = sp * P * sh.M - sh.Hp;
+        const long gbase = s0 >= 0 ? (s0 & ~7L) : -((-s0 + 7) & ~7L);
+        lead = (int)(s0 - gbase);
+        return gbase;
+    };
+    auto streams = [&](long gbase) { return aligned_in && gbase >= 0 && gbase + 8L * sh.ngroups <= n_in; };
+
+    // the wave's tile: digits, band start, start values, masks (see k_resample_i8x)
+    const int t = wave;
+    const bool has_tile = t < sh.nt;
+    scr_i32x4 ad[KS][5];
+    int a_t = 0;
+    scr_i32x4 start[3] = {};                            // scr_start of the lane's four phases
+    // slots that never need a second look (lane masks): the EXACT phases (a single tap 1.0: the outputs are integers -- always
+    // "unsure", and not to be moved toward zero: bit-field width 0 in the decision) and the rows past the last phase
+    unsigned long long settled[4] = {0, 0, 0, 0};
+    unsigned inexact[4] = {1u, 1u, 1u, 1u};
+    unsigned e32v = sh.e32;                             // (in a VGPR: an instruction takes one scalar operand, and the shift is one)
+    const int f0 = 16 * t + 4 * kq;
+    if (has_tile) {
+        const signed char *ap = atab + ((size_t)t * KS * 5) * 1024 + lane * 16;
+#pragma unroll
+        for (int s = 0; s < KS; s++)
+#pragma unroll
+            for (int p = 0; p < 5; p++) ad[s][p] = *reinterpret_cast<const scr_i32x4 *>(ap + (s * 5 + p) * 1024);
+        a_t = aoff[t];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const scr_i32x4 row4 = *reinterpret_cast<const scr_i32x4 *>(bqtab + 4 * (f0 + j));
+            int s0, s2, s4;
+            scr_start(row4[0], row4[1], s0, s2, s4);
+            start[0][j] = s0;
+            start[1][j] = s2;
+            start[2][j] = s4;
+            inexact[j] = (row4[3] >> 16) != 0 ? 0u : 1u;
+            settled[j] = __ballot(inexact[j] == 0 || f0 + j >= sh.L);
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < KS; s++)
+#pragma unroll
+            for (int p = 0; p < 5; p++) ad[s][p] = (scr_i32x4){0, 0, 0, 0};
+    }
+    const bool tile_whole = 16 * t + 15 < sh.L;                                  // every row of the tile is a phase
+    // The tile's registers pass through one empty asm HERE: the compiler waits for their loads in front of it, once.  Left to
+    // itself it keeps them "possibly in flight" at the head of the period-tile loop and puts s_waitcnt vmcnt(0) in front of the
+    // first products of EVERY period tile -- which also waits for the previous tile's store to be acknowledged (measured: 870
+    // clocks per period tile in the products against ~300).
+#pragma unroll
+    for (int s = 0; s < KS; s++)
+        asm volatile("" : "+v"(ad[s][0]), "+v"(ad[s][1]), "+v"(ad[s][2]), "+v"(ad[s][3]), "+v"(ad[s][4]) : : "memory");
+    asm volatile("" : "+v"(start[0]), "+v"(start[1]), "+v"(start[2]), "+v"(e32v) : : "memory");
+    if constexpr (EXACTS) asm volatile("" : "+v"(inexact[0]), "+v"(inexact[1]), "+v"(inexact[2]), "+v"(inexact[3]) : : "memory");
+
+    RI_T0();
+    // ---- a span's samples into the planes of buffer b ----
+    auto stage = [&](long sp, int b, i16x8 (&v)[RI_NG], bool streamed, int young) {
+        signed char *lo_p = reinterpret_cast<signed char *>(lds) + 2 * b * sh.plane, *hi_p = lo_p + sh.plane;
+        if (streamed) {
+            ri_wait_vm(young);                          // the request is older than exactly `young` stores (0: do not count)
+            ri_pin(v);
+#pragma unroll
+            for (int k = 0; k < RI_NG; k++) {
+                const int gi = k * threads + tid;
+                if (gi < sh.ngroups) {
+                    const u32x4 d = __builtin_bit_cast(u32x4, v[k]);
+                    u32x2 lo, hi;
+                    lo[0] = __builtin_amdgcn_perm(d[1], d[0], 0x06040200u) ^ 0x80808080u;
+                    lo[1] = __builtin_amdgcn_perm(d[3], d[2], 0x06040200u) ^ 0x80808080u;
+                    hi[0] = __builtin_amdgcn_perm(d[1], d[0], 0x07050301u);
+                    hi[1] = __builtin_amdgcn_perm(d[3], d[2], 0x07050301u);
+                    *reinterpret_cast<u32x2 *>(&lo_p[8 * gi]) = lo;
+                    *reinterpret_cast<u32x2 *>(&hi_p[8 * gi]) = hi;
+                }
+            }
+        } else {
+            // a frame edge (history in front, zeros behind), an unaligned frame, or the first span of the walk
+            int lead;
+            const long gbase = image_base(sp, lead);
+            for (int e = tid; e < 8 * sh.ngroups; e += threads) {
+                const long idx = gbase + e;
+                int x = 0;
+                if (idx >= 0) {
+                    if (idx < n_in) x = row[idx];
+                } else if (hrow && idx >= -(long)(sh.Q - 1)) {
+                    x = hrow[sh.Q - 1 + idx];
+                }
+                lo_p[e] = (signed char)((x & 255) - 128);
+                hi_p[e] = (signed char)(x >> 8);
+            }
+        }
+    };
+
+    // ---- products, decisions and stores of the wave's tile over the span in buffer b; returns the number of store
+    //      instructions issued (0 when it is not the same for every lane).  The loop is bound by the NUMBER of instructions a
+    //      wave issues (the waves of a SIMD leave the barrier together and take turns, one instruction each): operand and
+    //      output addresses advance by increments, the store takes an SGPR base and a 32-bit lane offset, the exact phases are
+    //      a per-lane bit-field width inside the decision instead of a second pass. ----
+    auto products = [&](long sp, int b) {
+        const signed char *lo_p = reinterpret_cast<const signed char *>(lds) + 2 * b * sh.plane;
+        int lead;
+        (void)image_base(sp, lead);
+        const long m0 = sp * P;
+        const long left = sh.periods - m0;                                        // periods of this span that exist
+        const bool whole = tile_whole && left >= P;
+        short *ospan = orow + m0 * sh.L;                                          // (wave-uniform)
+        unsigned b_at = (unsigned)(2 * b * sh.plane + lead + col16 * sh.M + a_t + 16 * ck);       // LDS byte address of the lane's B operand
+        unsigned o_at = 2u * (unsigned)(col16 * sh.L + f0);                       // byte offset of the lane's 8 output bytes in the span
+        const unsigned b_step = 16u * (unsigned)sh.M, o_step = 32u * (unsigned)sh.L;
+#pragma unroll 1
+        for (int p = 0; p < sh.pt; p++, b_at += b_step, o_at += o_step) {
+            const signed char *bp = reinterpret_cast<const signed char *>(lds) + b_at;
+            scr_i32x4 acc[5];
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                const scr_i32x4 b_lo = reinterpret_cast<const ri_b128 *>(bp + 64 * s)->v;
+                const scr_i32x4 b_hi = reinterpret_cast<const ri_b128 *>(bp + sh.plane + 64 * s)->v;
+                if (s == 0) scr_step<true>(acc, ad[s], b_lo, b_hi, start);
+                else scr_step<false>(acc, ad[s], b_lo, b_hi, start);
+            }
+            int res[4];
+            bool unsure[4];
+            unsigned long long open = 0;                                          // lanes with an undecided slot (a scalar mask)
+#ifdef RI_TRACE
+            asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[4][0]));             // (the products have landed)
+#endif
+            RI_MARK(7);                                 // operand reads and products
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                res[j] = scr_decide<NEG>(acc[0][j], acc[1][j], acc[2][j], acc[3][j], acc[4][j], sh.rs, e32v, unsure[j], EXACTS ? inexact[j] : 1u,
+                                         2u * sh.e32);
+                open |= __ballot(unsure[j]) & ~settled[j];
+            }
+            if (open != 0) {
+                const int col = 16 * p + col16;
+                unsigned mine = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    mine = mine + mine + ((unsure[j] && !((settled[j] >> lane) & 1ull)) ? 1u : 0u);    // slot j at bit 3 - j
+#pragma unroll 1
+                while (mine != 0) {
+                    // an integer within eps of the value: the reference's own arithmetic decides, in the lane that found it
+                    const int j = 3 - __builtin_ctz(mine);
+                    mine &= mine - 1;
+                    const int f = f0 + j;
+                    int cur = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) cur = j == u ? res[u] : cur;
+                    // (a value far outside the clamp range needs no second look, nor does a period that does not exist)
+                    if (col < left && scr_in_reach(cur)) {
+                        const int cf = (int)(((long)f * sh.M) / sh.L);
+                        const int kr = bqtab[4 * f + 3] & 0xffff;                 // first | last << 8 non-zero tap of the phase
+                        const int r = ri_exact(lo_p + sh.plane, lo_p, lead + col * sh.M + cf + sh.Hp, g + (size_t)f * sh.Q, kr & 255,
+                                               kr >> 8, sh.gain);
+#pragma unroll
+                        for (int u = 0; u < 4; u++) res[u] = j == u ? r : res[u];
+                    }
+                }
+            }
+            // four consecutive phases of one period: 8 bytes of the output row, at any even byte address
+            const scr_i16x4 y = scr_clamp4(res);
+#ifdef RI_TRACE
+            asm volatile("s_nop 0" ::"v"(y), "s"(open));
+#endif
+            RI_MARK(8);                                 // decisions
+            if (whole) {
+                asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(o_at), "v"(y), "s"(ospan) : "memory");
+            } else if (16 * p + col16 < left) {
+                short *op = reinterpret_cast<short *>(reinterpret_cast<char *>(ospan) + o_at);
+                if (f0 + 3 < sh.L) {
+                    reinterpret_cast<ri_g64 *>(op)->v = y;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 3; j++)
+                        if (f0 + j < sh.L) op[j] = y[j];
+                }
+            }
+            RI_MARK(9);                                 // stores
+        }
+        return whole ? sh.pt : 0;
+    };
+
+    // One loop, one request site.  Iteration i runs the products of span i (none in the first iteration), writes span i + 1
+    // into the other planes and requests span i + 2; the barrier at its end publishes the planes of i + 1 and retires the
+    // readers of i.  A request that does not stream (or has no span) reads the row's first groups instead: in bounds -- the
+    // launcher requires n_in >= 8 ngroups -- and never looked at.
+    const long span0 = (long)blockIdx.x * sh.spans_per_wg;
+    const long span1 = min(span0 + sh.spans_per_wg, sh.spans);
+    i16x8 v[RI_NG] = {};
+    bool requested = false;                             // the registers hold span i + 1
+    int b = 0;
+    for (long i = span0 - 1; i < span1; i++) {
+        int young = 0;
+        if (i >= span0 && has_tile) young = products(i, b);
+        RI_MARK(6);                                     // (the rest of the products phase)
+        if (i + 1 < span1) stage(i + 1, b ^ 1, v, requested, young);
+        RI_MARK(0);                                     // planes written
+        int lead;
+        const long gnext = image_base(i + 2, lead);
+        requested = i + 2 < span1 && streams(gnext);
+        const short *src = requested ? row + gnext : row;
+#pragma unroll
+        for (int k = 0; k < RI_NG; k++) v[k] = ri_load_nt(src, goff(k));
+        RI_MARK(1);                                     // next span requested
+        __syncthreads();
+        RI_MARK(2);                                     // the barrier
+        b ^= 1;
+    }
+    RI_DUMP();
+}
+
 // steps of 64 window samples the widest band needs: the band of tile t spans positions a_t .. c_{last phase} + Hp
 int ri_ksteps(int L, int M, int Q)
 {
@@ -362,6 +661,35 @@ static bool ri_make_shape(int L, int M, int Q, long n_out, ri_shape *sh, int *wa
     }
     if (!ok) return false;
     const long periods = (n_out + L - 1) / L;
+    sh->periods = periods;
+    sh->spans = (periods + sh->P - 1) / sh->P;
+    sh->spans_per_wg = 1;
+    return true;
+}
+
+// geometry of the direct form (k_resample_i8d): a wave per phase tile, up to 8 period tiles per span in two pairs of planes
+static bool ri_make_shape_d(int L, int M, int Q, long n_out, ri_shape *sh, int *waves, size_t *lds)
+{
+    sh->L = L; sh->M = M; sh->Q = Q;
+    sh->nt = (L + 15) / 16;
+    sh->Hp = (Q - 1 + 7) & ~7;
+    const int ks = ri_ksteps(L, M, Q);
+    if (ks > 2 || sh->nt > RI_D_THREADS / 64) return false;
+    *waves = sh->nt < 2 ? 2 : sh->nt;
+    const long periods = (n_out + L - 1) / L;
+    bool ok = false;
+    const int pt_forced = llzs_tune(LLZS_TUNE_RS_I16_TILES);
+    for (int pt = (pt_forced >= 1 && pt_forced <= 8) ? pt_forced : 8; pt >= 1 && !ok; pt--) {
+        if (pt > 1 && 16L * (pt - 1) >= periods) continue;              // (no span longer than the signal needs)
+        sh->pt = pt; sh->P = 16 * pt;
+        const long bytes = 7 + (long)M * (sh->P - 1) + (M - 1) + sh->Hp + 64 * ks + 16;
+        sh->ngroups = (int)((bytes + 7) / 8);
+        sh->plane = (8 * sh->ngroups + 15) & ~15;
+        *lds = 4 * (size_t)sh->plane;
+        ok = sh->ngroups <= RI_NG * 64 * *waves && *lds <= 64 * 1024;
+    }
+    if (!ok) return false;
+    sh->periods = periods;
     sh->spans = (periods + sh->P - 1) / sh->P;
     sh->spans_per_wg = 1;
     return true;
@@ -383,14 +711,28 @@ static void ri_pick_walk(ri_shape *sh, int channels, long resident)
     sh->spans_per_wg = (int)spw;
 }
 
+// direct form where it applies (at most two steps, at most twelve phase tiles, a frame at least one span's image long -- its
+// requests without a span read the row's first groups), the first form otherwise
+static bool ri_pick_form(int L, int M, int Q, long n_in, long n_out, ri_shape *sh, int *waves, size_t *lds, bool *direct)
+{
+    *direct = llzs_tune(LLZS_TUNE_RS_I16_FORM) != 1 && ri_make_shape_d(L, M, Q, n_out, sh, waves, lds) && n_in >= 8L * sh->ngroups;
+    return *direct || ri_make_shape(L, M, Q, n_out, sh, waves, lds);
+}
+
 // the kernel instance of a shape, the workgroups of it a CU holds at a time (registers, LDS and waves of THAT instance), and the
 // walk length that follows
-static int ri_plan(int ks, bool neg, bool reload, int waves, size_t lds, int channels, ri_shape *sh, const void **fn, int *per_cu)
+static int ri_plan(bool direct, bool exacts, int ks, bool neg, bool reload, int waves, size_t lds, int channels, ri_shape *sh, const void **fn,
+                   int *per_cu)
 {
 #define RI_FN3(K, N, R) reinterpret_cast<const void *>(k_resample_i8x<K, N, R>)
 #define RI_FN2(K, N) (reload ? RI_FN3(K, N, true) : RI_FN3(K, N, false))
 #define RI_FN(K) (neg ? RI_FN2(K, true) : RI_FN2(K, false))
-    *fn = ks == 1 ? RI_FN(1) : ks == 2 ? RI_FN(2) : ks == 3 ? RI_FN(3) : RI_FN(4);
+#define RI_FD2(K, N) (exacts ? reinterpret_cast<const void *>(k_resample_i8d<K, N, true>) : reinterpret_cast<const void *>(k_resample_i8d<K, N, false>))
+#define RI_FD(K) (neg ? RI_FD2(K, true) : RI_FD2(K, false))
+    if (direct) *fn = ks == 1 ? RI_FD(1) : RI_FD(2);
+    else *fn = ks == 1 ? RI_FN(1) : ks == 2 ? RI_FN(2) : ks == 3 ? RI_FN(3) : RI_FN(4);
+#undef RI_FD
+#undef RI_FD2
 #undef RI_FN
 #undef RI_FN2
 #undef RI_FN3
@@ -406,23 +748,24 @@ static int ri_plan(int ks, bool neg, bool reload, int waves, size_t lds, int cha
     return LLZ_OK;
 }
 
-// the launch a call would make (measurement and documentation): plan[0..5] = waves per workgroup, periods per span, spans per
-// workgroup, workgroups, workgroups resident per CU, LDS bytes per workgroup
+// the launch a call would make (measurement and documentation): plan[0..6] = waves per workgroup, periods per span, spans per
+// workgroup, workgroups, workgroups resident per CU, LDS bytes per workgroup, 1 for the direct form (k_resample_i8d)
 extern "C" int llzs_resample_i16x_plan(int L, int M, int Q, int channels, long n_out, int shift, int *plan)
 {
     ri_shape sh;
     int waves, per_cu = 0;
     size_t lds;
     const void *fn = nullptr;
-    if (!plan || channels < 1 || n_out < 1 || !ri_make_shape(L, M, Q, n_out, &sh, &waves, &lds)) {
+    bool direct = false;
+    if (!plan || channels < 1 || n_out < 1 || !ri_pick_form(L, M, Q, (n_out / L) * M, n_out, &sh, &waves, &lds, &direct)) {
         llzs_set_error("resample_i16x_plan: bad arguments");
         return LLZ_ERR_ARG;
     }
-    const int rc = ri_plan(ri_ksteps(L, M, Q), shift - 40 < 0, sh.nt > waves, waves, lds, channels, &sh, &fn, &per_cu);
+    const int rc = ri_plan(direct, false, ri_ksteps(L, M, Q), shift - 40 < 0, sh.nt > waves, waves, lds, channels, &sh, &fn, &per_cu);
     if (rc != LLZ_OK) return rc;
     plan[0] = waves; plan[1] = sh.P; plan[2] = sh.spans_per_wg;
     plan[3] = (int)((sh.spans + sh.spans_per_wg - 1) / sh.spans_per_wg) * channels;
-    plan[4] = per_cu; plan[5] = (int)lds;
+    plan[4] = per_cu; plan[5] = (int)lds; plan[6] = direct ? 1 : 0;
     return LLZ_OK;
 }
 
@@ -443,14 +786,15 @@ extern "C" int llzs_resample_i16x_fits(int L, int M, int Q)
 // start on a period boundary (input index % M == 0, output index % L == 0).
 extern "C" int llzs_resample_i16x(const short *in, short *out, const short *hist, const signed char *atab, const int *aoff,
                                   const int *bqtab, const double *g, int channels, long n_in, long n_out, long in_pitch,
-                                  long out_pitch, int L, int M, int Q, int shift, double gain, double eps, void *stream)
+                                  long out_pitch, int L, int M, int Q, int shift, double gain, double eps, int any_exact, void *stream)
 {
     ri_shape sh;
     int waves;
     size_t lds;
+    bool direct = false;
     if (!in || !out || !atab || !aoff || !bqtab || !g || channels <= 0 || channels > 65535 || n_in <= 0 || n_out <= 0 ||
         in_pitch < n_in || out_pitch < n_out || shift < 32 || shift > 46 || !(eps > 0.0) || !(eps < 0.0625) ||
-        !llzs_resample_i16x_fits(L, M, Q) || !ri_make_shape(L, M, Q, n_out, &sh, &waves, &lds)) {
+        !llzs_resample_i16x_fits(L, M, Q) || !ri_pick_form(L, M, Q, n_in, n_out, &sh, &waves, &lds, &direct)) {
         llzs_set_error("resample_i16x: bad arguments (channels=%d L=%d M=%d Q=%d shift=%d eps=%g)", channels, L, M, Q, shift, eps);
         return LLZ_ERR_ARG;
     }
@@ -461,7 +805,7 @@ extern "C" int llzs_resample_i16x(const short *in, short *out, const short *hist
     const bool neg = sh.rs < 0, reload = sh.nt > waves;
     int per_cu = 0;
     const void *fn = nullptr;
-    const int prc = ri_plan(ks, neg, reload, waves, lds, channels, &sh, &fn, &per_cu);
+    const int prc = ri_plan(direct, any_exact != 0, ks, neg, reload, waves, lds, channels, &sh, &fn, &per_cu);
     if (prc != LLZ_OK) return prc;
     const dim3 grid((unsigned)((sh.spans + sh.spans_per_wg - 1) / sh.spans_per_wg), (unsigned)channels), block(64 * waves);
     void *args[] = {&in, &out, &hist, &atab, &aoff, &bqtab, &g, &n_in, &n_out, &in_pitch, &out_pitch, &sh};

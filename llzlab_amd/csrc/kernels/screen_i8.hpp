@@ -37,8 +37,10 @@ __device__ __forceinline__ void scr_start(int bq_lo, int bq_hi, int &s0, int &s2
 // an integer (then it is I itself, and `unsure` is always set: ignore it).
 template <bool NEG>
 __device__ __forceinline__ int scr_decide(int a0, int a1, int a2, int a3, int a4, int rs, unsigned e32, bool &unsure,
-                                          unsigned not_integer = 1u)
+                                          unsigned not_integer = 1u, unsigned e32_twice = 0u)
 {
+    // (e32_twice: 2 e32 from the caller's own scalar register when e32 itself sits in a vector register)
+    if (e32_twice == 0u) e32_twice = 2u * e32;
     const unsigned p = (unsigned)a0 + ((unsigned)a1 << 8);
     const int q = a2 + (a3 << 8);
     // (a4 : p) + (q << 16) as two 32-bit additions chained by the carry
@@ -54,7 +56,7 @@ __device__ __forceinline__ int scr_decide(int a0, int a1, int a2, int a3, int a4
         I = hi >> rs;
         F = __builtin_amdgcn_alignbit((unsigned)hi, lo, (unsigned)rs);
     }
-    unsure = F + e32 <= 2u * e32;                               // wrapping: the fraction is within e32 of 0 or of 1
+    unsure = F + e32 <= e32_twice;                              // wrapping: the fraction is within e32 of 0 or of 1
     // toward zero: the value is not an integer here, so a negative one moves up by one -- the sign bit, taken as a bit field
     // of width not_integer (0 where the caller knows the output IS an integer: then it is I itself)
     return I + (int)__builtin_amdgcn_ubfe((unsigned)I, 31u, not_integer);

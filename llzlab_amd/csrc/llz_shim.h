@@ -53,6 +53,7 @@ enum {
     LLZS_TUNE_MDCTQ_STEPS,          /* 1: fixed-point N/4-point MDCT as three launches (step, transform, step) */
     LLZS_TUNE_RS_I16_TILES,         /* bit-exact int16 L/M resampler: period tiles per span (1..4) */
     LLZS_TUNE_RS_I16_WALK,          /* ... consecutive spans per workgroup */
+    LLZS_TUNE_RS_I16_FORM,          /* ... 1: the first form (k_resample_i8x: output image in LDS, two barriers per span) */
     LLZS_TUNE_COUNT
 };
 int llzs_tune(int id);                                   /* current override or -1 */
@@ -213,15 +214,16 @@ int llzs_resample_i16(const short *in, short *out, const short *hist, const doub
                       int L, int M, int Q, double gain, long long i0, long long in0, void *stream);
 /* the same bit-exact int16 result for L >= 2, screened on the int8 matrix cores per phase (resample_i8.hip): atab [ceil(L/16)]
  * [steps][5][64][16] tap digits in operand order (steps = llzs_resample_i16x_ksteps), aoff [ceil(L/16)] band starts, bqtab
- * [16 ceil(L/16)][2] = floor(128 sum_k G_f[k] / 256) as (lo, hi), g the L x Q double taps, eps the largest per-phase bound.
+ * [16 ceil(L/16)][4] = floor(128 sum_k G_f[k] / 256) as (lo, hi), the phase's own e32, first | last << 8 non-zero tap | exact
+ * << 16; g the L x Q double taps, eps the largest per-phase bound, any_exact: some phase carries the exact flag.
  * The call must start on a period boundary (input index % M == 0, output index % L == 0). */
 int llzs_resample_i16x(const short *in, short *out, const short *hist, const signed char *atab, const int *aoff,
                        const int *bqtab, const double *g, int channels, long n_in, long n_out, long in_pitch, long out_pitch,
-                       int L, int M, int Q, int shift, double gain, double eps, void *stream);
+                       int L, int M, int Q, int shift, double gain, double eps, int any_exact, void *stream);
 int llzs_resample_i16x_fits(int L, int M, int Q);
 int llzs_resample_i16x_ksteps(int L, int M, int Q);
-/* the launch a call would make (measurement / documentation): plan[0..5] = waves per workgroup, periods per span, spans per
- * workgroup, workgroups, workgroups resident per CU, LDS bytes per workgroup */
+/* the launch a call would make (measurement / documentation): plan[0..6] = waves per workgroup, periods per span, spans per
+ * workgroup, workgroups, workgroups resident per CU, LDS bytes per workgroup, 1 for the direct form */
 int llzs_resample_i16x_plan(int L, int M, int Q, int channels, long n_out, int shift, int *plan);
 int llzs_tail_i16(const short *in, const short *hist_old, short *hist_new, int channels, long n, long in_pitch,
                   int keep, void *stream);

@@ -1645,7 +1645,7 @@ def test_resample_i16_screened_large_batch(dev, oracle):
 # ------------------------------------------------------------------------------------------------ int16 L/M resampler, screened per phase
 @pytest.mark.parametrize("L,M,win,gain", [(147, 160, po.BLACKMAN, 1.0), (160, 147, po.BLACKMAN, 1.0), (2, 3, po.HAMMING, 1.0),
                                           (3, 2, po.KAISER, 1.0), (20, 147, po.BLACKMAN, 1.0), (147, 160, po.HAMMING, 2.5),
-                                          (160, 147, po.KAISER, 0.37), (7, 5, po.BLACKMAN, 1e-3)])
+                                          (160, 147, po.KAISER, 0.37), (7, 5, po.BLACKMAN, 1e-3), (441, 320, po.BLACKMAN, 1.0)])
 def test_resample_i16_lm_screened_is_bit_exact(dev, oracle, L, M, win, gain):
     """LLZ_PCM_I16 with L >= 2 runs the per-phase integer screen on the matrix cores (resample_i8.hip: the reference CLI's own
     ratios 147:160 and 160:147 among them) and recomputes in the reference's double order only the outputs the screen cannot
@@ -1668,7 +1668,10 @@ def test_resample_i16_lm_screened_is_bit_exact(dev, oracle, L, M, win, gain):
     ref = oracle.rs_batch_i16(x, L, M, gain, win)
     outs, outs_plain = [], []
     cut = (frames // 2) * nin1                                                  # whole reference frames: a period boundary
-    for tuned, dst in (({}, outs), ({"rs_i16_path": 1}, outs_plain)):
+    outs_first = []
+    # the default (a wave per phase tile, results stored from the registers: k_resample_i8d, where it applies), the first form
+    # (k_resample_i8x: output image in LDS) and the all-double kernel
+    for tuned, dst in (({}, outs), ({"rs_i16_form": 1}, outs_first), ({"rs_i16_path": 1}, outs_plain)):
         with capi.tuned(**tuned):
             r = filters.ResampleMC(ch, L, M, gain, win, filters.PCM_I16)
             for (o, e) in ((0, cut), (cut, nin)):
@@ -1677,10 +1680,46 @@ def test_resample_i16_lm_screened_is_bit_exact(dev, oracle, L, M, win, gain):
                 assert r.process(xi, yi) == yi.shape[1]
                 dst.append(yi.cpu().numpy())
             r.close()
-    got, plain = np.concatenate(outs, axis=1), np.concatenate(outs_plain, axis=1)
+    got, plain, first = np.concatenate(outs, axis=1), np.concatenate(outs_plain, axis=1), np.concatenate(outs_first, axis=1)
     assert np.array_equal(plain, ref), "all-double kernel vs oracle"
-    bad = np.argwhere(got != ref)
-    assert bad.size == 0, (L, M, len(bad), bad[:5].tolist(), got[tuple(bad[0])], ref[tuple(bad[0])])
+    for form in (got, first):
+        bad = np.argwhere(form != ref)
+        assert bad.size == 0, (L, M, len(bad), bad[:5].tolist(), form[tuple(bad[0])], ref[tuple(bad[0])])
+
+
+@pytest.mark.parametrize("L,M", [(4, 3), (48, 7), (160, 147)])
+def test_resample_i16_lm_exact_and_empty_phases(dev, L, M):
+    """a caller's own polyphase matrix (llz_resample_mc_set_matrix) with a phase that is ONE tap 1.0 -- its outputs are the input
+    samples themselves, integers the screen reproduces exactly and must not move toward zero -- and a phase with no tap at all
+    (every output the integer 0): the screened kernels (both forms) against the all-double kernel, which follows the
+    reference's loop, and the exact phase against the samples it copies"""
+    ch, periods = 5, 400
+    rng = np.random.default_rng(L + M)
+    x = rng.integers(-32768, 32767, (ch, M * periods), dtype=np.int64).astype(np.int16)
+    x[1] = -32768
+    x[2, ::2] = -1
+    outs = {}
+    for name, tuned in (("direct", {}), ("first", {"rs_i16_form": 1}), ("double", {"rs_i16_path": 1})):
+        with capi.tuned(**tuned):
+            r = filters.ResampleMC(ch, L, M, 1.0, po.BLACKMAN, filters.PCM_I16)
+            m = r.matrix()
+            k = r.Q // 2
+            m[0] = 0.0
+            m[0, k] = 1.0
+            m[1] = 0.0
+            r.set_matrix(m)
+            y = torch.empty(ch, L * periods, dtype=torch.int16, device=dev)
+            assert r.process(torch.from_numpy(x).to(dev), y) == L * periods
+            outs[name] = y.cpu().numpy()
+            r.close()
+    assert np.array_equal(outs["direct"], outs["double"]) and np.array_equal(outs["first"], outs["double"])
+    # phase 0 of period m is x[M m - k] (zero history in front of the first call); phase 1 is silence
+    got0 = outs["direct"][:, 0::L]
+    want0 = np.zeros_like(got0)
+    idx = M * np.arange(periods) - k
+    want0[:, idx >= 0] = x[:, idx[idx >= 0]]
+    assert np.array_equal(got0, want0)
+    assert not outs["direct"][:, 1::L].any()
 
 
 # ------------------------------------------------------------------------------------------------ general direct form I, many channels

@@ -49,6 +49,6 @@ if L_ > 1 and len(sys.argv) > 4:
     capi.tune("rs_i16_walk", -1)
 if L_ > 1:
     import ctypes
-    plan = (ctypes.c_int * 6)()
+    plan = (ctypes.c_int * 7)()
     if Lb.llzs_resample_i16x_plan(L_, M_, r.Q, ch, ctypes.c_long(n * L_ // M_), 38, plan) == 0:
-        print("   plan: waves/wg %d, periods/span %d, spans/wg %d, workgroups %d, resident/CU %d, LDS %d B" % tuple(plan))
+        print("   plan: waves/wg %d, periods/span %d, spans/wg %d, workgroups %d, resident/CU %d, LDS %d B, direct form %d" % tuple(plan))

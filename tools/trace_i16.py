@@ -24,24 +24,28 @@ r = filters.ResampleMC(ch, L_, M_, 1.0, filters.BLACKMAN, filters.PCM_I16, strea
 for _ in range(20):
     r.process(x, y)
 torch.cuda.synchronize()
-plan = (ctypes.c_int * 6)()
+plan = (ctypes.c_int * 7)()
 Lb.llzs_resample_i16x_plan(L_, M_, r.Q, ch, ctypes.c_long(n * L_ // M_), 38, plan)
 waves, wgs = plan[0], plan[3]
 count = min(65536, waves * wgs)
 buf = np.zeros(count * 10, dtype=np.uint64)
 Lb.llzs_ri_trace_read(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(count * 10))
 t = buf.reshape(count, 10).astype(np.float64)
-names = ("planes written", "next span requested", "staging barrier", "(event counts)", "second barrier", "output stored",
-         "  per-tile constants", "  operand reads, products", "  decisions", "  second looks, image")
-print("plan: waves/wg %d, periods/span %d, spans/wg %d, workgroups %d, resident/CU %d, LDS %d B" % tuple(plan))
+names = ("planes written", "next span requested", "barrier (first form: staging barrier)", "(event counts)", "second barrier", "output stored",
+         "  per-tile constants / rest of the tile loop", "  operand reads, products", "  decisions", "  second looks, image / stores")
+print("plan: waves/wg %d, periods/span %d, spans/wg %d, workgroups %d, resident/CU %d, LDS %d B, direct form %d" % tuple(plan))
 spans = plan[2]
 print(f"shader-clock ticks per span, mean over {count} waves (and of wave 0 / the last wave of each workgroup)")
 for i, nm in enumerate(names):
     col = t[:, i] / spans
-    print(f"  {nm:24s} {col.mean():9.0f}   first wave {col[0::waves].mean():9.0f}   last wave {col[waves - 1::waves].mean():9.0f}")
-print(f"  total                    {t.sum(axis=1).mean() / spans:9.0f}")
+    print(f"  {nm:46s} {col.mean():9.0f}   first wave {col[0::waves].mean():9.0f}   last wave {col[waves - 1::waves].mean():9.0f}")
+t[:, 3] = 0
+print(f"  total {t.sum(axis=1).mean() / spans:9.0f}")
 ev = buf.reshape(count, 10)[:, 3]
 taken, looks = (ev >> np.uint64(32)).astype(np.float64), (ev & np.uint64(0xffffffff)).astype(np.float64)
 iters = spans * (plan[1] // 16)
 print(f"tile iterations with an undecided output: {taken.mean() / iters * 100:.1f} % (first wave {taken[0::waves].mean() / iters * 100:.1f} %, "
       f"last wave {taken[waves - 1::waves].mean() / iters * 100:.1f} %); second looks per tile iteration {looks.mean() / iters:.3f}")
+print("per wave of the workgroup (ticks per span):  " + "  ".join(n[:14].strip() for n in names if "event" not in n))
+for w in range(waves):
+    print(f"  wave {w:2d}: " + "  ".join(f"{t[w::waves, i].mean() / spans:8.0f}" for i in range(10) if i != 3))
