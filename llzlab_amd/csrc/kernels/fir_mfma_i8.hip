@@ -124,7 +124,23 @@ __device__ __forceinline__ void mx_pin(i16x8 (&v)[NV])
 __device__ __forceinline__ int mx_seg(int n) { return scr_col(n); }          // (screen_i8.hpp: why this order)
 __host__ __device__ __forceinline__ int mx_chunk(int kq) { return scr_chunk(kq); }
 
-template <int NACC, int NV, bool NEG>
+} // namespace
+// MX_TRACE (a measurement build only): shader-clock time of each phase of the tile loop, summed per wave (tools/trace_i16.py)
+#ifdef MX_TRACE
+__device__ unsigned long long mx_trace_buf[65536 * 8];
+#define MX_T0() unsigned long long mx_t = __builtin_readcyclecounter(), mx_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define MX_MARK(i) do { const unsigned long long now = __builtin_readcyclecounter(); mx_acc[i] += now - mx_t; mx_t = now; } while (0)
+#define MX_DUMP() do { if ((threadIdx.x & 63) == 0) { const unsigned w = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 65535u; \
+    for (int i = 0; i < 8; i++) mx_trace_buf[w * 8 + i] = mx_acc[i]; } } while (0)
+#else
+#define MX_T0() do { } while (0)
+#define MX_MARK(i) do { } while (0)
+#define MX_DUMP() do { } while (0)
+#endif
+namespace {
+
+// KS: the number of 64-sample steps when it is 1..3 (every LDS operand address is then base + constant), 0 = read sh.ksteps
+template <int NACC, int NV, bool NEG, int KS>
 __global__ void __launch_bounds__(MX_THREADS)
 k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const short *__restrict__ hist,
                const signed char *__restrict__ digits /* [MX_PLANES][T] */, const double *__restrict__ gd, long n_in,
@@ -132,9 +148,10 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int TILE_OUT = MX_WAVES * NACC * 256;
-    const int aplane = sh.ksteps * 1024;                 // A table: [planes][ksteps][64 lanes][16 bytes]
+    const int ksteps = KS > 0 ? KS : sh.ksteps;
+    const int abytes = MX_PLANES * ksteps * 1024;        // A table: [ksteps][planes][64 lanes][16 bytes]
     signed char *atab = reinterpret_cast<signed char *>(lds);
-    signed char *xs_lo = atab + MX_PLANES * aplane;      // sample planes: low digit (x & 255) - 128, then x >> 8
+    signed char *xs_lo = atab + abytes;                  // sample planes: low digit (x & 255) - 128, then x >> 8
     signed char *xs_hi = xs_lo + sh.plane;
     double *gd_lds = reinterpret_cast<double *>(xs_hi + sh.plane);      // the T double taps (recompute path)
     int *any_flag = reinterpret_cast<int *>(gd_lds + sh.T);             // two words: see the staging barrier
@@ -146,9 +163,9 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
     const bool aligned_in = (in_pitch & 7) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
     const bool aligned_out = (out_pitch & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0;
 
-    for (int e = tid; e < MX_PLANES * aplane; e += MX_THREADS) {
-        const int p = e / aplane, r = e - p * aplane;
-        const int s = r >> 10, l = (r >> 4) & 63, j = r & 15;
+    for (int e = tid; e < abytes; e += MX_THREADS) {
+        const int sp = e >> 10, s = sp / MX_PLANES, p = sp - s * MX_PLANES;
+        const int l = (e >> 4) & 63, j = e & 15;
         const int t = 64 * s + 16 * mx_chunk(l >> 4) + j;
         const int k = (l & 15) * sh.M + sh.tpad - t;
         atab[e] = (k >= 0 && k < sh.T) ? digits[p * sh.T + k] : (signed char)0;
@@ -185,8 +202,11 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
     }
 
     // front half of a tile: its samples into the LDS planes; returns "some sample is non-zero"
+    MX_T0();
+    [[maybe_unused]] int mx_tiles = 0;
     auto stage = [&](int c, int t, i16x8 (&v)[NV], bool streamed, int young) {
         __syncthreads();                                  // the previous tile's readers of the planes are done
+        MX_MARK(0);                                       // first barrier
         int nonzero = 0;
         if (streamed) {
             // the stores of the previous tile are the only operations younger than the request
@@ -228,8 +248,10 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         // (plain stores of the same value), read behind the staging barrier -- __syncthreads_or costs two more barriers and
         // an LDS atomic per tile.  The word of the NEXT tile is cleared here, behind this tile's barrier (its last readers
         // passed two barriers ago).
+        MX_MARK(1);                                       // request awaited, planes written
         if (__ballot(nonzero != 0) != 0 && lane == 0) any_flag[flip] = 1;
         __syncthreads();
+        MX_MARK(2);                                       // second barrier
         const int any = any_flag[flip];
         if (tid == 0) any_flag[flip ^ 1] = 0;
         flip ^= 1;
@@ -246,6 +268,16 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         start[2] = (i32x4){s4, s4, s4, s4};
     }
 
+    // lane constants of the back half: byte offset of the lane's B operand inside a plane and of its 8 output bytes inside
+    // the tile, per accumulator block
+    int b_lane[NACC];
+    unsigned o_lane[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+        b_lane[a] = ((wave * NACC + a) * 16 + seg) * 16 * sh.M + 16 * mx_chunk(kq);
+        o_lane[a] = 2u * (unsigned)(((wave * NACC + a) * 16 + seg) * 16 + 4 * kq);
+    }
+
     // back half: products, decisions, stores; returns the number of store instructions issued per lane (for the wait count)
     auto finish = [&](int t, long ooff, int any) {
         const long o0 = (long)t * TILE_OUT;
@@ -255,7 +287,8 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
             const int oo = ((wave * NACC + a) * 16 + seg) * 16 + 4 * kq;        // first of this lane's 4 outputs of block a
             const i16x4 y = scr_clamp4(r4);
             if (whole) {
-                *reinterpret_cast<i16x4 *>(otile + oo) = y;
+                // (SGPR base + the lane's constant offset: no address arithmetic per store)
+                asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(o_lane[a]), "v"(y), "s"(otile) : "memory");
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
@@ -270,20 +303,23 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         }
         i32x4 acc[NACC][MX_ACCS];
         {
-            const signed char *bp[NACC];
+            const signed char *bp[NACC], *bph[NACC];
 #pragma unroll
-            for (int a = 0; a < NACC; a++) bp[a] = xs_lo + ((wave * NACC + a) * 16 + seg) * 16 * sh.M + 16 * mx_chunk(kq);
+            for (int a = 0; a < NACC; a++) {
+                bp[a] = xs_lo + b_lane[a];
+                bph[a] = xs_hi + b_lane[a];
+            }
             const signed char *ap = atab + lane * 16;
             // one step = 64 window samples: tap planes 0..4 against the high sample plane (weights 1..5), planes 1..4 against
             // the low one (weights 1..4).  The first step starts every accumulator from the constant 0 (no zeroing pass).
             auto step = [&](int s, auto first_step) {
                 i32x4 ad[MX_PLANES], bd[NACC][2];
 #pragma unroll
-                for (int p = 0; p < MX_PLANES; p++) ad[p] = *reinterpret_cast<const i32x4 *>(ap + p * aplane + s * 1024);
+                for (int p = 0; p < MX_PLANES; p++) ad[p] = *reinterpret_cast<const i32x4 *>(ap + (s * MX_PLANES + p) * 1024);
 #pragma unroll
                 for (int a = 0; a < NACC; a++) {
                     bd[a][0] = *reinterpret_cast<const i32x4 *>(bp[a] + s * 64);
-                    bd[a][1] = *reinterpret_cast<const i32x4 *>(bp[a] + sh.plane + s * 64);
+                    bd[a][1] = *reinterpret_cast<const i32x4 *>(bph[a] + s * 64);
                 }
 #pragma unroll
                 for (int p = 0; p < MX_PLANES; p++)
@@ -300,11 +336,20 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
                         }
             };
             step(0, std::true_type{});
-            for (int s = 1; s < sh.ksteps; s++) step(s, std::false_type{});
+            if constexpr (KS > 0) {
+                if constexpr (KS > 1) step(1, std::false_type{});
+                if constexpr (KS > 2) step(2, std::false_type{});
+            } else {
+                for (int s = 1; s < ksteps; s++) step(s, std::false_type{});
+            }
         }
 
         // every output decided without a branch; a lane notes the slots it could not decide in a bit mask, and the rare lanes
         // that have any (about 2 eps of all outputs: most tiles have none) work them off one by one afterwards
+#ifdef MX_TRACE
+        asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[NACC - 1][4][0]));
+#endif
+        MX_MARK(4);                                                 // operand reads, products
         int res[NACC][4];
         bool unsure[NACC][4];
         unsigned long long open = 0;                                // lanes with an undecided slot (a scalar mask)
@@ -343,8 +388,13 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
                 }
             }
         }
+#ifdef MX_TRACE
+        asm volatile("s_nop 0" ::"v"(res[0][0]), "v"(res[NACC - 1][3]));
+#endif
+        MX_MARK(5);                                                 // decisions (and second looks)
 #pragma unroll
         for (int a = 0; a < NACC; a++) store4(a, res[a]);
+        MX_MARK(6);                                                 // stores
         return whole ? NACC : 0;
     };
 
@@ -366,8 +416,9 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         const short *src = next_streams ? in + (ioff_n - sh.tpad) : in;
 #pragma unroll
         for (int j = 0; j < NV; j++) v[j] = mx_load_nt(src, poff[j]);
+        MX_MARK(3);                                         // next tile requested
         young = 0;
-        if (in_work) young = finish(t, ooff, any);
+        if (in_work) { young = finish(t, ooff, any); mx_tiles++; }
         c = cn;
         t = tn;
         ooff = ooff_n;
@@ -375,6 +426,10 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         streamed = next_streams;
         advance(cn, tn, ioff_n, ooff_n);
     }
+#ifdef MX_TRACE
+    mx_acc[7] = (unsigned long long)mx_tiles;
+#endif
+    MX_DUMP();
 }
 
 bool mx_make_shape(int T, int M, int nacc, long n_out, mx_shape *sh, size_t *lds_bytes)
@@ -402,7 +457,7 @@ int mx_pick_nacc(int T, int M)
     return 0;
 }
 
-template <int NACC, int NV, bool NEG>
+template <int NACC, int NV, bool NEG, int KS>
 int mx_launch(const short *in, short *out, const short *hist, const signed char *digits, const double *gd, int channels,
               long n_in, long n_out, long in_pitch, long out_pitch, int T, int M, const mx_params &pr, void *stream)
 {
@@ -410,7 +465,7 @@ int mx_launch(const short *in, short *out, const short *hist, const signed char 
     size_t lds_bytes;
     mx_make_shape(T, M, NACC, n_out, &sh, &lds_bytes);
     if (lds_bytes > 64 * 1024)
-        LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma_i8x<NACC, NV, NEG>),
+        LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma_i8x<NACC, NV, NEG, KS>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     const long ntiles = (long)sh.tiles_per_ch * channels;
     int cus = 256, dev = 0;
@@ -422,7 +477,7 @@ int mx_launch(const short *in, short *out, const short *hist, const signed char 
     // a persistent grid: exactly the workgroups the chip holds at once (a workgroup that has to wait for a slot would
     // run its share of the tiles after everyone else: 768 workgroups on 512 slots measured 48 ms instead of 36)
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_fir_mfma_i8x<NACC, NV, NEG>),
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_fir_mfma_i8x<NACC, NV, NEG, KS>),
                                                      MX_THREADS, lds_bytes) != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 2;
@@ -430,7 +485,7 @@ int mx_launch(const short *in, short *out, const short *hist, const signed char 
     if (const int v = llzs_tune(LLZS_TUNE_MFMA_WG_PER_CU); v >= 1 && v <= 8) per_cu = v;
     long grid = (long)cus * per_cu;
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL((k_fir_mfma_i8x<NACC, NV, NEG>), dim3((unsigned)grid), dim3(MX_THREADS), lds_bytes, as_stream(stream),
+    hipLaunchKernelGGL((k_fir_mfma_i8x<NACC, NV, NEG, KS>), dim3((unsigned)grid), dim3(MX_THREADS), lds_bytes, as_stream(stream),
                        in, out, hist, digits, gd, n_in, n_out, in_pitch, out_pitch, sh, pr, channels);
     LLZ_LAUNCH_CHECK("k_fir_mfma_i8x");
     return LLZ_OK;
@@ -476,13 +531,31 @@ extern "C" int llzs_fir_mfma_i16x(const short *in, short *out, const short *hist
         return LLZ_ERR_RANGE;
     }
     const bool small = sh.total <= 4 * MX_THREADS * 8;
+#define MX_GO3(A, V, N, K) return mx_launch<A, V, N, K>(in, out, hist, digits, gd, channels, n_in, n_out, in_pitch, out_pitch, T, M, pr, stream)
+#define MX_GO2(A, V, N)                                                                                                        \
+    do {                                                                                                                       \
+        if (sh.ksteps == 1) MX_GO3(A, V, N, 1);                                                                                \
+        if (sh.ksteps == 2) MX_GO3(A, V, N, 2);                                                                                \
+        if (sh.ksteps == 3) MX_GO3(A, V, N, 3);                                                                                \
+        MX_GO3(A, V, N, 0);                                                                                                    \
+    } while (0)
 #define MX_GO(A, V)                                                                                                            \
     do {                                                                                                                       \
-        if (pr.rs < 0)                                                                                                         \
-            return mx_launch<A, V, true>(in, out, hist, digits, gd, channels, n_in, n_out, in_pitch, out_pitch, T, M, pr, stream); \
-        return mx_launch<A, V, false>(in, out, hist, digits, gd, channels, n_in, n_out, in_pitch, out_pitch, T, M, pr, stream);    \
+        if (pr.rs < 0) MX_GO2(A, V, true);                                                                                     \
+        MX_GO2(A, V, false);                                                                                                   \
     } while (0)
     if (nb == 2) { if (small) MX_GO(2, 4); else MX_GO(2, 8); }
     if (small) MX_GO(1, 4); else MX_GO(1, 8);
 #undef MX_GO
+#undef MX_GO2
+#undef MX_GO3
 }
+
+#ifdef MX_TRACE
+extern "C" int llzs_mx_trace_read(unsigned long long *dst, int count)
+{
+    LLZ_HIP_CHECK(hipDeviceSynchronize());
+    LLZ_HIP_CHECK(hipMemcpyFromSymbol(dst, HIP_SYMBOL(mx_trace_buf), sizeof(unsigned long long) * (size_t)count));
+    return LLZ_OK;
+}
+#endif
