@@ -377,13 +377,13 @@ def main():
         for key, kern in (("resample_1to3_f32_8192ch_sharded", "k_fir_mfma_bf16x3#0"), ("resample_1to3_i16_exact_8192ch_sharded", "k_fir_mfma_i8x#0"),
                           ("resample_1to3_i16_fast_8192ch_sharded", "k_fir_mfma_i16#0"), ("iir8_1024ch_sharded", "k_iir_cascade_wave_pk32#0"),
                           ("iir8_r099_1024ch_sharded", "k_iir_cascade_wave_pf64w#0"), ("resample_147to160_f32_256ch", "k_resample_mfma_pt_f32#0"),
-                          ("resample_160to147_f32_256ch", "k_resample_mfma_pt_f32#1"), ("resample_147to160_i16_256ch", "k_resample_i8x#0"),
-                          ("resample_160to147_i16_256ch", "k_resample_i8x#1")):
+                          ("resample_160to147_f32_256ch", "k_resample_mfma_pt_f32#1"), ("resample_147to160_i16_256ch", "k_resample_i8d#0"),
+                          ("resample_160to147_i16_256ch", "k_resample_i8d#1")):
             rec = recs.get(kern)
             if rec and key in also and "error" not in also[key]:
                 files = {"k_iir": ["iir.hip"], "k_fir_mfma_bf16x3": ["fir_mfma.hip"], "k_fir_mfma_i16": ["fir_mfma.hip"],
                          "k_fir_mfma_i8x": ["fir_mfma_i8.hip", "screen_i8.hpp"], "k_resample_mfma": ["resample_mfma.hip"],
-                         "k_resample_i8x": ["resample_i8.hip", "screen_i8.hpp"]}
+                         "k_resample_i8d": ["resample_i8.hip", "screen_i8.hpp"]}
                 src = next(v for p_, v in files.items() if kern.startswith(p_))
                 import hashlib
                 h = hashlib.sha256()

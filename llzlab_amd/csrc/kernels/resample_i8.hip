@@ -508,6 +508,7 @@ k_resample_i8d(const short *__restrict__ in, short *__restrict__ out, const shor
         unsigned b_at = (unsigned)(2 * b * sh.plane + lead + col16 * sh.M + a_t + 16 * ck);       // LDS byte address of the lane's B operand
         unsigned o_at = 2u * (unsigned)(col16 * sh.L + f0);                       // byte offset of the lane's 8 output bytes in the span
         const unsigned b_step = 16u * (unsigned)sh.M, o_step = 32u * (unsigned)sh.L;
+        const int tail = f0 + 3 < sh.L ? 4 : (f0 < sh.L ? sh.L - f0 : 0);         // values of the lane that are phases
 #pragma unroll 1
         for (int p = 0; p < sh.pt; p++, b_at += b_step, o_at += o_step) {
             const signed char *bp = reinterpret_cast<const signed char *>(lds) + b_at;
@@ -567,13 +568,18 @@ k_resample_i8d(const short *__restrict__ in, short *__restrict__ out, const shor
             if (whole) {
                 asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(o_at), "v"(y), "s"(ospan) : "memory");
             } else if (16 * p + col16 < left) {
-                short *op = reinterpret_cast<short *>(reinterpret_cast<char *>(ospan) + o_at);
-                if (f0 + 3 < sh.L) {
-                    reinterpret_cast<ri_g64 *>(op)->v = y;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 3; j++)
-                        if (f0 + j < sh.L) op[j] = y[j];
+                // the ragged last tile (and the last span): whole lanes as above; the lane group that straddles the last phase
+                // stores its 1..3 values as a 4-byte and / or a 2-byte piece (tail: the same for the whole launch)
+                if (tail == 4) {
+                    asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(o_at), "v"(y), "s"(ospan) : "memory");
+                } else if (tail > 0) {
+                    const scr_i16x2 y01 = {y[0], y[1]};
+                    if (tail >= 2) asm volatile("global_store_dword %0, %1, %2" : : "v"(o_at), "v"(y01), "s"(ospan) : "memory");
+                    if (tail == 1) asm volatile("global_store_short %0, %1, %2" : : "v"(o_at), "v"(y01), "s"(ospan) : "memory");
+                    if (tail == 3) {
+                        const int y2 = y[2];
+                        asm volatile("global_store_short %0, %1, %2 offset:4" : : "v"(o_at), "v"(y2), "s"(ospan) : "memory");
+                    }
                 }
             }
             RI_MARK(9);                                 // stores

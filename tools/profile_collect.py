@@ -179,8 +179,12 @@ ALGO = [   # (kernel name part, occurrence in dispatch order, workload, algorith
     ("k_fir_mfma_i16", 0, "config 5 int16 fast (1 LSB), 2048 ch x 4 Mi, 1:3", (2 + 2 / 3) * 2048 * N5),
     ("k_resample_mfma_pt_f32", 0, "147:160 float32, 256 ch x 160 x 8192", (4 + 4 * 147 / 160) * 256 * 160 * 8192),
     ("k_resample_mfma_pt_f32", 1, "160:147 float32, 256 ch x 147 x 8192", (4 + 4 * 160 / 147) * 256 * 147 * 8192),
-    ("k_resample_i8x", 0, "147:160 int16 bit-exact, 256 ch x 160 x 8192", (2 + 2 * 147 / 160) * 256 * 160 * 8192),
-    ("k_resample_i8x", 1, "160:147 int16 bit-exact, 256 ch x 147 x 8192", (2 + 2 * 160 / 147) * 256 * 147 * 8192),
+    ("k_resample_i8d", 0, "147:160 int16 bit-exact, 256 ch x 160 x 8192", (2 + 2 * 147 / 160) * 256 * 160 * 8192),
+    ("k_resample_i8d", 1, "160:147 int16 bit-exact, 256 ch x 147 x 8192", (2 + 2 * 160 / 147) * 256 * 147 * 8192),
+    ("k_mdct4_q15", 0, "fixed-point MDCT forward, N = 2048 x 65536 frames (int32 in, N/2 int32 out)", 6 * 2048 * 65536),
+    ("k_mdct4_q15", 1, "fixed-point MDCT inverse, N = 2048 x 65536 frames", 6 * 2048 * 65536),
+    ("k_mdct_reg_f32", 0, "MDCT frames analysis, F = 256, 1024 ch x 1024 frames (float32 in and out)", 8 * 256 * 1024 * 1024),
+    ("k_mdct_reg_f32", 1, "MDCT frames synthesis in runs of 16 segments, same shape", 8 * 256 * 1024 * 1024),
 ]
 
 
@@ -204,7 +208,8 @@ def sha_of(files):
 
 SRC = {"k_iir": ["iir.hip"], "k_fir_mfma_bf16x3": ["fir_mfma.hip"], "k_fir_mfma_i16": ["fir_mfma.hip"],
        "k_fir_mfma_i8x": ["fir_mfma_i8.hip", "screen_i8.hpp"], "k_resample_mfma": ["resample_mfma.hip"],
-       "k_resample_i8x": ["resample_i8.hip", "screen_i8.hpp"]}
+       "k_resample_i8d": ["resample_i8.hip", "screen_i8.hpp"], "k_mdct4_q15": ["mdct_q15.hip", "fft_core.hpp"],
+       "k_mdct_reg_f32": ["fft.hip", "fft_core.hpp"]}
 if os.path.isdir(os.path.join(src, "set_fetch")):
     sf, sw, ssq = counters("set_fetch"), counters("set_write"), counters("set_sq")
     kernels = {}

@@ -121,5 +121,22 @@ elif what == "traffic_set":
         go(lambda: r.process(xi, yi))
         r.close()
         del x, y, xi, yi
+    # rank 4 of the widening: fixed-point MDCT (N/4-point form, one launch), MDCT-frames synthesis in runs of segments
+    n, count = 2048, 1 << 16
+    xq = torch.randint(-(1 << 20), 1 << 20, (count, n), dtype=torch.int32, device=dev)
+    Xq = torch.empty(count, n // 2, dtype=torch.int32, device=dev)
+    mq = filters.MdctFixed(2, n)
+    go(lambda: mq.forward_batch(xq, Xq))
+    go(lambda: mq.inverse_batch(Xq, xq))
+    mq.close()
+    del xq, Xq
+    F, ch, frames = 256, 1024, 1024
+    xf = torch.rand(ch, frames * F, dtype=torch.float32, device=dev) * 2 - 1
+    Xf = torch.empty(ch, frames, F, dtype=torch.float32, device=dev)
+    mf = filters.MdctFramesMC(ch, F, capi.MDCT_SINE)
+    go(lambda: mf.analysis(xf, Xf))
+    go(lambda: mf.synthesis(Xf, xf))
+    mf.close()
+    del xf, Xf
 torch.cuda.synchronize()
 print("done", what)
