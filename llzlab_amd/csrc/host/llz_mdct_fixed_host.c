@@ -234,9 +234,12 @@ static int mdcx_run(unsigned long handle, const int *in, int *out, int count, in
         d_out = (int *)llz_stage_reserve(inverse ? &f->time : &f->bins, ob);
         if (!d_out) rc = LLZ_ERR_NOMEM;
     }
-    /* (a launch takes at most 65535 frames: the frame index is the grid's second dimension) */
-    for (int done = 0; rc == LLZ_OK && done < count; done += 65535) {
-        const int part = count - done < 65535 ? count - done : 65535;
+    /* (a launch of the step kernels takes at most 65535 frames: the frame index is the grid's second dimension; the one-launch
+     * N/4-point form takes any number) */
+    const int whole = f->form == MDCT_FIXED_FFT4 && llzs_tune(LLZS_TUNE_MDCTQ_STEPS) < 1;
+    const int most = whole ? count : 65535;
+    for (int done = 0; rc == LLZ_OK && done < count; done += most) {
+        const int part = count - done < most ? count - done : most;
         const size_t n_in = inverse ? (size_t)f->length / 2 : (size_t)f->length, n_out = inverse ? (size_t)f->length : (size_t)f->length / 2;
         rc = mdcx_on_device(f, d_in + (size_t)done * n_in, d_out + (size_t)done * n_out, part, inverse);
     }

@@ -48,7 +48,7 @@ json.dump(warm, open(os.path.join(dst, f"{tag}_headline_kernel_trace.json"), "w"
 
 
 def counters(sub):
-    """{(kernel name, grid size): {counter: [value per dispatch]}} plus the dispatch durations (ms) under the key "_ms".
+    """{(kernel name, grid size, run): {counter: [value per dispatch]}} plus the dispatch durations (ms) under the key "_ms".
     One kernel name can be launched with several grids in one run (the headline batch and the 64-channel config share
     k_fir_ols_chain_f32): dispatches are told apart by (name, grid), never averaged across grids."""
     f = newest(f"{src}/{sub}/*/*_counter_collection.csv")
@@ -56,12 +56,24 @@ def counters(sub):
     seen = set()
     for r in csv.DictReader(open(f)):
         key = (r["Kernel_Name"], r["Grid_Size"])
-        agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[key][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
         if (key, r["Dispatch_Id"]) not in seen:
             seen.add((key, r["Dispatch_Id"]))
-            agg[key]["_ms"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-            agg[key]["_id"].append(int(r["Dispatch_Id"]))
-    return agg
+            agg[key]["_ms"].append((int(r["Dispatch_Id"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
+            agg[key]["_id"].append((int(r["Dispatch_Id"]), int(r["Dispatch_Id"])))
+    # two workloads of one kernel may share name AND grid (147:160 and 160:147 on k_resample_i8d): a workload's launches follow
+    # each other within a few dispatches, so a group is split where the dispatch ids jump
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    for key, cols in agg.items():
+        ids = sorted(i for i, _ in cols["_id"])
+        run_of, run = {}, 0
+        for a, b in zip([ids[0]] + ids, ids):
+            run += b - a > 8
+            run_of[b] = run
+        for c, vals in cols.items():
+            for i, v in vals:
+                out[(key[0], key[1], run_of[i])][c].append(v)
+    return out
 
 
 def pick(agg, needle, grid=None):
