@@ -696,10 +696,12 @@ static long rsm_process(rsm_t *r, unsigned long handle, const void *in, long n_i
                      LLZ_ERR_RANGE)
             ;                                   /* (LLZ_ERR_RANGE: a frame too short or misaligned for the screened kernel) */
         else if (r->fmt == LLZ_PCM_I16 && r->use_screen_lm && r->in_count % r->M == 0 && r->out_count % r->L == 0 &&
-                 r->channels <= 65535)
-            rc = llzs_resample_i16x((const short *)d_in, (short *)d_out, (const short *)hist, r->d_scr_atab, r->d_scr_aoff,
-                                    r->d_scr_bq, (const double *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->L, r->M,
-                                    r->Q, r->screen_shift, r->gain, r->screen_eps, r->screen_any_exact, r->stream);
+                 r->channels <= 65535 &&
+                 (rc = llzs_resample_i16x((const short *)d_in, (short *)d_out, (const short *)hist, r->d_scr_atab, r->d_scr_aoff,
+                                          r->d_scr_bq, (const double *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->L,
+                                          r->M, r->Q, r->screen_shift, r->gain, r->screen_eps, r->screen_any_exact,
+                                          r->stream)) != LLZ_ERR_RANGE)
+            ;                                   /* (LLZ_ERR_RANGE: a frame shorter than one span's image) */
         else if (r->fmt == LLZ_PCM_I16)
             rc = llzs_resample_i16((const short *)d_in, (short *)d_out, (const short *)hist,
                                    (const double *)r->d_mat, r->channels, n_in, n_out, n_in, n_out, r->L, r->M,

@@ -18,14 +18,27 @@
 // stays in the wave's registers while it walks the period tiles of a span.  The LDS image is the span's samples as two
 // CONTIGUOUS byte planes (low digit (x & 255) - 128, high digit x >> 8; written 8 samples at a time): period n's window starts
 // M n bytes into a plane, so a B operand is ONE ds_read_b128 at an arbitrary byte address -- unaligned 16-byte LDS reads are
-// legal on gfx950 (it is what hipcc itself emits for an under-aligned load), and no second copy of any sample is needed (a
-// first version kept one aligned column per period: 1.7 copies of every sample, byte stores when M is odd -- 3.6 ms against
-// 1.2 ms at 160:147 / 147:160).  Results go to an LDS image of the output in memory order and leave in 8-byte pieces; the next
-// span's samples are requested one span ahead into registers.
+// legal on gfx950 (it is what hipcc itself emits for an under-aligned load; measured cost 13 %), and no second copy of any
+// sample is needed (a first version kept one aligned column per period: 1.7 copies of every sample, byte stores when M is
+// odd -- 3.6 ms against 1.2 ms at 160:147 / 147:160).
+//
+// Structure of the kernel (its first form -- output image in LDS, two barriers per span, tiles dealt over at most eight waves,
+// per-tile constants fetched per span -- took 0.99 / 1.02 ms at 147:160 / 160:147; profiles/r03/ab_resample_i8x_general.txt has
+// the phase times that led here: 0.57 / 0.68 ms):
+//   * every wave owns ONE phase tile for the whole launch where the tiles fit the workgroup (twelve waves: L <= 192) and keeps
+//     its digits, start values and masks in registers; more tiles are dealt evenly over the waves and set up per span;
+//   * four consecutive phases of one period are 8 contiguous bytes of the output row: one global store per lane and period
+//     tile at an even byte address -- no output image in LDS (its unaligned 8-byte LDS writes measured ~650 clocks per period
+//     tile), no copy-out phase, no second barrier.  The waves of a period fill its 2 L bytes within one span, so the lines
+//     leave L2 whole;
+//   * the planes are DOUBLE-BUFFERED: span i + 1 is written while slower waves still read span i -- ONE barrier per span;
+//   * the next span's samples are requested by hand (global_load ... from an SGPR base, as in fir_mfma_i8.hip) and awaited
+//     with the count of younger stores, so staging does not wait for the previous span's stores to be acknowledged.  Spans at
+//     a frame's edges (history in front, zeros behind) and the first span of a walk are staged sample by sample.
 #include "screen_i8.hpp"
 #include <math.h>
 
-// RI_TRACE (a measurement build only: tools/ubench/Makefile): shader-clock time of each phase of the span loop, summed per wave
+// RI_TRACE (a measurement build only, tools/trace_i16.py says how): shader-clock time of each phase of the span loop, summed per wave
 #ifdef RI_TRACE
 __device__ unsigned long long ri_trace_buf[65536 * 10];
 #define RI_T0() unsigned long long ri_t = __builtin_readcyclecounter(), ri_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned ri_cnt[2] = {0, 0}
@@ -63,7 +76,6 @@ struct ri_shape {
 };
 
 struct __attribute__((packed, aligned(1))) ri_b128 { scr_i32x4 v; };      // a 16-byte LDS read at any byte address
-struct __attribute__((packed, aligned(2))) ri_o64 { scr_i16x4 v; };        // an 8-byte LDS write at any even byte address
 
 // the reference's loop for one output from the planes: the sample at image position p is 256 hi[p] + lo[p] + 128
 // (taps k < k0 and k > k1 are zero: adding x * 0 = +-0 to the running sum changes nothing, bit for bit -- phase 0 of an
@@ -85,261 +97,6 @@ __device__ __forceinline__ short ri_exact(const signed char *hi, const signed ch
     return (short)y;                                // :601, toward zero
 }
 
-template <int KS, bool NEG, bool RELOAD>
-__global__ void __launch_bounds__(KS == 1 ? 1024 : 512)
-k_resample_i8x(const short *__restrict__ in, short *__restrict__ out, const short *__restrict__ hist,
-               const signed char *__restrict__ atab /* [nt][KS][5][64][16] */, const int *__restrict__ aoff /* [nt] */,
-               const int *__restrict__ bqtab /* [16 nt][4]: bias lo, hi; e32; first | last << 8 non-zero tap | exact << 16 */, const double *__restrict__ g /* [L][Q] */, long n_in, long n_out,
-               long in_pitch, long out_pitch, ri_shape sh)
-{
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    signed char *xs_lo = reinterpret_cast<signed char *>(lds);
-    signed char *xs_hi = xs_lo + sh.plane;
-    short *oimg = reinterpret_cast<short *>(xs_hi + sh.plane);          // [P][L] outputs in memory order
-    const int tid = threadIdx.x, lane = tid & 63, threads = (int)blockDim.x, waves = threads >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 15, kq = lane >> 4;
-    const int col16 = scr_col(n), ck = scr_chunk(kq);
-    const int c = blockIdx.y;
-    const short *row = in + (size_t)c * in_pitch;
-    const short *hrow = hist ? hist + (size_t)c * (sh.Q - 1) : nullptr;
-    short *orow = out + (size_t)c * out_pitch;
-    const bool vec_in = (in_pitch & 7) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
-    const bool vec_out = (out_pitch & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0;
-
-    // a span's samples: from absolute index M m0 - Hp on, requested in 16-byte groups starting at the 8-aligned index at or below it
-    i16x8 v[RI_NG];
-    auto request = [&](long m0s) {
-        const long s0 = m0s * sh.M - sh.Hp;
-        const long gbase = s0 >= 0 ? (s0 & ~7L) : -((-s0 + 7) & ~7L);
-#pragma unroll
-        for (int k = 0; k < RI_NG; k++) {
-            const int gi = k * threads + tid;
-            i16x8 w = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (gi < sh.ngroups) {
-                const long a = gbase + 8L * gi;
-                if (vec_in && a >= 0 && a + 8 <= n_in) {
-                    w = __builtin_nontemporal_load(reinterpret_cast<const i16x8 *>(row + a));
-                } else {
-                    // a frame edge (history in front, zeros behind) or an unaligned frame: sample by sample, packed into dwords
-                    unsigned d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-#pragma unroll 1
-                    for (int e = 0; e < 8; e++) {
-                        const long idx = a + e;
-                        int x = 0;
-                        if (idx >= 0) {
-                            if (idx < n_in) x = row[idx];
-                        } else if (hrow && idx >= -(long)(sh.Q - 1)) {
-                            x = hrow[sh.Q - 1 + idx];
-                        }
-                        const unsigned bits = ((unsigned)x & 0xffffu) << (16 * (e & 1));
-                        d0 |= (e >> 1) == 0 ? bits : 0u;
-                        d1 |= (e >> 1) == 1 ? bits : 0u;
-                        d2 |= (e >> 1) == 2 ? bits : 0u;
-                        d3 |= (e >> 1) == 3 ? bits : 0u;
-                    }
-                    w = __builtin_bit_cast(i16x8, (u32x4){d0, d1, d2, d3});
-                }
-            }
-            v[k] = w;
-        }
-    };
-
-    scr_i32x4 ad[KS][5];
-    auto load_a = [&](int t) {
-        const signed char *ap = atab + ((size_t)t * KS * 5) * 1024 + lane * 16;
-#pragma unroll
-        for (int s = 0; s < KS; s++)
-#pragma unroll
-            for (int p = 0; p < 5; p++) ad[s][p] = *reinterpret_cast<const scr_i32x4 *>(ap + (s * 5 + p) * 1024);
-    };
-    // Per phase tile: the band start, scr_start of the lane's four phases, and lane masks, one per slot, of the EXACT phases (a
-    // phase whose only tap is 1.0: its outputs are integers -- always "unsure", and not to be moved toward zero) and of the
-    // slots that never need a second look (those, and the rows past the last phase: all-zero taps, the value 0 exactly).  A
-    // wave that keeps its one tile sets these up once, like the tile's digits.
-    int a_t = 0;
-    scr_i32x4 start[3] = {};
-    unsigned long long exact[4] = {0, 0, 0, 0}, settled[4] = {0, 0, 0, 0};
-    bool some_exact = false;                                                          // (wave-uniform)
-    auto tile_setup = [&](int t) {
-        a_t = aoff[t];
-        const int f0 = 16 * t + 4 * kq;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const scr_i32x4 row4 = *reinterpret_cast<const scr_i32x4 *>(bqtab + 4 * (f0 + j));
-            int s0, s2, s4;
-            scr_start(row4[0], row4[1], s0, s2, s4);
-            start[0][j] = s0;
-            start[1][j] = s2;
-            start[2][j] = s4;
-            exact[j] = __ballot((row4[3] >> 16) != 0);
-            settled[j] = exact[j] | __ballot(f0 + j >= sh.L);
-        }
-        some_exact = (exact[0] | exact[1] | exact[2] | exact[3]) != 0;
-    };
-    if (!RELOAD && wave < sh.nt) {
-        load_a(wave);
-        tile_setup(wave);
-    }
-
-    const int P = sh.P;
-    const long span0 = (long)blockIdx.x * sh.spans_per_wg;
-    const long span1 = min(span0 + sh.spans_per_wg, sh.spans);
-    if (span0 < span1) request(span0 * P);
-    RI_T0();
-    for (long sp = span0; sp < span1; sp++) {
-        const long m0 = sp * P;
-        const long s0 = m0 * sh.M - sh.Hp;
-        // the image starts at the 8-aligned sample index at or below s0: window position pos of period q sits `lead + M q + pos`
-        // bytes into a plane
-        const int lead = (int)(s0 - (s0 >= 0 ? (s0 & ~7L) : -((-s0 + 7) & ~7L)));
-        // ---- the requested groups into the planes (the previous span's readers passed the barrier at its end) ----
-#pragma unroll
-        for (int k = 0; k < RI_NG; k++) {
-            const int gi = k * threads + tid;
-            if (gi < sh.ngroups) {
-                const u32x4 d = __builtin_bit_cast(u32x4, v[k]);
-                u32x2 lo, hi;
-                lo[0] = __builtin_amdgcn_perm(d[1], d[0], 0x06040200u) ^ 0x80808080u;
-                lo[1] = __builtin_amdgcn_perm(d[3], d[2], 0x06040200u) ^ 0x80808080u;
-                hi[0] = __builtin_amdgcn_perm(d[1], d[0], 0x07050301u);
-                hi[1] = __builtin_amdgcn_perm(d[3], d[2], 0x07050301u);
-                *reinterpret_cast<u32x2 *>(&xs_lo[8 * gi]) = lo;
-                *reinterpret_cast<u32x2 *>(&xs_hi[8 * gi]) = hi;
-            }
-        }
-        RI_MARK(0);                                    // planes written
-        if (sp + 1 < span1) request(m0 + P);
-        RI_MARK(1);                                    // next span requested
-        __syncthreads();
-        RI_MARK(2);                                    // staging barrier
-
-        // ---- products and decisions: this wave's phase tile(s) x the span's period tiles ----
-        const long periods_left = sh.periods - m0;                                // periods of this span that exist
-        for (int t = wave; t < sh.nt; t += waves) {
-            if (RELOAD) {
-                load_a(t);
-                tile_setup(t);
-            }
-            const int f0 = 16 * t + 4 * kq;                                       // the lane's first phase (row 4 kq) of the tile
-            RI_MARK(6);                                // per-tile constants
-#pragma unroll 1
-            for (int p = 0; p < sh.pt; p++) {
-                const int col = 16 * p + col16;
-                const signed char *bp = xs_lo + lead + col * sh.M + a_t + 16 * ck;
-                scr_i32x4 acc[5];
-#pragma unroll
-                for (int s = 0; s < KS; s++) {
-                    const scr_i32x4 b_lo = reinterpret_cast<const ri_b128 *>(bp + 64 * s)->v;
-                    const scr_i32x4 b_hi = reinterpret_cast<const ri_b128 *>(bp + sh.plane + 64 * s)->v;
-                    if (s == 0) scr_step<true>(acc, ad[s], b_lo, b_hi, start);
-                    else scr_step<false>(acc, ad[s], b_lo, b_hi, start);
-                }
-                int res[4];
-                bool unsure[4];
-                unsigned long long open = 0;                                      // lanes with an undecided slot (a scalar mask)
-#ifdef RI_TRACE
-                asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[4][0]));         // (the products have landed)
-#endif
-                RI_MARK(7);                            // operand reads and products
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    res[j] = scr_decide<NEG>(acc[0][j], acc[1][j], acc[2][j], acc[3][j], acc[4][j], sh.rs, sh.e32, unsure[j]);
-                    open |= __ballot(unsure[j]) & ~settled[j];
-                }
-#ifdef RI_TRACE
-                asm volatile("s_nop 0" ::"v"(res[0]), "v"(res[3]), "s"(open));
-#endif
-                RI_MARK(8);                            // decisions
-                if (some_exact) {                                                 // (the wave of phase tile 0, as a rule)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        bool dummy;
-                        const int whole = scr_decide<NEG>(acc[0][j], acc[1][j], acc[2][j], acc[3][j], acc[4][j], sh.rs, sh.e32, dummy, 0u);
-                        res[j] = ((exact[j] >> lane) & 1ull) ? whole : res[j];
-                    }
-                }
-#ifdef RI_TRACE
-                ri_cnt[0] += open != 0 ? 1 : 0;
-#endif
-                if (open != 0) {
-                    unsigned mine = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        mine = mine + mine + ((unsure[j] && !((settled[j] >> lane) & 1ull)) ? 1u : 0u);    // slot j at bit 3 - j
-#pragma unroll 1
-                    while (mine != 0) {
-                        // an integer within eps of the value: the reference's own arithmetic decides, in the lane that found it
-                        const int j = 3 - __builtin_ctz(mine);
-                        mine &= mine - 1;
-                        const int f = f0 + j;
-                        int cur = 0;
-#pragma unroll
-                        for (int u = 0; u < 4; u++) cur = j == u ? res[u] : cur;
-                        // (a value far outside the clamp range needs no second look, nor does a row or period that does not exist)
-                        if (f < sh.L && col < periods_left && scr_in_reach(cur)) {
-                            const int cf = (int)(((long)f * sh.M) / sh.L);
-                            const int kr = bqtab[4 * f + 3] & 0xffff;             // first | last << 8 non-zero tap of the phase
-#ifdef RI_TRACE
-                            ri_cnt[1] += 1;
-#endif
-                            const int r = ri_exact(xs_hi, xs_lo, lead + col * sh.M + cf + sh.Hp, g + (size_t)f * sh.Q, kr & 255, kr >> 8,
-                                                   sh.gain);
-#pragma unroll
-                            for (int u = 0; u < 4; u++) res[u] = j == u ? r : res[u];
-                        }
-                    }
-                }
-                // four consecutive phases of one period: 8 bytes of the output image (at any even byte address)
-                short *op = oimg + col * sh.L + f0;
-                const scr_i16x4 y = scr_clamp4(res);
-                if (f0 + 3 < sh.L) {
-                    reinterpret_cast<ri_o64 *>(op)->v = y;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 3; j++)
-                        if (f0 + j < sh.L) op[j] = y[j];
-                }
-                RI_MARK(9);                            // second looks, output image
-            }
-        }
-        RI_MARK(3);                                    // products and decisions
-        __syncthreads();
-        RI_MARK(4);                                    // second barrier
-
-        // ---- the output image leaves in memory order ----
-        short *ospan = orow + m0 * sh.L;
-        const long left = n_out - m0 * sh.L;
-        const int total = (int)(left < (long)P * sh.L ? left : (long)P * sh.L);
-        if (vec_out) {                                                           // (m0 L is a multiple of 16: 8-byte pieces stay aligned)
-            const int quads = total >> 2;
-            for (int e = tid; e < quads; e += threads)
-                *reinterpret_cast<i16x4 *>(ospan + 4 * e) = *reinterpret_cast<const i16x4 *>(oimg + 4 * e);
-            for (int e = 4 * quads + tid; e < total; e += threads) ospan[e] = oimg[e];
-        } else {
-            for (int e = tid; e < total; e += threads) ospan[e] = oimg[e];
-        }
-        // (the next span's image is written by threads that have passed the barrier above: nobody reads the planes any more;
-        //  the output image is next written behind the next span's staging barrier)
-        RI_MARK(5);                                    // output image stored
-    }
-    RI_DUMP();
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// The same arithmetic with every wave on its own phase tile for the whole launch (up to 12 waves: L <= 192), the sample planes
-// DOUBLE-BUFFERED and the results stored straight from the registers:
-//   * a wave keeps its tile's digits, start values and masks in registers from the first span to the last (the first form
-//     fetched them again per span and tile: ~600 clocks of exposed latency per span);
-//   * four consecutive phases of one period are 8 contiguous bytes of the output row: one global store per lane and period
-//     tile at an even byte address -- no output image in LDS (its unaligned 8-byte LDS writes measured ~650 clocks per period
-//     tile), no copy-out phase, no second barrier.  The ten waves of a period fill its 2 L bytes within one span, so the lines
-//     leave L2 whole;
-//   * span i + 1 is written into the other pair of planes while slower waves still read span i: ONE barrier per span;
-//   * the next span's samples are requested by hand (global_load ... from an SGPR base, as in fir_mfma_i8.hip) and awaited
-//     with the exact count of younger stores, so staging does not wait for the previous span's stores to be acknowledged.
-//     Spans at a frame's edges (history in front, zeros behind) and the first span of a walk are staged sample by sample.
-// Measured per span of 64 periods at 147:160 (shader clocks, -DRI_TRACE build): 13.8 K for the first form.
 struct __attribute__((packed, aligned(2))) ri_g64 { scr_i16x4 v; };        // an 8-byte global store at any even byte address
 
 __device__ __forceinline__ i16x8 ri_load_nt(const short *base, int off)
@@ -371,16 +128,16 @@ __device__ __forceinline__ void ri_pin(i16x8 (&v)[RI_NG])
 
 constexpr int RI_D_THREADS = 768;           // twelve waves: 170 VGPRs a lane
 
-// EXACTS: some phase is exact (per-lane bit-field widths in the decision: four more registers)
-template <int KS, bool NEG, bool EXACTS>
-__global__ void __launch_bounds__(RI_D_THREADS)
+// EXACTS: some phase is exact (per-lane bit-field widths in the decision: four more registers); MULTI: more phase tiles than waves
+template <int KS, bool NEG, bool EXACTS, bool MULTI>
+__global__ void __launch_bounds__(KS <= 2 ? RI_D_THREADS : 512)
 k_resample_i8d(const short *__restrict__ in, short *__restrict__ out, const short *__restrict__ hist,
                const signed char *__restrict__ atab, const int *__restrict__ aoff, const int *__restrict__ bqtab,
                const double *__restrict__ g, long n_in, long n_out, long in_pitch, long out_pitch, ri_shape sh)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // planes of buffer b: low digits at 2 b plane, high digits one plane further
-    const int tid = threadIdx.x, lane = tid & 63, threads = (int)blockDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, threads = (int)blockDim.x, waves = threads >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
     const int col16 = scr_col(n), ck = scr_chunk(kq);
@@ -406,19 +163,23 @@ k_resample_i8d(const short *__restrict__ in, short *__restrict__ out, const shor
     };
     auto streams = [&](long gbase) { return aligned_in && gbase >= 0 && gbase + 8L * sh.ngroups <= n_in; };
 
-    // the wave's tile: digits, band start, start values, masks (see k_resample_i8x)
-    const int t = wave;
-    const bool has_tile = t < sh.nt;
+    // A tile's state: digits, band start, start values of the lane's four phases, and the slots that never need a second look
+    // (lane masks): the EXACT phases (a single tap 1.0, or no tap: the outputs are integers -- always "unsure", and not to be
+    // moved toward zero: bit-field width 0 in the decision) and the rows past the last phase.  MULTI = false: the wave owns tile
+    // `wave` for the whole launch and sets this up once; MULTI = true (more phase tiles than waves): tiles wave, wave + waves,
+    // ... per span, set up again for each (global loads that hit L2).
+    int t = wave, f0 = 16 * wave + 4 * kq;
+    bool tile_whole = false;                                                     // every row of the tile is a phase
     scr_i32x4 ad[KS][5];
     int a_t = 0;
-    scr_i32x4 start[3] = {};                            // scr_start of the lane's four phases
-    // slots that never need a second look (lane masks): the EXACT phases (a single tap 1.0: the outputs are integers -- always
-    // "unsure", and not to be moved toward zero: bit-field width 0 in the decision) and the rows past the last phase
+    scr_i32x4 start[3] = {};
     unsigned long long settled[4] = {0, 0, 0, 0};
     unsigned inexact[4] = {1u, 1u, 1u, 1u};
     unsigned e32v = sh.e32;                             // (in a VGPR: an instruction takes one scalar operand, and the shift is one)
-    const int f0 = 16 * t + 4 * kq;
-    if (has_tile) {
+    auto tile_setup = [&](int tile) {
+        t = tile;
+        f0 = 16 * t + 4 * kq;
+        tile_whole = 16 * t + 15 < sh.L;
         const signed char *ap = atab + ((size_t)t * KS * 5) * 1024 + lane * 16;
 #pragma unroll
         for (int s = 0; s < KS; s++)
@@ -436,22 +197,26 @@ k_resample_i8d(const short *__restrict__ in, short *__restrict__ out, const shor
             inexact[j] = (row4[3] >> 16) != 0 ? 0u : 1u;
             settled[j] = __ballot(inexact[j] == 0 || f0 + j >= sh.L);
         }
-    } else {
+    };
+    const bool has_tile = wave < sh.nt;
+    if (!MULTI) {
+        if (has_tile) {
+            tile_setup(wave);
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; s++)
+#pragma unroll
+                for (int p = 0; p < 5; p++) ad[s][p] = (scr_i32x4){0, 0, 0, 0};
+        }
+        // The tile's registers pass through one empty asm HERE: the compiler waits for their loads in front of it, once.  Left
+        // to itself it keeps them "possibly in flight" at the head of the period-tile loop and puts s_waitcnt vmcnt(0) in front
+        // of the first products of EVERY period tile -- which also waits for the previous tile's store to be acknowledged.
 #pragma unroll
         for (int s = 0; s < KS; s++)
-#pragma unroll
-            for (int p = 0; p < 5; p++) ad[s][p] = (scr_i32x4){0, 0, 0, 0};
+            asm volatile("" : "+v"(ad[s][0]), "+v"(ad[s][1]), "+v"(ad[s][2]), "+v"(ad[s][3]), "+v"(ad[s][4]) : : "memory");
+        asm volatile("" : "+v"(start[0]), "+v"(start[1]), "+v"(start[2]), "+v"(e32v) : : "memory");
+        if constexpr (EXACTS) asm volatile("" : "+v"(inexact[0]), "+v"(inexact[1]), "+v"(inexact[2]), "+v"(inexact[3]) : : "memory");
     }
-    const bool tile_whole = 16 * t + 15 < sh.L;                                  // every row of the tile is a phase
-    // The tile's registers pass through one empty asm HERE: the compiler waits for their loads in front of it, once.  Left to
-    // itself it keeps them "possibly in flight" at the head of the period-tile loop and puts s_waitcnt vmcnt(0) in front of the
-    // first products of EVERY period tile -- which also waits for the previous tile's store to be acknowledged (measured: 870
-    // clocks per period tile in the products against ~300).
-#pragma unroll
-    for (int s = 0; s < KS; s++)
-        asm volatile("" : "+v"(ad[s][0]), "+v"(ad[s][1]), "+v"(ad[s][2]), "+v"(ad[s][3]), "+v"(ad[s][4]) : : "memory");
-    asm volatile("" : "+v"(start[0]), "+v"(start[1]), "+v"(start[2]), "+v"(e32v) : : "memory");
-    if constexpr (EXACTS) asm volatile("" : "+v"(inexact[0]), "+v"(inexact[1]), "+v"(inexact[2]), "+v"(inexact[3]) : : "memory");
 
     RI_T0();
     // ---- a span's samples into the planes of buffer b ----
@@ -598,7 +363,21 @@ k_resample_i8d(const short *__restrict__ in, short *__restrict__ out, const shor
     int b = 0;
     for (long i = span0 - 1; i < span1; i++) {
         int young = 0;
-        if (i >= span0 && has_tile) young = products(i, b);
+        if (i >= span0) {
+            if (!MULTI) {
+                if (has_tile) young = products(i, b);
+            } else {
+                bool counted = true;
+                for (int tile = wave; tile < sh.nt; tile += waves) {
+                    tile_setup(tile);
+                    const int stores = products(i, b);
+                    counted = counted && stores > 0;
+                    young += stores;
+                }
+                // (fewer than the true number of younger stores only waits for more; the tile loads above are younger too)
+                young = counted ? (young < 8 ? young : 8) : 0;
+            }
+        }
         RI_MARK(6);                                     // (the rest of the products phase)
         if (i + 1 < span1) stage(i + 1, b ^ 1, v, requested, young);
         RI_MARK(0);                                     // planes written
@@ -634,65 +413,35 @@ int ri_ksteps(int L, int M, int Q)
 
 extern "C" int llzs_resample_i16x_ksteps(int L, int M, int Q) { return ri_ksteps(L, M, Q); }
 
-// geometry of the launch (without the walk length: ri_pick_walk)
-static bool ri_make_shape(int L, int M, int Q, long n_out, ri_shape *sh, int *waves, size_t *lds)
+// geometry of the launch (without the walk length: ri_pick_walk): a wave per phase tile where the tiles fit the workgroup (twelve
+// waves at up to two steps, eight above), else the tiles dealt evenly over the waves; up to 8 period tiles per span in two pairs
+// of planes of at most 64 KB together; n_in > 0: no span longer than the frame (requests without a span read the row's head)
+static bool ri_make_shape(int L, int M, int Q, long n_in, long n_out, ri_shape *sh, int *waves, size_t *lds)
 {
     sh->L = L; sh->M = M; sh->Q = Q;
     sh->nt = (L + 15) / 16;
     sh->Hp = (Q - 1 + 7) & ~7;
     const int ks = ri_ksteps(L, M, Q);
     if (ks > 4) return false;
-    // waves: the phase tiles dealt evenly over at most 8 waves (147 phases: 10 tiles -> 5 waves x 2 tiles).  The span is the
-    // largest number of period tiles (at most 4) whose samples those waves can hold in flight (RI_NG groups a thread) and
-    // whose planes and output image stay within 40 KB -- at 147:160 four tiles need 1297 groups against 1280, and a sixth wave
-    // that only stages costs a resident workgroup per CU (16 waves: 3 x 5, but 2 x 6): three tiles then.  Only a single
-    // period tile may add staging waves or take more LDS.
-    const int wmax = ks == 1 ? 16 : 8;                  // (one step: 128 VGPRs, sixteen waves fit; more steps: up to 205, eight)
+    const int wmax = ks <= 2 ? RI_D_THREADS / 64 : 8;
     const int rounds = (sh->nt + wmax - 1) / wmax;
     int w = (sh->nt + rounds - 1) / rounds;
     if (w < 2) w = 2;
-    bool ok = false;
-    const int pt_forced = llzs_tune(LLZS_TUNE_RS_I16_TILES);
-    for (int pt = (pt_forced >= 1 && pt_forced <= 4) ? pt_forced : 4; pt >= 1 && !ok; pt--) {
-        sh->pt = pt; sh->P = 16 * pt;
-        // the last period's last band ends at most M - 1 + Hp + 64 ks positions into its window; + 7 of alignment slack in front
-        const long bytes = 7 + (long)M * (sh->P - 1) + (M - 1) + sh->Hp + 64 * ks + 16;
-        sh->ngroups = (int)((bytes + 7) / 8);
-        sh->plane = (8 * sh->ngroups + 15) & ~15;
-        *lds = 2 * (size_t)sh->plane + sizeof(short) * (size_t)sh->P * L;
-        *waves = w;
-        if (pt == 1)
-            while (*waves < wmax && sh->ngroups > RI_NG * 64 * *waves) (*waves)++;
-        ok = sh->ngroups <= RI_NG * 64 * *waves && (*lds <= 40 * 1024 || (pt == 1 && *lds <= 160 * 1024));
-    }
-    if (!ok) return false;
-    const long periods = (n_out + L - 1) / L;
-    sh->periods = periods;
-    sh->spans = (periods + sh->P - 1) / sh->P;
-    sh->spans_per_wg = 1;
-    return true;
-}
-
-// geometry of the direct form (k_resample_i8d): a wave per phase tile, up to 8 period tiles per span in two pairs of planes
-static bool ri_make_shape_d(int L, int M, int Q, long n_out, ri_shape *sh, int *waves, size_t *lds)
-{
-    sh->L = L; sh->M = M; sh->Q = Q;
-    sh->nt = (L + 15) / 16;
-    sh->Hp = (Q - 1 + 7) & ~7;
-    const int ks = ri_ksteps(L, M, Q);
-    if (ks > 2 || sh->nt > RI_D_THREADS / 64) return false;
-    *waves = sh->nt < 2 ? 2 : sh->nt;
     const long periods = (n_out + L - 1) / L;
     bool ok = false;
     const int pt_forced = llzs_tune(LLZS_TUNE_RS_I16_TILES);
     for (int pt = (pt_forced >= 1 && pt_forced <= 8) ? pt_forced : 8; pt >= 1 && !ok; pt--) {
         if (pt > 1 && 16L * (pt - 1) >= periods) continue;              // (no span longer than the signal needs)
         sh->pt = pt; sh->P = 16 * pt;
+        // the last period's last band ends at most M - 1 + Hp + 64 ks positions into its window; + 7 of alignment slack in front
         const long bytes = 7 + (long)M * (sh->P - 1) + (M - 1) + sh->Hp + 64 * ks + 16;
         sh->ngroups = (int)((bytes + 7) / 8);
         sh->plane = (8 * sh->ngroups + 15) & ~15;
         *lds = 4 * (size_t)sh->plane;
-        ok = sh->ngroups <= RI_NG * 64 * *waves && *lds <= 64 * 1024;
+        *waves = w;
+        if (pt == 1)
+            while (*waves < wmax && sh->ngroups > RI_NG * 64 * *waves) (*waves)++;      // (a single tile may add staging waves)
+        ok = sh->ngroups <= RI_NG * 64 * *waves && *lds <= 64 * 1024 && (n_in <= 0 || n_in >= 8L * sh->ngroups);
     }
     if (!ok) return false;
     sh->periods = periods;
@@ -717,31 +466,22 @@ static void ri_pick_walk(ri_shape *sh, int channels, long resident)
     sh->spans_per_wg = (int)spw;
 }
 
-// direct form where it applies (at most two steps, at most twelve phase tiles, a frame at least one span's image long -- its
-// requests without a span read the row's first groups), the first form otherwise
-static bool ri_pick_form(int L, int M, int Q, long n_in, long n_out, ri_shape *sh, int *waves, size_t *lds, bool *direct)
-{
-    *direct = llzs_tune(LLZS_TUNE_RS_I16_FORM) != 1 && ri_make_shape_d(L, M, Q, n_out, sh, waves, lds) && n_in >= 8L * sh->ngroups;
-    return *direct || ri_make_shape(L, M, Q, n_out, sh, waves, lds);
-}
-
 // the kernel instance of a shape, the workgroups of it a CU holds at a time (registers, LDS and waves of THAT instance), and the
 // walk length that follows
-static int ri_plan(bool direct, bool exacts, int ks, bool neg, bool reload, int waves, size_t lds, int channels, ri_shape *sh, const void **fn,
+static int ri_plan(bool exacts, int ks, bool neg, bool multi, int waves, size_t lds, int channels, ri_shape *sh, const void **fn,
                    int *per_cu)
 {
-#define RI_FN3(K, N, R) reinterpret_cast<const void *>(k_resample_i8x<K, N, R>)
-#define RI_FN2(K, N) (reload ? RI_FN3(K, N, true) : RI_FN3(K, N, false))
-#define RI_FN(K) (neg ? RI_FN2(K, true) : RI_FN2(K, false))
-#define RI_FD2(K, N) (exacts ? reinterpret_cast<const void *>(k_resample_i8d<K, N, true>) : reinterpret_cast<const void *>(k_resample_i8d<K, N, false>))
-#define RI_FD(K) (neg ? RI_FD2(K, true) : RI_FD2(K, false))
-    if (direct) *fn = ks == 1 ? RI_FD(1) : RI_FD(2);
-    else *fn = ks == 1 ? RI_FN(1) : ks == 2 ? RI_FN(2) : ks == 3 ? RI_FN(3) : RI_FN(4);
-#undef RI_FD
-#undef RI_FD2
-#undef RI_FN
-#undef RI_FN2
-#undef RI_FN3
+#define RI_F4(K, N, E, U) reinterpret_cast<const void *>(k_resample_i8d<K, N, E, U>)
+#define RI_F3(K, N, E) (multi ? RI_F4(K, N, E, true) : RI_F4(K, N, E, false))
+#define RI_F2(K, N) (exacts ? RI_F3(K, N, true) : RI_F3(K, N, false))
+#define RI_F(K) (neg ? RI_F2(K, true) : RI_F2(K, false))
+    // (more than one step: the exact-phase registers are always there -- half the instances, and no register is short)
+    *fn = ks == 1 ? RI_F(1) : neg ? (ks == 2 ? RI_F3(2, true, true) : ks == 3 ? RI_F3(3, true, true) : RI_F3(4, true, true))
+                                  : (ks == 2 ? RI_F3(2, false, true) : ks == 3 ? RI_F3(3, false, true) : RI_F3(4, false, true));
+#undef RI_F
+#undef RI_F2
+#undef RI_F3
+#undef RI_F4
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
         cus < 1) {
@@ -755,23 +495,22 @@ static int ri_plan(bool direct, bool exacts, int ks, bool neg, bool reload, int 
 }
 
 // the launch a call would make (measurement and documentation): plan[0..6] = waves per workgroup, periods per span, spans per
-// workgroup, workgroups, workgroups resident per CU, LDS bytes per workgroup, 1 for the direct form (k_resample_i8d)
+// workgroup, workgroups, workgroups resident per CU, LDS bytes per workgroup, 1 when a wave takes several phase tiles
 extern "C" int llzs_resample_i16x_plan(int L, int M, int Q, int channels, long n_out, int shift, int *plan)
 {
     ri_shape sh;
     int waves, per_cu = 0;
     size_t lds;
     const void *fn = nullptr;
-    bool direct = false;
-    if (!plan || channels < 1 || n_out < 1 || !ri_pick_form(L, M, Q, (n_out / L) * M, n_out, &sh, &waves, &lds, &direct)) {
+    if (!plan || channels < 1 || n_out < 1 || !ri_make_shape(L, M, Q, (n_out / L) * M, n_out, &sh, &waves, &lds)) {
         llzs_set_error("resample_i16x_plan: bad arguments");
         return LLZ_ERR_ARG;
     }
-    const int rc = ri_plan(direct, false, ri_ksteps(L, M, Q), shift - 40 < 0, sh.nt > waves, waves, lds, channels, &sh, &fn, &per_cu);
+    const int rc = ri_plan(false, ri_ksteps(L, M, Q), shift - 40 < 0, sh.nt > waves, waves, lds, channels, &sh, &fn, &per_cu);
     if (rc != LLZ_OK) return rc;
     plan[0] = waves; plan[1] = sh.P; plan[2] = sh.spans_per_wg;
     plan[3] = (int)((sh.spans + sh.spans_per_wg - 1) / sh.spans_per_wg) * channels;
-    plan[4] = per_cu; plan[5] = (int)lds; plan[6] = direct ? 1 : 0;
+    plan[4] = per_cu; plan[5] = (int)lds; plan[6] = sh.nt > waves ? 1 : 0;
     return LLZ_OK;
 }
 
@@ -781,7 +520,7 @@ extern "C" int llzs_resample_i16x_fits(int L, int M, int Q)
     ri_shape sh;
     int waves;
     size_t lds;
-    return ri_make_shape(L, M, Q, L, &sh, &waves, &lds) ? 1 : 0;
+    return ri_make_shape(L, M, Q, 0, L, &sh, &waves, &lds) ? 1 : 0;
 }
 
 // atab: [ceil(L/16)][ksteps][5][64][16] tap digits in operand order; aoff: [ceil(L/16)] band starts; bqtab: [16 ceil(L/16)][4]
@@ -797,26 +536,31 @@ extern "C" int llzs_resample_i16x(const short *in, short *out, const short *hist
     ri_shape sh;
     int waves;
     size_t lds;
-    bool direct = false;
     if (!in || !out || !atab || !aoff || !bqtab || !g || channels <= 0 || channels > 65535 || n_in <= 0 || n_out <= 0 ||
         in_pitch < n_in || out_pitch < n_out || shift < 32 || shift > 46 || !(eps > 0.0) || !(eps < 0.0625) ||
-        !llzs_resample_i16x_fits(L, M, Q) || !ri_pick_form(L, M, Q, n_in, n_out, &sh, &waves, &lds, &direct)) {
+        !llzs_resample_i16x_fits(L, M, Q)) {
         llzs_set_error("resample_i16x: bad arguments (channels=%d L=%d M=%d Q=%d shift=%d eps=%g)", channels, L, M, Q, shift, eps);
         return LLZ_ERR_ARG;
+    }
+    // the kernel's sample requests are unconditional: one that has no span reads the head of the row instead, so a frame must be
+    // at least one span's image long (shorter: the caller takes the all-double kernel)
+    if (!ri_make_shape(L, M, Q, n_in, n_out, &sh, &waves, &lds)) {
+        llzs_set_error("resample_i16x: a frame of %ld samples is shorter than one span's image at %d:%d", n_in, L, M);
+        return LLZ_ERR_RANGE;
     }
     sh.rs = shift - 40;
     sh.e32 = (unsigned)ceil(ldexp(eps, 32)) + 2u;
     sh.gain = gain;
     const int ks = ri_ksteps(L, M, Q);
-    const bool neg = sh.rs < 0, reload = sh.nt > waves;
+    const bool neg = sh.rs < 0, multi = sh.nt > waves;
     int per_cu = 0;
     const void *fn = nullptr;
-    const int prc = ri_plan(direct, any_exact != 0, ks, neg, reload, waves, lds, channels, &sh, &fn, &per_cu);
+    const int prc = ri_plan(any_exact != 0, ks, neg, multi, waves, lds, channels, &sh, &fn, &per_cu);
     if (prc != LLZ_OK) return prc;
     const dim3 grid((unsigned)((sh.spans + sh.spans_per_wg - 1) / sh.spans_per_wg), (unsigned)channels), block(64 * waves);
     void *args[] = {&in, &out, &hist, &atab, &aoff, &bqtab, &g, &n_in, &n_out, &in_pitch, &out_pitch, &sh};
     LLZ_HIP_CHECK(hipLaunchKernel(fn, grid, block, args, lds, as_stream(stream)));
-    LLZ_LAUNCH_CHECK("k_resample_i8x");
+    LLZ_LAUNCH_CHECK("k_resample_i8d");
     return LLZ_OK;
 }
 

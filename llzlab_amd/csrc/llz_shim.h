@@ -53,7 +53,6 @@ enum {
     LLZS_TUNE_MDCTQ_STEPS,          /* 1: fixed-point N/4-point MDCT as three launches (step, transform, step) */
     LLZS_TUNE_RS_I16_TILES,         /* bit-exact int16 L/M resampler: period tiles per span (1..4) */
     LLZS_TUNE_RS_I16_WALK,          /* ... consecutive spans per workgroup */
-    LLZS_TUNE_RS_I16_FORM,          /* ... 1: the first form (k_resample_i8x: output image in LDS, two barriers per span) */
     LLZS_TUNE_COUNT
 };
 int llzs_tune(int id);                                   /* current override or -1 */
@@ -223,7 +222,7 @@ int llzs_resample_i16x(const short *in, short *out, const short *hist, const sig
 int llzs_resample_i16x_fits(int L, int M, int Q);
 int llzs_resample_i16x_ksteps(int L, int M, int Q);
 /* the launch a call would make (measurement / documentation): plan[0..6] = waves per workgroup, periods per span, spans per
- * workgroup, workgroups, workgroups resident per CU, LDS bytes per workgroup, 1 for the direct form */
+ * workgroup, workgroups, workgroups resident per CU, LDS bytes per workgroup, 1 when a wave takes several phase tiles */
 int llzs_resample_i16x_plan(int L, int M, int Q, int channels, long n_out, int shift, int *plan);
 int llzs_tail_i16(const short *in, const short *hist_old, short *hist_new, int channels, long n, long in_pitch,
                   int keep, void *stream);

@@ -1669,9 +1669,9 @@ def test_resample_i16_lm_screened_is_bit_exact(dev, oracle, L, M, win, gain):
     outs, outs_plain = [], []
     cut = (frames // 2) * nin1                                                  # whole reference frames: a period boundary
     outs_first = []
-    # the default (a wave per phase tile, results stored from the registers: k_resample_i8d, where it applies), the first form
-    # (k_resample_i8x: output image in LDS) and the all-double kernel
-    for tuned, dst in (({}, outs), ({"rs_i16_form": 1}, outs_first), ({"rs_i16_path": 1}, outs_plain)):
+    # the default launch (k_resample_i8d: the longest span that fits), one period tile per span with walks of three spans (many
+    # workgroup edges, every span staged both ways) and the all-double kernel
+    for tuned, dst in (({}, outs), ({"rs_i16_tiles": 1, "rs_i16_walk": 3}, outs_first), ({"rs_i16_path": 1}, outs_plain)):
         with capi.tuned(**tuned):
             r = filters.ResampleMC(ch, L, M, gain, win, filters.PCM_I16)
             for (o, e) in ((0, cut), (cut, nin)):
@@ -1691,7 +1691,7 @@ def test_resample_i16_lm_screened_is_bit_exact(dev, oracle, L, M, win, gain):
 def test_resample_i16_lm_exact_and_empty_phases(dev, L, M):
     """a caller's own polyphase matrix (llz_resample_mc_set_matrix) with a phase that is ONE tap 1.0 -- its outputs are the input
     samples themselves, integers the screen reproduces exactly and must not move toward zero -- and a phase with no tap at all
-    (every output the integer 0): the screened kernels (both forms) against the all-double kernel, which follows the
+    (every output the integer 0): the screened kernel (two launch shapes) against the all-double kernel, which follows the
     reference's loop, and the exact phase against the samples it copies"""
     ch, periods = 5, 400
     rng = np.random.default_rng(L + M)
@@ -1699,7 +1699,7 @@ def test_resample_i16_lm_exact_and_empty_phases(dev, L, M):
     x[1] = -32768
     x[2, ::2] = -1
     outs = {}
-    for name, tuned in (("direct", {}), ("first", {"rs_i16_form": 1}), ("double", {"rs_i16_path": 1})):
+    for name, tuned in (("direct", {}), ("first", {"rs_i16_tiles": 2, "rs_i16_walk": 2}), ("double", {"rs_i16_path": 1})):
         with capi.tuned(**tuned):
             r = filters.ResampleMC(ch, L, M, 1.0, po.BLACKMAN, filters.PCM_I16)
             m = r.matrix()

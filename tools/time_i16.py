@@ -51,4 +51,4 @@ if L_ > 1:
     import ctypes
     plan = (ctypes.c_int * 7)()
     if Lb.llzs_resample_i16x_plan(L_, M_, r.Q, ch, ctypes.c_long(n * L_ // M_), 38, plan) == 0:
-        print("   plan: waves/wg %d, periods/span %d, spans/wg %d, workgroups %d, resident/CU %d, LDS %d B, direct form %d" % tuple(plan))
+        print("   plan: waves/wg %d, periods/span %d, spans/wg %d, workgroups %d, resident/CU %d, LDS %d B, several tiles per wave %d" % tuple(plan))

@@ -33,7 +33,7 @@ Lb.llzs_ri_trace_read(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(count * 
 t = buf.reshape(count, 10).astype(np.float64)
 names = ("planes written", "next span requested", "barrier (first form: staging barrier)", "(event counts)", "second barrier", "output stored",
          "  per-tile constants / rest of the tile loop", "  operand reads, products", "  decisions", "  second looks, image / stores")
-print("plan: waves/wg %d, periods/span %d, spans/wg %d, workgroups %d, resident/CU %d, LDS %d B, direct form %d" % tuple(plan))
+print("plan: waves/wg %d, periods/span %d, spans/wg %d, workgroups %d, resident/CU %d, LDS %d B, several tiles per wave %d" % tuple(plan))
 spans = plan[2]
 print(f"shader-clock ticks per span, mean over {count} waves (and of wave 0 / the last wave of each workgroup)")
 for i, nm in enumerate(names):
