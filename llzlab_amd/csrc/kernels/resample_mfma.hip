@@ -174,13 +174,48 @@ struct rp_shape {
     int spans_per_wg;    // consecutive spans a workgroup walks
 };
 
+// Round 3: the structure that took the bit-exact int16 sibling (resample_i8.hip) from 0.99 to 0.57 ms, here:
+//   * a lane's four results of a period tile are four consecutive phases of one period = 16 contiguous bytes of the output row:
+//     stored straight from the accumulator (global_store_dwordx4 from an SGPR base at a 4-byte aligned address) -- no output
+//     image in LDS, no copy-out phase, no second barrier; the waves of a period fill its 4 L bytes within a span;
+//   * the input image is DOUBLE-BUFFERED: span i + 1 is written while slower waves still read span i, ONE barrier per span;
+//   * the next span is requested by hand (global_load_dword from an SGPR base) and awaited with the count of younger stores,
+//     so staging does not wait for the previous span's stores to be acknowledged; spans at a frame's edges (history in front,
+//     zeros behind) and the first span of a walk are staged sample by sample.
+__device__ __forceinline__ float rp_load_nt(const float *base, int off)
+{
+    float r;
+    asm volatile("global_load_dword %0, %1, %2 nt" : "=v"(r) : "v"(off), "s"(base) : "memory");
+    return r;
+}
+// at most n vector-memory operations (the youngest) still in flight; n = 0 .. 8
+__device__ __forceinline__ void rp_wait_vm(int n)
+{
+    switch (n) {
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+__device__ __forceinline__ void rp_pin(float (&v)[16])
+{
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
+    asm volatile("" : "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : : "memory");
+}
+
 template <int KS, bool RELOAD>
 __global__ void __launch_bounds__(1024, KS <= 16 ? 5 : 4)
 k_resample_mfma_pt_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
                        const float *__restrict__ atab /* [ntiles][KS][64] */, const int *__restrict__ c0tab /* [ntiles] */,
                        long n_in, long n_out, long in_pitch, long out_pitch, rp_shape rp)
 {
-    extern __shared__ __attribute__((aligned(16))) float xs[];
+    extern __shared__ __attribute__((aligned(16))) float xs[];      // two input images of rp.img floats
     const int tid = threadIdx.x, lane = tid & 63, waves = blockDim.x >> 6, threads = (int)blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
@@ -191,45 +226,60 @@ k_resample_mfma_pt_f32(const float *__restrict__ in, float *__restrict__ out, co
     const float *row = in + (size_t)c * in_pitch;
     const float *hrow = hist ? hist + (size_t)c * H : nullptr;
     float *obase = out + (size_t)c * out_pitch;
+    const long total_periods = (n_out + rp.L - 1) / rp.L;
+
+    // the wave's tile (RELOAD: tiles wave, wave + waves, ... per span, set up again for each)
     float av[KS];
-    if (!RELOAD && wave < rp.ntiles) {
-        const float *ap = atab + ((size_t)wave * KS) * 64 + lane;
+    int c0 = 0, f0 = 16 * wave + 4 * kq;
+    auto tile_setup = [&](int t) {
+        const float *ap = atab + ((size_t)t * KS) * 64 + lane;
 #pragma unroll
         for (int s = 0; s < KS; s++) av[s] = ap[s * 64];
-    }
-    float v[16];
-    auto request = [&](long m0s) {
-        const long first = m0s * rp.M - H;                          // input index of span element 0
-        const float *bp = row + first;                              // wave-uniform: a load is base_j + lane offset
-        if (first >= 0 && first + count <= n_in) {
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const float *bj = bp + j * threads;
-                v[j] = 0.f;
-                if (j * threads + tid < count) v[j] = __builtin_nontemporal_load(&bj[tid]);
-            }
+        c0 = c0tab[t];
+        f0 = 16 * t + 4 * kq;
+    };
+    if (!RELOAD) {
+        if (wave < rp.ntiles) {
+            tile_setup(wave);
         } else {
-            // the channel's first span (history in front) and its last (zeros behind): p in [lo, hi) is inside the frame
+#pragma unroll
+            for (int s = 0; s < KS; s++) av[s] = 0.f;
+        }
+        // (the tile's registers pass through empty asm here: the compiler waits for their loads once, in front of it, instead of
+        //  keeping them "possibly in flight" at the head of the period-tile loop -- see resample_i8.hip)
+#pragma unroll
+        for (int s = 0; s < KS; s++) asm volatile("" : "+v"(av[s]) : : "memory");
+    }
+
+    // a span streams when all 16 x threads samples of its request lie inside the frame (lanes past `count` read on in the row)
+    auto first_of = [&](long sp) { return sp * periods * rp.M - H; };
+    auto streams = [&](long first) { return first >= 0 && first + 16L * threads <= n_in; };
+
+    // ---- a span's samples into image b ----
+    auto stage = [&](long sp, int b, float (&v)[16], bool streamed, int young) {
+        float *img = xs + (size_t)b * rp.img;
+        if (streamed) {
+            rp_wait_vm(young);
+            rp_pin(v);
+        } else {
+            // a frame edge (history in front, zeros behind) or the first span of the walk: sample by sample (behind whatever
+            // request is still on its way into the same registers)
+            rp_wait_vm(0);
+            rp_pin(v);
+            const long first = first_of(sp);
             const int lo = first < 0 ? (int)-first : 0;
             const long room = n_in - first;
             const int hi = room < (long)count ? (int)(room < 0 ? 0 : room) : count;
+            const float *bp = row + first;
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const int p = j * threads + tid;
-                v[j] = 0.f;
-                if (p >= lo && p < hi) v[j] = bp[p];
-                else if (p < lo && hrow && p >= lo - H) v[j] = hrow[H - lo + p];
+                float x = 0.f;
+                if (p >= lo && p < hi) x = bp[p];
+                else if (p < lo && hrow && p >= lo - H) x = hrow[H - lo + p];
+                v[j] = x;
             }
         }
-    };
-    float *oimg = xs + rp.img;
-    const int opad = rp.ostride - rp.L;
-    const long span0 = (long)blockIdx.x * rp.spans_per_wg;
-    const long span1 = min(span0 + rp.spans_per_wg, rp.spans);
-    if (span0 < span1) request(span0 * periods);
-    for (long sp = span0; sp < span1; sp++) {
-        const long m0 = sp * periods;
-        // (the previous span's products are done: every thread passed the barrier behind them)
         // The image positions do not depend on the span; left to itself the compiler keeps all 32 of them (and their
         // conditions) live across the whole walk and spills them -- recomputed per span from a value it cannot see through.
         int tid_now = tid;
@@ -239,60 +289,80 @@ k_resample_mfma_pt_f32(const float *__restrict__ in, float *__restrict__ out, co
             const int p = j * threads + tid_now;
             const int q = (int)__umulhi((unsigned)p, rp.m_magic), r = p - q * rp.M;
             if (p < count) {
-                if (q < periods) xs[q * rp.cstride + r] = v[j];
-                if (r < 4 * KS && q > 0) xs[(q - 1) * rp.cstride + rp.M + r] = v[j];
+                if (q < periods) img[q * rp.cstride + r] = v[j];
+                if (r < 4 * KS && q > 0) img[(q - 1) * rp.cstride + rp.M + r] = v[j];
             }
         }
-        if (sp + 1 < span1) request(m0 + periods);
-        __syncthreads();
-        for (int t = wave; t < rp.ntiles; t += waves) {
-            if (RELOAD) {
-                const float *ap = atab + ((size_t)t * KS) * 64 + lane;
-#pragma unroll
-                for (int s = 0; s < KS; s++) av[s] = ap[s * 64];
-            }
-            const float *bp = xs + n * rp.cstride + c0tab[t] + kq;   // + 16 p cstride + 4 s
-            const int f0 = 16 * t + 4 * kq;                          // the lane's first phase of the tile
-            float *op = oimg + n * rp.ostride + f0;                  // D[4 kq + j][n] = output (phase f0 + j, period 16 p + n)
+    };
+
+    // ---- products and stores of one phase tile over the span in image b; returns the number of store instructions issued
+    //      (0 when it is not the same for every lane) ----
+    auto products = [&](long sp, int b) {
+        const long m0 = sp * periods;
+        const long left = total_periods - m0;                       // periods of this span that exist
+        const bool whole = f0 - 4 * kq + 15 < rp.L && left >= periods;
+        float *ospan = obase + m0 * rp.L;                            // (wave-uniform)
+        const float *bp = xs + (size_t)b * rp.img + n * rp.cstride + c0 + kq;       // + 16 p cstride + 4 s
+        unsigned o_at = 4u * (unsigned)(n * rp.L + f0);              // byte offset of the lane's 16 output bytes in the span
+        const unsigned o_step = 64u * (unsigned)rp.L;
+        const int tail = f0 + 3 < rp.L ? 4 : (f0 < rp.L ? rp.L - f0 : 0);           // values of the lane that are phases
 #pragma unroll 1
-            for (int p = 0; p < rp.pt; p++) {
-                float bv[KS];
+        for (int p = 0; p < rp.pt; p++, bp += 16 * rp.cstride, o_at += o_step) {
+            float bv[KS];
 #pragma unroll
-                for (int s = 0; s < KS; s++) bv[s] = bp[4 * s];
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < KS; s++) bv[s] = bp[4 * s];
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < KS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
-                if (f0 + 3 < rp.L) { op[0] = acc[0]; op[1] = acc[1]; op[2] = acc[2]; op[3] = acc[3]; }
-                else {
+            for (int s = 0; s < KS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc, 0, 0, 0);
+            if (whole) {
+                asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(o_at), "v"(acc), "s"(ospan) : "memory");
+            } else if (16 * p + n < left) {
+                float *op = reinterpret_cast<float *>(reinterpret_cast<char *>(ospan) + o_at);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) if (f0 + j < rp.L) op[j] = acc[j];
+                for (int j = 0; j < 4; j++)
+                    if (j < tail) op[j] = acc[j];
+            }
+        }
+        return whole ? rp.pt : 0;
+    };
+
+    // One loop, one request site.  Iteration i runs the products of span i (none in the first iteration), writes span i + 1
+    // into the other image and requests span i + 2; the barrier at its end publishes image i + 1 and retires the readers of i.
+    // A request that does not stream (or has no span) reads the row's head instead: in bounds -- the launcher requires
+    // n_in >= 16 x threads -- and never looked at.
+    const long span0 = (long)blockIdx.x * rp.spans_per_wg;
+    const long span1 = min(span0 + rp.spans_per_wg, rp.spans);
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = 0.f;
+    bool requested = false;                             // the registers hold span i + 1
+    int b = 0;
+    const int lane_off = 4 * tid;
+    for (long i = span0 - 1; i < span1; i++) {
+        int young = 0;
+        if (i >= span0) {
+            if (!RELOAD) {
+                if (wave < rp.ntiles) young = products(i, b);
+            } else {
+                bool counted = true;
+                for (int t = wave; t < rp.ntiles; t += waves) {
+                    tile_setup(t);
+                    const int stores = products(i, b);
+                    counted = counted && stores > 0;
+                    young += stores;
                 }
-                bp += 16 * rp.cstride;
-                op += 16 * rp.ostride;
+                // (fewer than the true number of younger stores only waits for more; the tile loads above are younger too)
+                young = counted ? (young < 8 ? young : 8) : 0;
             }
         }
+        if (i + 1 < span1) stage(i + 1, b ^ 1, v, requested, young);
+        const long fnext = first_of(i + 2);
+        requested = i + 2 < span1 && streams(fnext);
+        const float *src = requested ? row + fnext : row;
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = rp_load_nt(src + (size_t)j * threads, lane_off);
         __syncthreads();
-        // stream the output image out in memory order
-        float *orow = obase + m0 * rp.L;
-        const long left = n_out - m0 * rp.L;
-        const int total = (int)(left < (long)periods * rp.L ? left : (long)periods * rp.L);
-        // four outputs in flight per thread (an LDS read answered before the next is asked for costs its latency each time)
-        for (int e = tid; e < total; e += 4 * threads) {
-            float w[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int eu = e + u * threads;
-                const int r = (int)__umulhi((unsigned)eu, rp.l_magic);
-                w[u] = eu < total ? oimg[eu + opad * r] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int eu = e + u * threads;
-                if (eu < total) __builtin_nontemporal_store(w[u], &orow[eu]);
-            }
-        }
-        // (the next span's image is written by threads that have passed the barrier above: nobody reads xs any more; the
-        //  output image is next written after the next span's first barrier)
+        b ^= 1;
     }
 }
 
@@ -356,8 +426,9 @@ extern "C" int llzs_resample_mfma_f32(const float *in, float *out, const float *
     }
     const int kst = llzs_resample_mfma_f32_table_steps(L, M, Q);
     if (llzs_tune(LLZS_TUNE_RS_MFMA_FORM) != 1) {
-        // a wave per phase tile (k_resample_mfma_pt_f32): the span is as many period tiles (at most 4) as keep the input and
-        // output images of a workgroup under ~78 KB (two workgroups share a CU) and its samples within 16 per thread
+        // a wave per phase tile (k_resample_mfma_pt_f32): the span is as many period tiles (at most 4) as keep the two input
+        // images of a workgroup within 128 KB and its samples within 16 per thread; the frame must be at least one request long
+        // (requests without a span read the row's head): shorter frames take the period-tile form below
         rp_shape rp;
         rp.L = L; rp.M = M; rp.Q = Q;
         rp.ntiles = (L + 15) / 16;
@@ -366,15 +437,16 @@ extern "C" int llzs_resample_mfma_f32(const float *in, float *out, const float *
         rp.cstride += ((2 - rp.cstride) % 32 + 32) % 32;
         const int waves_min = rp.ntiles < 4 ? 4 : (rp.ntiles > 16 ? 16 : rp.ntiles);
         int waves = waves_min, pt = 4;
+        if (const int forced = llzs_tune(LLZS_TUNE_RS_TILES); forced >= 1 && forced <= 4) pt = forced;
         size_t lds = 0;
         bool ok = false;
         for (; pt >= 1; pt--) {
             rp.img = 16 * pt * rp.cstride;
-            lds = ((size_t)rp.img + (size_t)16 * pt * rp.ostride) * sizeof(float);
+            lds = 2 * (size_t)rp.img * sizeof(float);
             const long count = (long)16 * pt * M + 4 * kst;
             waves = waves_min;
             while (waves < 16 && count > 16L * 64 * waves) waves++;
-            ok = lds <= 78 * 1024 && count <= 16L * 64 * waves;
+            ok = lds <= 128 * 1024 && count <= 16L * 64 * waves && n_in >= 16L * 64 * waves;
             if (ok) break;
         }
         if (ok) {
@@ -383,14 +455,15 @@ extern "C" int llzs_resample_mfma_f32(const float *in, float *out, const float *
             rp.l_magic = (unsigned)((0x100000000ull + (unsigned)L - 1) / (unsigned)L);
             const long periods = (n_out + L - 1) / L;
             rp.spans = (periods + 16 * pt - 1) / (16 * pt);
-            // consecutive spans per workgroup: the walk length that minimises rounds x (length + 1) over the 512 resident
-            // workgroups (two per CU) -- a walk's first span waits for memory with nothing to do, and a last round that is
-            // half empty costs as much as a full one (147:160, 256 channels: 14 spans per walk made 6.5 rounds)
+            // consecutive spans per workgroup: the walk length that minimises rounds x (length + 1) over the resident
+            // workgroups -- a walk's first span waits for memory with nothing to do, and a last round that is half empty costs
+            // as much as a full one
+            const long resident = lds > 78 * 1024 ? 256 : 512;
             long spw = rp.spans < 4 ? rp.spans : 4;
             double best = 1e300;
             for (long c = spw; c <= rp.spans; c++) {
                 const long wgs = ((rp.spans + c - 1) / c) * (long)channels;
-                const double cost = (double)((wgs + 511) / 512) * (double)(c + 1);
+                const double cost = (double)((wgs + resident - 1) / resident) * (double)(c + 1);
                 if (cost < best * 0.999) { best = cost; spw = c; }
             }
             rp.spans_per_wg = (int)spw;
