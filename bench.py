@@ -378,12 +378,15 @@ def main():
                           ("resample_1to3_i16_fast_8192ch_sharded", "k_fir_mfma_i16#0"), ("iir8_1024ch_sharded", "k_iir_cascade_wave_pk32#0"),
                           ("iir8_r099_1024ch_sharded", "k_iir_cascade_wave_pf64w#0"), ("resample_147to160_f32_256ch", "k_resample_mfma_pt_f32#0"),
                           ("resample_160to147_f32_256ch", "k_resample_mfma_pt_f32#1"), ("resample_147to160_i16_256ch", "k_resample_i8d#0"),
-                          ("resample_160to147_i16_256ch", "k_resample_i8d#1")):
+                          ("resample_160to147_i16_256ch", "k_resample_i8d#1"), ("mdct_fixed_fwd_2048x65536", "k_mdct4_q15#0"),
+                          ("mdct_fixed_inv_2048x65536", "k_mdct4_q15#1"), ("mdct_frames_analysis_256x1024ch", "k_mdct_reg_f32#0"),
+                          ("mdct_frames_synthesis_256x1024ch", "k_mdct_reg_f32#1")):
             rec = recs.get(kern)
             if rec and key in also and "error" not in also[key]:
                 files = {"k_iir": ["iir.hip"], "k_fir_mfma_bf16x3": ["fir_mfma.hip"], "k_fir_mfma_i16": ["fir_mfma.hip"],
                          "k_fir_mfma_i8x": ["fir_mfma_i8.hip", "screen_i8.hpp"], "k_resample_mfma": ["resample_mfma.hip"],
-                         "k_resample_i8d": ["resample_i8.hip", "screen_i8.hpp"]}
+                         "k_resample_i8d": ["resample_i8.hip", "screen_i8.hpp"], "k_mdct4_q15": ["mdct_q15.hip", "fft_core.hpp"],
+                         "k_mdct_reg_f32": ["fft.hip", "fft_core.hpp"]}
                 src = next(v for p_, v in files.items() if kern.startswith(p_))
                 import hashlib
                 h = hashlib.sha256()
@@ -523,7 +526,8 @@ def i16_parity(orc, fresh_handle, xi, yi, L_, M_, n_out_check, gain=1.0, win=1):
 
 
 EXTRA_KEYS = ["fir63_64ch_time_domain", "fir63_64ch_overlap_save", "resample_147to160_f32_256ch", "resample_160to147_f32_256ch",
-              "resample_147to160_i16_256ch", "resample_160to147_i16_256ch"]
+              "resample_147to160_i16_256ch", "resample_160to147_i16_256ch", "mdct_fixed_fwd_2048x65536", "mdct_fixed_inv_2048x65536",
+              "mdct_frames_analysis_256x1024ch", "mdct_frames_synthesis_256x1024ch"]
 
 
 def extra_paths(ctx):
@@ -574,6 +578,31 @@ def extra_paths(ctx):
         out[f"resample_{L_}to{M_}_i16_256ch"] = (ms, lambda ms, ch=ch, n=n, bpi=2 + 2 * L_ / M_, par=par, make=make:
                                                   make(ms, ch, n, bpi, {"parity": par}))
         del xi, yi
+    # the fixed-point MDCT in batch (int32, Q15 tables, bit-exact: one launch per direction) and the windowed
+    # 50 %-overlap MDCT frames (float32; the synthesis writes every sample once)
+    n, count = 2048, 1 << 16
+    xq = torch.randint(-(1 << 20), 1 << 20, (count, n), dtype=torch.int32, device=dev)
+    Xq = torch.empty(count, n // 2, dtype=torch.int32, device=dev)
+    mq = filters.MdctFixed(2, n)
+    mq.set_stream(stream)
+    for name, fn in (("mdct_fixed_fwd_2048x65536", lambda: mq.forward_batch(xq, Xq)),
+                     ("mdct_fixed_inv_2048x65536", lambda: mq.inverse_batch(Xq, xq))):
+        ms = time_local(fn, 10)
+        out[name] = (ms, lambda ms, b=6 * n * count: {"GBs": b / ms / 1e6, "hbm_frac": b / ms / 1e6 / HBM_PEAK_GBS, "ms": ms,
+                                                        "bytes_per_sample": 6})
+    mq.close()
+    del xq, Xq
+    F, ch, frames = 256, 1024, 1024
+    xf = torch.rand(ch, frames * F, dtype=torch.float32, device=dev) * 2 - 1
+    Xf = torch.empty(ch, frames, F, dtype=torch.float32, device=dev)
+    mf = filters.MdctFramesMC(ch, F, 0, stream=stream)
+    for name, fn in (("mdct_frames_analysis_256x1024ch", lambda: mf.analysis(xf, Xf)),
+                     ("mdct_frames_synthesis_256x1024ch", lambda: mf.synthesis(Xf, xf))):
+        ms = time_local(fn, 10)
+        out[name] = (ms, lambda ms, b=8 * F * ch * frames: {"GBs": b / ms / 1e6, "hbm_frac": b / ms / 1e6 / HBM_PEAK_GBS, "ms": ms,
+                                                             "bytes_per_sample": 8})
+    mf.close()
+    del xf, Xf
     return out
 
 
