@@ -375,7 +375,7 @@ def main():
         except Exception:
             recs = {}
         for key, kern in (("resample_1to3_f32_8192ch_sharded", "k_fir_mfma_bf16x3#0"), ("resample_1to3_i16_exact_8192ch_sharded", "k_fir_mfma_i8x#0"),
-                          ("resample_1to3_i16_fast_8192ch_sharded", "k_fir_mfma_i16#0"), ("iir8_1024ch_sharded", "k_iir_cascade_wave_pk32#0"),
+                          ("resample_1to3_i16_fast_8192ch_sharded", "k_fir_mfma_i8x#0"), ("iir8_1024ch_sharded", "k_iir_cascade_wave_pk32#0"),
                           ("iir8_r099_1024ch_sharded", "k_iir_cascade_wave_pf64w#0"), ("resample_147to160_f32_256ch", "k_resample_mfma_pt_f32#0"),
                           ("resample_160to147_f32_256ch", "k_resample_mfma_pt_f32#1"), ("resample_147to160_i16_256ch", "k_resample_i8d#0"),
                           ("resample_160to147_i16_256ch", "k_resample_i8d#1"), ("mdct_fixed_fwd_2048x65536", "k_mdct4_q15#0"),

@@ -274,6 +274,7 @@ typedef struct {
     /* F32, L >= 5: the banded tap matrix in matrix-core operand order (resample_mfma.hip) */
     float *d_band;
     int *d_band_c0;
+    double *d_gd;                       /* LLZ_PCM_I16_FAST on the screened kernel: the double taps of its second looks */
     void *d_hist[2];            /* [channels][Q-1] samples of the handle's format, ping-pong */
     int cur;
     long long in_count, out_count;   /* samples consumed / produced per channel so far */
@@ -289,7 +290,7 @@ static void rsm_destroy(rsm_t *r)
     if (!r) return;
     tapmat_free(&r->taps);
     llzs_free(r->d_mat); llzs_free(r->d_phase); llzs_free(r->d_digits); llzs_free(r->d_scr_atab); llzs_free(r->d_scr_aoff);
-    llzs_free(r->d_scr_bq); llzs_free(r->d_band); llzs_free(r->d_band_c0); llzs_free(r->d_hist[0]); llzs_free(r->d_hist[1]);
+    llzs_free(r->d_scr_bq); llzs_free(r->d_band); llzs_free(r->d_band_c0); llzs_free(r->d_gd); llzs_free(r->d_hist[0]); llzs_free(r->d_hist[1]);
     llz_stage_release(&r->st_in); llz_stage_release(&r->st_out);
     r->tag = 0;
     free(r);
@@ -490,6 +491,14 @@ static int rsm_upload_matrix(rsm_t *r)
     if (!m32) return LLZ_ERR_NOMEM;
     for (size_t i = 0; i < count; i++) m32[i] = (float)r->taps.mat[i];
     int rc = llzs_h2d_table(r->d_mat, m32, sizeof(float) * count);
+    /* LLZ_PCM_I16_FAST promises the reference's result within 1 LSB.  The bit-exact screened kernel is the faster of the two since
+     * round 3 (BASELINE config 5: 23 ms against 31 ms for the float32-sum kernel): a FAST handle takes it whenever the screen
+     * accepts the taps, and keeps the float32-sum kernel for the rest (gains above ~64, frames shorter than a tile). */
+    r->use_screen = 0;
+    if (rc == LLZ_OK && r->fmt == LLZ_PCM_I16_FAST && r->L == 1 && llzs_tune(LLZS_TUNE_RS_I16_PATH) != 1) {
+        if (!r->d_gd) r->d_gd = (double *)llzs_malloc(sizeof(double) * count);
+        r->use_screen = r->d_gd && llzs_h2d_table(r->d_gd, r->taps.mat, sizeof(double) * count) == LLZ_OK && rsm_build_screen(r);
+    }
     if (rc == LLZ_OK && r->fmt == LLZ_PCM_F32 && llzs_resample_mfma_f32_fits(r->L, r->M, r->Q) &&
         llzs_tune(LLZS_TUNE_RS_GENERIC) < 1) {
         /* phase tile t = phases 16t .. 16t+15; its band starts at input offset c0 - (Q-1), c0 = floor(16 t M / L), and is
@@ -686,7 +695,12 @@ static long rsm_process(rsm_t *r, unsigned long handle, const void *in, long n_i
     }
     const void *hist = r->Q > 1 ? r->d_hist[r->cur] : NULL;
     if (rc == LLZ_OK) {
-        if (r->fmt == LLZ_PCM_I16_FAST)
+        if (r->fmt == LLZ_PCM_I16_FAST && r->use_screen &&
+            (rc = llzs_fir_mfma_i16x((const short *)d_in, (short *)d_out, (const short *)hist, r->d_digits, r->d_gd, r->channels,
+                                     n_in, n_out, n_in, n_out, r->Q, r->M, r->screen_shift, r->screen_bias, r->gain,
+                                     r->screen_eps, r->stream)) != LLZ_ERR_RANGE)
+            ;                                   /* (the exact result is within the format's 1 LSB) */
+        else if (r->fmt == LLZ_PCM_I16_FAST)
             rc = llzs_fir_mfma_i16((const short *)d_in, (short *)d_out, (const short *)hist, (const float *)r->d_mat,
                                    r->channels, n_in, n_out, n_in, n_out, r->Q, r->M, (float)r->gain, r->stream);
         else if (r->fmt == LLZ_PCM_I16 && r->use_screen &&

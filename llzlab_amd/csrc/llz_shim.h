@@ -34,7 +34,7 @@ enum {
     LLZS_TUNE_RS_GENERIC,           /* 1: general L/M resampler without the register-window kernel; 2: first LDS kernel */
     LLZS_TUNE_RS_TILES,             /* tiles per workgroup of the general L/M resampler */
     LLZS_TUNE_RS_DEC_VALU,          /* 1: L = 1 float32 decimator on the vector pipe (LDS polyphase kernel) */
-    LLZS_TUNE_RS_I16_PATH,          /* 1: int16 resampler always on the all-double kernel (no screened fast pass) */
+    LLZS_TUNE_RS_I16_PATH,          /* 1: no screened pass: LLZ_PCM_I16 on the all-double kernel, LLZ_PCM_I16_FAST on the float32-sum one */
     LLZS_TUNE_MFMA_NACC,            /* accumulator tiles per wave of the matrix-core FIR (1 / 2) */
     LLZS_TUNE_MFMA_WG_PER_CU,
     LLZS_TUNE_FFT_GENERIC,          /* 1: staged LDS passes instead of the register transforms */
