@@ -102,7 +102,9 @@ elif what == "traffic_set":
     yi = torch.empty(ch, n // 3, dtype=torch.int16, device=dev)
     filters.synth_i16(xi, 1)
     for fmt in (filters.PCM_I16, filters.PCM_I16_FAST):
-        r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, fmt)
+        # (a FAST handle would take the screened kernel too: its own float32-sum kernel is what is recorded here)
+        with capi.tuned(rs_i16_path=1 if fmt == filters.PCM_I16_FAST else -1):
+            r = filters.ResampleMC(ch, 1, 3, 1.0, filters.BLACKMAN, fmt)
         go(lambda: r.process(xi, yi))
         r.close()
     del xi, yi
