@@ -101,6 +101,70 @@ k_autocorr_mc_f32(const float *__restrict__ x, float *__restrict__ r, int frames
     }
 }
 
+// Direct autocorrelation for SHORT lag ranges (p <= 8 NL <= 32: the LPC orders) without LDS: lane l keeps x[8 l .. 8 l + 7] of a
+// chunk in registers and gets the samples it slides over from lanes l + 1 .. l + NL through the wave shuffle, so a chunk is
+// 8 (64 - NL) samples (the last NL lanes only look ahead: their own products are formed by the next chunk, where they are the
+// first lanes); the next chunk's samples are requested before the current one is worked on.  One 16-byte-pair load and
+// 8 (p + 1) FMAs per lane and chunk; the per-lane partial sums are reduced across the wave once per frame.  (The LDS form
+// above -- staging, two waits and the window reads per 512 samples, nothing in flight meanwhile -- measured 0.93 ms for 2^18
+// frames of 1024 at p = 16; this one is bound by the reduction and the FMAs.)
+typedef float ac_f32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) ac_x4 { ac_f32x4 v; };     // a 16-byte load at any 4-byte address
+
+template <int NL>
+__global__ void __launch_bounds__(64 * AC_WAVES)
+k_autocorr_reg_f32(const float *__restrict__ x, float *__restrict__ r, int frames, int n, int p)
+{
+    constexpr int NLAG = 8 * NL + 1, STEP = 8 * (64 - NL);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long waves_total = (long)gridDim.x * AC_WAVES;
+    const bool active = lane < 64 - NL;
+    for (long f = (long)blockIdx.x * AC_WAVES + wave; f < frames; f += waves_total) {
+        const float *row = x + (size_t)f * n;
+        auto fetch = [&](int c0, float (&v)[8]) {
+            const int i0 = c0 + 8 * lane;
+            if (i0 + 8 <= n) {
+                const ac_f32x4 a = reinterpret_cast<const ac_x4 *>(row + i0)->v, b = reinterpret_cast<const ac_x4 *>(row + i0 + 4)->v;
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+                v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = i0 + j < n ? row[i0 + j] : 0.f;   // zeros behind the frame: those products vanish
+            }
+        };
+        float acc[NLAG];
+#pragma unroll
+        for (int k = 0; k < NLAG; k++) acc[k] = 0.f;
+        float cur[8], nxt[8];
+        fetch(0, cur);
+        for (int c0 = 0; c0 < n; c0 += STEP) {
+            if (c0 + STEP < n) fetch(c0 + STEP, nxt);
+            // s = the lane's own samples followed by those of lanes l + 1 .. l + NL
+            float s[8 * (NL + 1)];
+#pragma unroll
+            for (int j = 0; j < 8; j++) s[j] = cur[j];
+#pragma unroll
+            for (int h = 1; h <= NL; h++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) s[8 * h + j] = __shfl_down(s[8 * (h - 1) + j], 1, 64);
+            float xa[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) xa[j] = active ? cur[j] : 0.f;
+#pragma unroll
+            for (int k = 0; k < NLAG; k++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[k] = __builtin_fmaf(xa[j], s[j + k], acc[k]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) cur[j] = nxt[j];
+        }
+#pragma unroll
+        for (int k = 0; k < NLAG; k++) {
+            const float v = wave_sum(acc[k]);
+            if (lane == 0 && k <= p) r[(size_t)f * (p + 1) + k] = v;
+        }
+    }
+}
+
 // zero-padded real frame -> interleaved complex of length F
 __global__ void __launch_bounds__(256)
 k_acf_pack(const float *__restrict__ x, float2 *__restrict__ z, int n, int F, long total)
@@ -154,6 +218,19 @@ extern "C" int llzs_autocorr_mc_f32(const float *x, float *r, int frames, int n,
     }
     long blocks = ((long)frames + AC_WAVES - 1) / AC_WAVES;
     if (blocks > 256L * 4) blocks = 256L * 4;                       // persistent: frames dealt round robin to the waves
+    if (p <= 32 && llzs_tune(LLZS_TUNE_ACF_LDS) < 1) {              // short lag ranges: the register form
+        const int nl = p <= 8 ? 1 : (p + 7) / 8;
+#define LLZ_AC_REG(NLV)                                                                                            \
+    hipLaunchKernelGGL(k_autocorr_reg_f32<NLV>, dim3((unsigned)blocks), dim3(64 * AC_WAVES), 0, as_stream(stream), x, r, \
+                       frames, n, p)
+        if (nl == 1) LLZ_AC_REG(1);
+        else if (nl == 2) LLZ_AC_REG(2);
+        else if (nl == 3) LLZ_AC_REG(3);
+        else LLZ_AC_REG(4);
+#undef LLZ_AC_REG
+        LLZ_LAUNCH_CHECK("k_autocorr_reg_f32");
+        return LLZ_OK;
+    }
     // lags are done 64 per launch (8 groups of 8 accumulators per lane); p > 63 re-reads the frames per block of lags
 #define LLZ_AC_LAUNCH(NG, LAG0)                                                                                   \
     hipLaunchKernelGGL(k_autocorr_mc_f32<NG>, dim3((unsigned)blocks), dim3(64 * AC_WAVES), 0, as_stream(stream), x, r, \

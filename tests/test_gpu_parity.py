@@ -712,15 +712,25 @@ def test_correlation_reference_symbols_exact(dev):
         capi.check_handle(capi.lib().llz_autocorr_fast_init(4096), "too long")
 
 
-@pytest.mark.parametrize("frames,n,p", [(7, 300, 16), (3, 1024, 32), (5, 20000, 40), (2, 64, 63), (130, 512, 255)])
+@pytest.mark.parametrize("frames,n,p", [(7, 300, 16), (3, 1024, 32), (5, 20000, 40), (2, 64, 63), (130, 512, 255),
+                                        # the register form for short lag ranges (k_autocorr_reg_f32<1..4>): every neighbour count,
+                                        # lengths that are no multiple of 8, shorter than a chunk, exactly one chunk, p = 0
+                                        (9, 1021, 0), (300, 1000, 7), (33, 496, 8), (5, 497, 9), (1000, 480, 16), (4, 3001, 17),
+                                        (6, 61, 24), (40, 2048, 25), (3, 10, 9), (2, 4096, 32)])
 def test_autocorr_mc_direct_vs_oracle(dev, oracle, frames, n, p):
     x = oracle.synth_f32(frames, n, seed=n + p)
-    ref = np.stack([oracle.autocorr(row.astype(np.float64), p) for row in x])
+    ref = np.stack([oracle.autocorr(row.astype(np.float64), p) for row in x[:64]])
     xd = torch.from_numpy(x).to(dev)
     rd = torch.empty(frames, p + 1, dtype=torch.float32, device=dev)
     filters.autocorr_mc(xd, rd, p)
     got = rd.cpu().numpy().astype(np.float64)
-    assert np.max(np.abs(got - ref)) <= 1e-5 * ref[:, 0].max()         # relative to the zero-lag energy
+    assert np.max(np.abs(got[:64] - ref)) <= 1e-5 * ref[:, 0].max()    # relative to the zero-lag energy
+    if p <= 32:
+        # the LDS-window kernel (every p) must agree with the register form on every frame
+        with capi.tuned(acf_lds=1):
+            r1 = torch.empty_like(rd)
+            filters.autocorr_mc(xd, r1, p)
+        assert np.max(np.abs(r1.cpu().numpy().astype(np.float64) - got)) <= 2e-6 * max(1.0, np.abs(got).max())
     r2 = np.zeros((frames, p + 1), dtype=np.float32)
     filters.autocorr_mc(x, r2, p)                                       # host buffers
     assert np.array_equal(r2, rd.cpu().numpy())
