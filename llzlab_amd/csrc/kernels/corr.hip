@@ -45,6 +45,32 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// All K per-lane partial sums of a wave at once by recursive halving: in the step with distance d a lane keeps one accumulator of a
+// pair and hands the other to lane ^ d, which keeps that one -- the number of live sums halves with every step (17 -> 9 -> 5 -> 3
+// -> 2 -> 1 -> 1: 21 exchanges instead of 17 x 6).  Returns the total of sum number (six bits of the lane, reversed) -- for
+// K <= 64 every sum ends in exactly one lane; *which says which.
+template <int K>
+__device__ __forceinline__ float wave_sums(float (&acc)[K], int lane, int *which)
+{
+    static_assert(K <= 64, "one sum per lane at most");
+    int cnt = K;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const bool upper = (lane & d) != 0;
+        const int half = (cnt + 1) / 2;
+#pragma unroll
+        for (int i = 0; i < (K + 1) / 2; i++) {
+            if (i < half) {
+                const float a = acc[2 * i], b = 2 * i + 1 < cnt ? acc[2 * i + 1] : 0.f;
+                acc[i] = (upper ? b : a) + __shfl_xor(upper ? a : b, d, 64);
+            }
+        }
+        cnt = half;
+    }
+    *which = (int)(__brev((unsigned)lane) >> 26);
+    return acc[0];
+}
+
 template <int NG>                               // lag groups of 8 kept in registers: lags 0 .. 8*NG-1
 __global__ void __launch_bounds__(64 * AC_WAVES)
 k_autocorr_mc_f32(const float *__restrict__ x, float *__restrict__ r, int frames, int n, int p, int lag0)
@@ -93,11 +119,9 @@ k_autocorr_mc_f32(const float *__restrict__ x, float *__restrict__ r, int frames
                 for (int j = 0; j < 8; j++) wa[j] = wb[j];
             }
         }
-#pragma unroll
-        for (int k = 0; k < 8 * NG; k++) {
-            const float v = wave_sum(acc[k]);
-            if (lane == 0 && lag0 + k <= p) r[(size_t)f * (p + 1) + lag0 + k] = v;
-        }
+        int k;
+        const float v = wave_sums(acc, lane, &k);
+        if (k < 8 * NG && lag0 + k <= p) r[(size_t)f * (p + 1) + lag0 + k] = v;
     }
 }
 
@@ -157,11 +181,9 @@ k_autocorr_reg_f32(const float *__restrict__ x, float *__restrict__ r, int frame
 #pragma unroll
             for (int j = 0; j < 8; j++) cur[j] = nxt[j];
         }
-#pragma unroll
-        for (int k = 0; k < NLAG; k++) {
-            const float v = wave_sum(acc[k]);
-            if (lane == 0 && k <= p) r[(size_t)f * (p + 1) + k] = v;
-        }
+        int k;
+        const float v = wave_sums(acc, lane, &k);
+        if (k <= p) r[(size_t)f * (p + 1) + k] = v;
     }
 }
 
