@@ -38,13 +38,6 @@ constexpr int AC_LDS = (AC_CHUNK + AC_MAXLAG + 16) + ((AC_CHUNK + AC_MAXLAG + 16
 
 __device__ __forceinline__ int ac_phys(int p) { return p + ((p >> 3) << 2); }
 
-__device__ __forceinline__ float wave_sum(float v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-
 // All K per-lane partial sums of a wave at once by recursive halving: in the step with distance d a lane keeps one accumulator of a
 // pair and hands the other to lane ^ d, which keeps that one -- the number of live sums halves with every step (17 -> 9 -> 5 -> 3
 // -> 2 -> 1 -> 1: 21 exchanges instead of 17 x 6).  Returns the total of sum number (six bits of the lane, reversed) -- for
