@@ -32,7 +32,7 @@ k_iir_df1_mc(const float *__restrict__ in, float *__restrict__ out, const double
 #pragma unroll
     for (int k = 0; k <= ORD; k++) {
         a[k] = k <= M ? ab[k] : 0.0;
-        b[k] = k <= N ? ab[ORD + 1 + k] : 0.0;
+        b[k] = k <= N ? ab[DF1_MAX + 1 + k] : 0.0;
         xd[k] = yd[k] = 0.0;
     }
     const long start = seg * seg_len;
@@ -40,7 +40,7 @@ k_iir_df1_mc(const float *__restrict__ in, float *__restrict__ out, const double
     long t = start;
     if (seg == 0) {
         // the reference keeps x[N] newest .. x[0] oldest (llz_iir.c:117-122): xs[N-k] = x(-1-k), ys[M-k] = y(-1-k)
-        const double *xs = state_in + (size_t)c * 2 * (ORD + 1), *ys = xs + (ORD + 1);
+        const double *xs = state_in + (size_t)c * 2 * (DF1_MAX + 1), *ys = xs + (DF1_MAX + 1);
 #pragma unroll
         for (int k = 0; k <= ORD; k++) {
             if (k <= N) xd[k] = xs[N - k];
@@ -49,8 +49,9 @@ k_iir_df1_mc(const float *__restrict__ in, float *__restrict__ out, const double
     } else {
         t = start - warm;                                          // (the host guarantees warm <= seg_len)
     }
-    for (; t < stop; t++) {
-        const double xt = (double)x[t];
+    // one sample of the reference's loop (llz_iir.c:103-132)
+    auto step = [&](float xf) {
+        const double xt = (double)xf;
         double acc = 0.0;
         {
             const double prod = b[0] * xt;                         // y = sum_k b[k] x(t-k), ascending k
@@ -74,10 +75,46 @@ k_iir_df1_mc(const float *__restrict__ in, float *__restrict__ out, const double
         for (int k = ORD; k >= 1; k--) { xd[k] = xd[k - 1]; yd[k] = yd[k - 1]; }
         xd[0] = xt;
         yd[0] = acc;
-        if (t >= start) y[t] = (float)acc;
+        return (float)acc;
+    };
+    // A lane's row is its own: adjacent lanes are a whole segment apart, so a 4-byte access per lane and sample touches 64 cache
+    // lines per wave instruction and every line 32 times (measured 8 % of the HBM roofline whatever the order).  The row is
+    // walked in blocks of 16 samples instead -- four 16-byte loads, the next block's issued before this block's 16 steps, four
+    // 16-byte stores -- with single samples in front (warm-up outputs are dropped one by one, and up to the first 4-sample
+    // boundary of the row) and behind.
+    for (; t < stop && (t < start || ((t & 3) != 0)); t++) {
+        const float yv = step(x[t]);
+        if (t >= start) y[t] = yv;
     }
+    constexpr int BLK = 16;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    struct __attribute__((packed, aligned(4))) u4 { f32x4 v; };
+    if (t + BLK <= stop) {
+        f32x4 cur[BLK / 4], nxt[BLK / 4];
+#pragma unroll
+        for (int q = 0; q < BLK / 4; q++) cur[q] = reinterpret_cast<const u4 *>(x + t + 4 * q)->v;
+        for (; t + BLK <= stop; t += BLK) {
+            const bool more = t + 2 * BLK <= stop;
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < BLK / 4; q++) nxt[q] = reinterpret_cast<const u4 *>(x + t + BLK + 4 * q)->v;
+            }
+#pragma unroll
+            for (int q = 0; q < BLK / 4; q++) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = step(cur[q][e]);
+                reinterpret_cast<u4 *>(y + t + 4 * q)->v = o;
+            }
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < BLK / 4; q++) cur[q] = nxt[q];
+            }
+        }
+    }
+    for (; t < stop; t++) y[t] = step(x[t]);
     if (seg == segs - 1) {
-        double *xs = state_out + (size_t)c * 2 * (ORD + 1), *ys = xs + (ORD + 1);
+        double *xs = state_out + (size_t)c * 2 * (DF1_MAX + 1), *ys = xs + (DF1_MAX + 1);
 #pragma unroll
         for (int k = 0; k <= ORD; k++) {
             if (k <= N) xs[N - k] = xd[k];
@@ -108,8 +145,13 @@ extern "C" int llzs_iir_df1_mc_f32(const float *in, float *out, const double *ab
         seg_len = (n + segs - 1) / segs;
     }
     const long items = (long)channels * segs;
-    hipLaunchKernelGGL(k_iir_df1_mc<DF1_MAX>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, as_stream(stream), in, out, ab,
-                       state_in, state_out, channels, n, in_pitch, out_pitch, M, N, segs, seg_len, warm);
+    // (ORD: the orders the unrolled loops run to; the tables keep the stride of DF1_MAX)
+    if (M <= 4 && N <= 4)
+        hipLaunchKernelGGL(k_iir_df1_mc<4>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, as_stream(stream), in, out, ab,
+                           state_in, state_out, channels, n, in_pitch, out_pitch, M, N, segs, seg_len, warm);
+    else
+        hipLaunchKernelGGL(k_iir_df1_mc<DF1_MAX>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, as_stream(stream), in, out,
+                           ab, state_in, state_out, channels, n, in_pitch, out_pitch, M, N, segs, seg_len, warm);
     LLZ_LAUNCH_CHECK("k_iir_df1_mc");
     return LLZ_OK;
 }
