@@ -527,7 +527,8 @@ def i16_parity(orc, fresh_handle, xi, yi, L_, M_, n_out_check, gain=1.0, win=1):
 
 EXTRA_KEYS = ["fir63_64ch_time_domain", "fir63_64ch_overlap_save", "resample_147to160_f32_256ch", "resample_160to147_f32_256ch",
               "resample_147to160_i16_256ch", "resample_160to147_i16_256ch", "mdct_fixed_fwd_2048x65536", "mdct_fixed_inv_2048x65536",
-              "mdct_frames_analysis_256x1024ch", "mdct_frames_synthesis_256x1024ch"]
+              "mdct_frames_analysis_256x1024ch", "mdct_frames_synthesis_256x1024ch", "autocorr_direct_p16_262144x1024",
+              "iir_order3_df1_1024ch"]
 
 
 def extra_paths(ctx):
@@ -603,6 +604,25 @@ def extra_paths(ctx):
                                                              "bytes_per_sample": 8})
     mf.close()
     del xf, Xf
+    # direct autocorrelation at an LPC order (float32 batch form of llz_autocorr), and the reference's own
+    # order-3 direct-form-I filter (libllzaudio/llz_musicpitch.c:1277-1285) on 1024 channels (llz_iir_mc: exact-order double per lane)
+    frames_ac, n_ac, p_ac = 1 << 18, 1024, 16
+    xa = torch.rand(frames_ac, n_ac, dtype=torch.float32, device=dev) * 2 - 1
+    ra = torch.empty(frames_ac, p_ac + 1, dtype=torch.float32, device=dev)
+    ms = time_local(lambda: filters.autocorr_mc(xa, ra, p_ac, stream=stream), 10)
+    out["autocorr_direct_p16_262144x1024"] = (ms, lambda ms, b=4 * frames_ac * n_ac: {"GBs": b / ms / 1e6, "hbm_frac": b / ms / 1e6 / HBM_PEAK_GBS,
+                                                                                      "ms": ms, "bytes_per_sample": 4})
+    del xa, ra
+    ch, n = 1024, 1 << 20
+    xi3 = torch.empty(ch, n, dtype=torch.float32, device=dev)
+    yi3 = torch.empty_like(xi3)
+    filters.synth_f32(xi3, SEED, stream=stream)
+    q3 = filters.IirMC(ch, [1.0, -0.3695, 0.1958, 0.0], [1.0, 0.2066, 0.4131, 0.2066], stream=stream)
+    ms = time_local(lambda: q3.filter(xi3, yi3), 5)
+    out["iir_order3_df1_1024ch"] = (ms, lambda ms, b=8 * ch * n: {"Msamples_s": ch * n / ms / 1e3, "GBs": b / ms / 1e6,
+                                                                    "hbm_frac": b / ms / 1e6 / HBM_PEAK_GBS, "ms": ms})
+    q3.close()
+    del xi3, yi3
     return out
 
 
