@@ -198,6 +198,9 @@ static int mdcx_on_device(mdcx_t *f, const int *d_src, int *d_dst, int count, in
     if (quarter && N >= 8 && N <= 16384 && llzs_tune(LLZS_TUNE_MDCTQ_STEPS) < 1)   /* one launch, the frame in and out of HBM once */
         return llzs_mdct4_q15(d_src, d_dst, count, N, f->d_step[inverse ? STEP_INV_PRE : STEP_FWD_PRE],
                               f->d_step[inverse ? STEP_INV_POST : STEP_FWD_POST], f->d_fft_cs, inverse, f->cof, f->stream);
+    if (!quarter && N >= 4 && N <= 4096 && llzs_tune(LLZS_TUNE_MDCTQ_STEPS) < 1)   /* the N-point form likewise */
+        return llzs_mdct1_q15(d_src, d_dst, count, N, f->d_step[inverse ? STEP_INV_PRE : STEP_FWD_PRE],
+                              f->d_step[inverse ? STEP_INV_POST : STEP_FWD_POST], f->d_fft_cs, inverse, f->stream);
     int *d_work = (int *)llz_stage_reserve(&f->work, sizeof(int) * 2 * (size_t)f->fft_size * (size_t)count);
     if (!d_work) return LLZ_ERR_NOMEM;
     /* the N-point form inverts with the inverse transform (llz_mdct_fixed.c:190); the N/4-point form runs the FORWARD
@@ -236,7 +239,7 @@ static int mdcx_run(unsigned long handle, const int *in, int *out, int count, in
     }
     /* (a launch of the step kernels takes at most 65535 frames: the frame index is the grid's second dimension; the one-launch
      * N/4-point form takes any number) */
-    const int whole = f->form == MDCT_FIXED_FFT4 && llzs_tune(LLZS_TUNE_MDCTQ_STEPS) < 1;
+    const int whole = f->form != MDCT_FIXED_ORIGIN && llzs_tune(LLZS_TUNE_MDCTQ_STEPS) < 1;
     const int most = whole ? count : 65535;
     for (int done = 0; rc == LLZ_OK && done < count; done += most) {
         const int part = count - done < most ? count - done : most;

@@ -13,6 +13,7 @@
 //  k_mdctq_fold        MDCT_FIXED_FFT4, in front of the N/4-point transform: fold the frame to N/4 points, rotate, halve
 //  k_mdctq_unfold      MDCT_FIXED_FFT4, behind it: rotate and scatter (forward) / rebuild the time frame (inverse)
 //  k_mdct4_q15         MDCT_FIXED_FFT4 in ONE launch: fold, the N/4-point Q15 transform and unfold in LDS (rows in, rows out)
+//  k_mdct1_q15         MDCT_FIXED_FFT in ONE launch: modulate, the N-point Q15 transform and demodulate in LDS
 #include "common.hpp"
 #include "fft_core.hpp"
 
@@ -234,7 +235,107 @@ k_mdct4_q15(const int *__restrict__ in, int *__restrict__ out, int count, int N,
     }
 }
 
+// MDCT_FIXED_FFT whole (llz_mdct_fixed.c:155-196), the same way: modulate the frame into the N-point transform's LDS image
+// (k_mdctq_modulate's expressions; the inverse continues the N/2 coefficients with odd symmetry), the radix-2 passes of the
+// bit-exact Q15 transform -- forward for the MDCT, inverse (decimation in time from the bit-reversed image, then >> log2 N:
+// llz_fft_fixed.c:187-215) for the IMDCT -- and k_mdctq_demodulate's rotation of the bins the direction keeps, row by row.
+//   forward: in = x [count][N], out = X [count][N/2];   inverse: in = X [count][N/2], out = x [count][N]
+template <bool INVERSE>
+__global__ void __launch_bounds__(FFT_THREADS)
+k_mdct1_q15(const int *__restrict__ in, int *__restrict__ out, int count, int N, int log2n, const short2 *__restrict__ pre,
+            const short2 *__restrict__ post, const short *__restrict__ cs, int tpw, unsigned groups)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int N2 = N >> 1;
+    const int tstride = fft_phys(N) + 1;
+    cpx<int> *s = reinterpret_cast<cpx<int> *>(smem_raw);
+    cpx<short> *tw = reinterpret_cast<cpx<short> *>(s + (size_t)tpw * tstride);
+    const int tid = threadIdx.x;
+    const int tr0 = blockIdx.x * tpw;
+    const int ntr = min(tpw, count - tr0);
+    const int in_len = INVERSE ? N2 : N, out_len = INVERSE ? N : N2;
+    fft_load_twiddles(tw, cs, N, tid);
+    for (int e = tid; e < ntr * N; e += FFT_THREADS) {
+        const int tr = e >> log2n, k = e & (N - 1);
+        const int *src = in + (size_t)(tr0 + tr) * in_len;
+        int v;
+        if (!INVERSE) v = src[k];
+        else v = k < N2 ? src[k] : wrap_neg(src[N - 1 - k]);
+        const short2 w = pre[k];
+        cpx<int> z;
+        z.re = q15(v, w.x);
+        z.im = q15(v, w.y);
+        // the inverse passes start from the bit-reversed image (llz_fft_fixed.c:187-195)
+        const int at = INVERSE ? (int)(__brev((unsigned)k) >> (32 - log2n)) : k;
+        s[tr * tstride + fft_phys(at)] = z;
+    }
+    __syncthreads();
+    {
+        int done = 0;
+#pragma unroll 1
+        for (int p = 0; p < 4; p++) {
+            const int G = (groups >> (4 * p)) & 15;
+            if (G == 0) break;
+            const int log2step = INVERSE ? done : (log2n - done - G);
+            switch (G) {
+            case 1: fft_pass<arith_q15, 1, INVERSE>(s, ntr, N, log2n, log2step, tstride, tw, tid); break;
+            case 2: fft_pass<arith_q15, 2, INVERSE>(s, ntr, N, log2n, log2step, tstride, tw, tid); break;
+            case 3: fft_pass<arith_q15, 3, INVERSE>(s, ntr, N, log2n, log2step, tstride, tw, tid); break;
+            default: fft_pass<arith_q15, 4, INVERSE>(s, ntr, N, log2n, log2step, tstride, tw, tid); break;
+            }
+            done += G;
+        }
+    }
+    for (int e = tid; e < ntr * out_len; e += FFT_THREADS) {
+        const int tr = e / out_len, k = e - tr * out_len;
+        // forward: bin k sits at the bit-reversed position; inverse: sample k in place, scaled by 2^-log2n
+        cpx<int> p = s[tr * tstride + fft_phys(INVERSE ? k : (int)(__brev((unsigned)k) >> (32 - log2n)))];
+        if (INVERSE) {
+            p.re = arith_q15::scale_out(p.re, log2n);
+            p.im = arith_q15::scale_out(p.im, log2n);
+        }
+        const short2 w = post[k];
+        const int d = wrap_sub(q15(p.re, w.x), q15(p.im, w.y));
+        out[(size_t)(tr0 + tr) * out_len + k] = INVERSE ? (int)((unsigned)d << 1) : d;
+    }
+}
+
 } // namespace
+
+// MDCT_FIXED_FFT in one launch; N a power of two in 4..4096; pre: N (cos, sin) Q15 pairs; post: N/2 (forward) or N (inverse)
+// pairs; cs: the N-point transform's table
+extern "C" int llzs_mdct1_q15(const int *in, int *out, int count, int N, const short *pre, const short *post, const short *cs,
+                              int inverse, void *stream)
+{
+    int log2n = 0;
+    while ((1 << log2n) < N) log2n++;
+    if (!in || !out || !pre || !post || !cs || count < 1 || N < 4 || N > 4096 || (1 << log2n) != N) {
+        llzs_set_error("mdct1_q15: bad arguments (N=%d must be a power of two in 4..4096, count=%d)", N, count);
+        return LLZ_ERR_ARG;
+    }
+    int tpw = 2048 / N;
+    if (tpw < 1) tpw = 1;
+    if (tpw > count) tpw = count;
+    const int tstride = N + (N >> 5) + 1;
+    const size_t lds = (size_t)tpw * tstride * 2 * sizeof(int) + (size_t)tw_entries(N) * 2 * sizeof(short);
+    const unsigned blocks = (unsigned)((count + tpw - 1) / tpw);
+    const short2 *p2 = reinterpret_cast<const short2 *>(pre), *q2 = reinterpret_cast<const short2 *>(post);
+    if (inverse) {
+        if (lds >= 64 * 1024)
+            LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mdct1_q15<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_mdct1_q15<true>, dim3(blocks), dim3(FFT_THREADS), lds, as_stream(stream), in, out, count, N, log2n,
+                           p2, q2, cs, tpw, fft_groups(log2n));
+    } else {
+        if (lds >= 64 * 1024)
+            LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mdct1_q15<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_mdct1_q15<false>, dim3(blocks), dim3(FFT_THREADS), lds, as_stream(stream), in, out, count, N, log2n,
+                           p2, q2, cs, tpw, fft_groups(log2n));
+    }
+    LLZ_LAUNCH_CHECK("k_mdct1_q15");
+    return LLZ_OK;
+}
 
 // MDCT_FIXED_FFT4 in one launch; N a power of two in 8..16384; pre / post: N/4 (cos, sin) Q15 pairs; cs: the N/4-point
 // transform's table

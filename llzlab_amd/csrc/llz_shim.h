@@ -50,7 +50,7 @@ enum {
     LLZS_TUNE_OLS_SEG_LEN,          /* jobs per segment of the 1024-point overlap-save walk (1..16) */
     LLZS_TUNE_MDCT_RUN,             /* MDCT-frames synthesis: output segments per group (0: a launch for the even and one for
                                      * the odd frames) */
-    LLZS_TUNE_MDCTQ_STEPS,          /* 1: fixed-point N/4-point MDCT as three launches (step, transform, step) */
+    LLZS_TUNE_MDCTQ_STEPS,          /* 1: fixed-point MDCT (both FFT forms) as three launches (step, transform, step) */
     LLZS_TUNE_RS_I16_TILES,         /* bit-exact int16 L/M resampler: period tiles per span (1..4) */
     LLZS_TUNE_RS_I16_WALK,          /* ... consecutive spans per workgroup */
     LLZS_TUNE_ACF_LDS,              /* 1: direct autocorrelation always on the LDS-window kernel (no register form for p <= 32) */
@@ -280,6 +280,9 @@ int llzs_mdctq_step(int quarter, int post, const int *in, int *out, const short 
  * step tables of this direction; cs: the N/4-point transform's table */
 int llzs_mdct4_q15(const int *in, int *out, int count, int N, const short *pre, const short *post, const short *cs,
                    int inverse, int cof, void *stream);
+/* the N-point form whole in one launch: N a power of two in 4..4096; pre N pairs, post N/2 (forward) or N (inverse) pairs */
+int llzs_mdct1_q15(const int *in, int *out, int count, int N, const short *pre, const short *post, const short *cs, int inverse,
+                   void *stream);
 /* framing of the single-channel analysis / synthesis symbols in double, exact order (frames_f64.hip; llz_asmodel.c:177-462):
  * slide_window: held_next = (held << hop) ++ fresh, dst = held_next * window (interleaved complex with zero imaginary part
  * when as_complex); split / mirror: interleaved spectrum <-> planes [re 0..N/2 | im 0..N/2]; overlap_add: acc + src * window,

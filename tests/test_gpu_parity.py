@@ -923,7 +923,8 @@ def test_mdct_reference_symbols_exact(dev):
 
 
 @pytest.mark.parametrize("t,n,count", [(0, 16, 7), (0, 256, 40), (1, 16, 3), (1, 256, 129), (1, 4096, 5), (2, 8, 4), (2, 64, 1000),
-                                       (2, 2048, 37), (2, 16384, 3), (2, 16, 1), (2, 32, 2049), (2, 512, 301), (2, 8192, 2)])
+                                       (2, 2048, 37), (2, 16384, 3), (2, 16, 1), (2, 32, 2049), (2, 512, 301), (2, 8192, 2),
+                                       (1, 8, 5), (1, 64, 1000), (1, 2048, 33)])
 def test_mdct_fixed_batch_vs_oracle(dev, oracle, t, n, count):
     """llz_mdct_fixed_batch / llz_imdct_fixed_batch: `count` frames per call on the device kernels (mdct_q15.hip + the Q15
     transform), device tensors in place and host arrays staged, against the oracle's frame-by-frame llz_mdct_fixed (itself
@@ -940,8 +941,9 @@ def test_mdct_fixed_batch_vs_oracle(dev, oracle, t, n, count):
     m.inverse_batch(Xd, yd)
     torch.cuda.synchronize()
     X, y = Xd.cpu().numpy(), yd.cpu().numpy()
-    if t == 2:
-        # the N/4-point form is one launch (k_mdct4_q15); as three launches it must give the same integers on every frame
+    if t in (1, 2):
+        # the two FFT forms are one launch each (k_mdct1_q15 / k_mdct4_q15); as three launches they must give the same integers on
+        # every frame
         with capi.tuned(mdctq_steps=1):
             X3, y3 = torch.empty_like(Xd), torch.empty_like(yd)
             m.forward_batch(xd, X3)

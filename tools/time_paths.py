@@ -226,7 +226,7 @@ if "mdctq" in which:
         gb = 6 * count * n
         print(f"mdct fixed type {t} N={n} x {count}: forward {ms_f:.3f} ms {gb / ms_f / 1e6:.0f} GB/s ({gb / ms_f / 1e6 / 80:.1f} %), "
               f"inverse {ms_i:.3f} ms {gb / ms_i / 1e6:.0f} GB/s ({gb / ms_i / 1e6 / 80:.1f} %)")
-        if t == 2:
+        if t in (1, 2):
             with capi.tuned(mdctq_steps=1):
                 ms_f = timeit(lambda: q.forward_batch(x, X), 5)
                 ms_i = timeit(lambda: q.inverse_batch(X, x), 5)
