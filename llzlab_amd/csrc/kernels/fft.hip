@@ -1111,14 +1111,22 @@ k_stft_analysis_reg_f32(const float *__restrict__ x, const float *__restrict__ h
 // Synthesis frames for the same sizes: k_stft_synthesis1024_f32's walk (bins from HBM into registers with the Hermitian
 // upper half taken from the mirrored bin, inverse transform, windowed real output into an LDS segment image, overlap-add
 // in the reference's order, oldest frame first) with 256 / E frames per group on square_core.
-template <int E, bool TWO>
+// HALF (fft_len = 2 E^2): the spectrum of a REAL frame of N = 2H samples needs ONE H-point complex inverse transform, not two:
+// with E[k] = (X[k] + conj(X[H-k])) / 2 and O[k] = (X[k] - conj(X[H-k])) W_N^-k / 2 (the spectra of the even and the odd samples),
+// z = IDFT_H(E + j O) is x[2n] + j x[2n+1].  Both bins come from HBM (the mirrored one by its own index: no lane exchange), the
+// results leave as (even, odd) pairs: half the transform work of the TWO form (1024 ch x 128 frames at 3/4 overlap, fft_len 2048:
+// 1.89 -> 1.15 ms; fft_len 512, 256 frames at 1/2 overlap: 0.48 -> 0.33 ms).  cs: cos, then sin of 2 pi i / N.
+// (At fft_len 2048 eight frame images are 64 KB and allow ONE workgroup per CU; letting the frames enter a four-frame image in
+//  two parts -- 75 KB, two workgroups per CU, two more barriers per group -- measured slower, 1.15 -> 1.32 ms.)
+template <int E, bool TWO, bool HALF>
 __global__ void __launch_bounds__(256)
 k_stft_synthesis_reg_f32(const float *__restrict__ re, const float *__restrict__ im, float *__restrict__ x,
                          const float *__restrict__ ola_old, float *__restrict__ ola_new, const float *__restrict__ w,
                          int frames, int F, const float2 *__restrict__ tw2d, const float2 *__restrict__ tw1, long x_pitch,
-                         int run_len, int runs, float magic)
+                         int run_len, int runs, float magic, const float *__restrict__ cs)
 {
-    constexpr int H = E * E, N = TWO ? 2 * H : H, TPW = 256 / E, PITCH = E + 1, BINS = N / 2 + 1;
+    static_assert(!(TWO && HALF), "the half-size form runs one square transform");
+    constexpr int H = E * E, N = (TWO || HALF) ? 2 * H : H, TPW = 256 / E, PITCH = E + 1, BINS = N / 2 + 1;
     constexpr int MAXM = ((TPW - 1) * (N / 2) + N + 255) / 256;       // span of a group at the largest hop (N/2)
     __shared__ float bufs[TPW][E * PITCH];
     __shared__ float seg[TPW][N];
@@ -1141,7 +1149,27 @@ k_stft_synthesis_reg_f32(const float *__restrict__ re, const float *__restrict__
                 return cf{a, k <= N / 2 ? b : -b};
             };
             float *buf = bufs[grp];
-            if (!TWO) {
+            if constexpr (HALF) {
+                cf v[E];
+#pragma unroll
+                for (int j = 0; j < E; j++) {
+                    const int k = lg + E * j;                          // 0 .. H-1; its partner H - k is in 1 .. H
+                    // (bins 0 and H are real in the spectrum of a real frame; whatever their imaginary parts hold reaches only the
+                    //  imaginary output of the full-size transform, which is dropped: the same here)
+                    const float xr = re[o + k], xi = k == 0 ? 0.f : im[o + k], mr = re[o + H - k], mi = k == 0 ? 0.f : -im[o + H - k];
+                    const float sr = xr + mr, si = xi + mi, dr = xr - mr, di = xi - mi;
+                    const float cw = cs[k], sn = cs[N + k];            // W_N^-k = cw + j sn
+                    const float orr = dr * cw - di * sn, oi = dr * sn + di * cw;     // (X[k] - conj X[H-k]) W_N^-k
+                    v[j] = cf{(sr - oi) * sc, (si + orr) * sc};        // (E + j O) / H = (S + j D W) / N
+                }
+                square_core<E, true>(v, buf, tw2d, lg);                // v[q] = x[2n] + j x[2n+1], n = lg + E brevE(q)
+#pragma unroll
+                for (int q = 0; q < E; q++) {
+                    const int n = lg + E * brevE<E>(q);
+                    const float2 ww = *reinterpret_cast<const float2 *>(w + 2 * n);
+                    *reinterpret_cast<float2 *>(&seg[grp][2 * n]) = make_float2(v[q].x * ww.x, v[q].y * ww.y);
+                }
+            } else if (!TWO) {
                 cf v[E];
 #pragma unroll
                 for (int j = 0; j < E; j++) v[j] = bin(lg + E * j);
@@ -2041,15 +2069,23 @@ extern "C" int llzs_stft_synthesis_f32(const float *re, const float *im, float *
         if (run_len > frames) run_len = frames;
         const int runsr = (frames + run_len - 1) / run_len;
         const dim3 grid((unsigned)((long)channels * runsr));
+        // (fft_len 512 and 2048: the half-size form; tw2d of those sizes IS the E^2-point table derived from the 2 E^2-point one)
+        const bool full = llzs_tune(LLZS_TUNE_STFT_FULL) == 1;
         if (size == 256)
-            hipLaunchKernelGGL((k_stft_synthesis_reg_f32<16, false>), grid, dim3(256), 0, as_stream(stream), re, im, x, ola_old,
-                               ola_new, w, frames, F, tw2d, tw1, x_pitch, run_len, runsr, magic);
+            hipLaunchKernelGGL((k_stft_synthesis_reg_f32<16, false, false>), grid, dim3(256), 0, as_stream(stream), re, im, x,
+                               ola_old, ola_new, w, frames, F, tw2d, tw1, x_pitch, run_len, runsr, magic, cs);
+        else if (size == 512 && full)
+            hipLaunchKernelGGL((k_stft_synthesis_reg_f32<16, true, false>), grid, dim3(256), 0, as_stream(stream), re, im, x,
+                               ola_old, ola_new, w, frames, F, tw2d, tw1, x_pitch, run_len, runsr, magic, cs);
         else if (size == 512)
-            hipLaunchKernelGGL((k_stft_synthesis_reg_f32<16, true>), grid, dim3(256), 0, as_stream(stream), re, im, x, ola_old,
-                               ola_new, w, frames, F, tw2d, tw1, x_pitch, run_len, runsr, magic);
+            hipLaunchKernelGGL((k_stft_synthesis_reg_f32<16, false, true>), grid, dim3(256), 0, as_stream(stream), re, im, x,
+                               ola_old, ola_new, w, frames, F, tw2d, tw1, x_pitch, run_len, runsr, magic, cs);
+        else if (full)
+            hipLaunchKernelGGL((k_stft_synthesis_reg_f32<32, true, false>), grid, dim3(256), 0, as_stream(stream), re, im, x,
+                               ola_old, ola_new, w, frames, F, tw2d, tw1, x_pitch, run_len, runsr, magic, cs);
         else
-            hipLaunchKernelGGL((k_stft_synthesis_reg_f32<32, true>), grid, dim3(256), 0, as_stream(stream), re, im, x, ola_old,
-                               ola_new, w, frames, F, tw2d, tw1, x_pitch, run_len, runsr, magic);
+            hipLaunchKernelGGL((k_stft_synthesis_reg_f32<32, false, true>), grid, dim3(256), 0, as_stream(stream), re, im, x,
+                               ola_old, ola_new, w, frames, F, tw2d, tw1, x_pitch, run_len, runsr, magic, cs);
         LLZ_LAUNCH_CHECK("k_stft_synthesis_reg_f32");
         return LLZ_OK;
     }

@@ -24,7 +24,7 @@ static std::atomic<int> g_tune[LLZS_TUNE_COUNT];
 static const char *const g_tune_names[LLZS_TUNE_COUNT] = {
     "ols_wg_per_cu", "rs_generic", "rs_tiles", "rs_dec_valu", "rs_i16_path", "mfma_nacc",
     "mfma_wg_per_cu", "fft_generic", "iir_segs", "iir_unpacked", "iir_f64", "iir_pipe", "iir_wave_min_items",
-    "shard_rccl", "rs_mfma_form", "ols_seg_len", "mdct_run", "mdctq_steps", "rs_i16_tiles", "rs_i16_walk", "acf_lds"};
+    "shard_rccl", "rs_mfma_form", "ols_seg_len", "mdct_run", "mdctq_steps", "rs_i16_tiles", "rs_i16_walk", "acf_lds", "stft_full"};
 namespace {
 struct tune_init {
     tune_init() { for (auto &t : g_tune) t.store(-1, std::memory_order_relaxed); }

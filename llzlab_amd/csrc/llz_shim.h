@@ -54,6 +54,7 @@ enum {
     LLZS_TUNE_RS_I16_TILES,         /* bit-exact int16 L/M resampler: period tiles per span (1..4) */
     LLZS_TUNE_RS_I16_WALK,          /* ... consecutive spans per workgroup */
     LLZS_TUNE_ACF_LDS,              /* 1: direct autocorrelation always on the LDS-window kernel (no register form for p <= 32) */
+    LLZS_TUNE_STFT_FULL,            /* 1: STFT synthesis frames of 512 / 2048 points on the full-size complex inverse transform */
     LLZS_TUNE_COUNT
 };
 int llzs_tune(int id);                                   /* current override or -1 */

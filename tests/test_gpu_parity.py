@@ -861,6 +861,30 @@ def test_stft_mc_vs_oracle_streaming(dev, oracle, hint, frame_len, win, channels
     f.close()
 
 
+@pytest.mark.parametrize("hint,frame_len", [(0, 512), (1, 1024), (0, 128), (1, 256)])
+def test_stft_synthesis_half_size_transform_agrees_with_full(dev, hint, frame_len):
+    """fft_len 512 and 2048: the synthesis takes ONE half-size complex inverse transform per real frame (k_stft_synthesis_reg_f32<..,
+    HALF>); the full-size form (llz_hip_tune("stft_full", 1)) must give the same samples to float32 rounding, on spectra that
+    are NOT Hermitian-consistent at bins 0 and N/2 (their imaginary parts do not reach a real output in either form)"""
+    channels, frames = 3, 37
+    rng = np.random.default_rng(frame_len + hint)
+    bins = (frame_len << (2 if hint == 0 else 1)) // 2 + 1
+    re = rng.uniform(-1, 1, (channels, frames, bins)).astype(np.float32)
+    im = rng.uniform(-1, 1, (channels, frames, bins)).astype(np.float32)
+    outs = []
+    for full in (-1, 1):
+        capi.tune("stft_full", full)
+        try:
+            f = filters.StftMC(channels, hint, frame_len, po.BLACKMAN)
+            xo = torch.empty(channels, frames * frame_len, dtype=torch.float32, device=dev)
+            f.synthesis(torch.from_numpy(re).to(dev), torch.from_numpy(im).to(dev), xo)
+            outs.append(xo.cpu().numpy())
+            f.close()
+        finally:
+            capi.tune("stft_full", -1)
+    assert np.abs(outs[0] - outs[1]).max() <= 2e-5 * max(1.0, np.abs(outs[1]).max())
+
+
 def test_stft_mc_host_buffers_and_many_runs(dev, oracle):
     """host numpy buffers, and enough frames that one channel is split over several workgroup runs (warm-up frames and
     dropped blocks in the synthesis kernel)"""
