@@ -154,8 +154,6 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
     signed char *xs_lo = atab + abytes;                  // sample planes: low digit (x & 255) - 128, then x >> 8
     signed char *xs_hi = xs_lo + sh.plane;
     double *gd_lds = reinterpret_cast<double *>(xs_hi + sh.plane);      // the T double taps (recompute path)
-    int *any_flag = reinterpret_cast<int *>(gd_lds + sh.T);             // two words: see the staging barrier
-    int flip = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, kq = lane >> 4;
     const int seg = mx_seg(n);
@@ -171,7 +169,6 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         atab[e] = (k >= 0 && k < sh.T) ? digits[p * sh.T + k] : (signed char)0;
     }
     for (int k = tid; k < sh.T; k += MX_THREADS) gd_lds[k] = gd[k];
-    if (tid < 2) any_flag[tid] = 0;
 
     // the walk: tile (c, t) = channel c, tile t of the channel; a workgroup advances by gridDim.x tiles, channel by channel
     // (no division in the loop: gridDim.x = cdiv tiles_per_ch + crem is split once)
@@ -201,13 +198,12 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         poff[j] = 2 * (p < last8 ? p : last8);
     }
 
-    // front half of a tile: its samples into the LDS planes; returns "some sample is non-zero"
+    // front half of a tile: its samples into the LDS planes
     MX_T0();
     [[maybe_unused]] int mx_tiles = 0;
     auto stage = [&](int c, int t, i16x8 (&v)[NV], bool streamed, int young) {
         __syncthreads();                                  // the previous tile's readers of the planes are done
         MX_MARK(0);                                       // first barrier
-        int nonzero = 0;
         if (streamed) {
             // the stores of the previous tile are the only operations younger than the request
             if (young >= NACC) mx_wait_vm<NACC>();
@@ -218,7 +214,6 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
                 // 8 samples = 4 dwords; v_perm_b32 gathers the low / high bytes of four samples at a time, and
                 // (x & 255) - 128 as a signed byte is the low byte with its top bit flipped
                 const u32x4 d = __builtin_bit_cast(u32x4, v[j]);
-                nonzero |= (int)(d[0] | d[1] | d[2] | d[3]);
                 u32x2 lo, hi;
                 lo[0] = __builtin_amdgcn_perm(d[1], d[0], 0x06040200u) ^ 0x80808080u;
                 lo[1] = __builtin_amdgcn_perm(d[3], d[2], 0x06040200u) ^ 0x80808080u;
@@ -239,23 +234,15 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
                 } else if (hrow && idx >= -(long)(sh.T - 1)) {
                     x = hrow[sh.T - 1 + idx];
                 }
-                nonzero |= x;
                 xs_lo[p] = (signed char)((x & 255) - 128);
                 xs_hi[p] = (signed char)(x >> 8);
             }
         }
-        // "is any sample of the tile non-zero": one LDS word per tile parity, set by the first lane of each wave that saw one
-        // (plain stores of the same value), read behind the staging barrier -- __syncthreads_or costs two more barriers and
-        // an LDS atomic per tile.  The word of the NEXT tile is cleared here, behind this tile's barrier (its last readers
-        // passed two barriers ago).
+        // (Digital silence needs no flag: every output of a silent tile is the value 0 exactly, which scr_near_zero settles
+        //  without a second look.  Rounds 2-3 kept a "some sample is non-zero" word per tile in LDS and skipped the arithmetic.)
         MX_MARK(1);                                       // request awaited, planes written
-        if (__ballot(nonzero != 0) != 0 && lane == 0) any_flag[flip] = 1;
         __syncthreads();
         MX_MARK(2);                                       // second barrier
-        const int any = any_flag[flip];
-        if (tid == 0) any_flag[flip ^ 1] = 0;
-        flip ^= 1;
-        return any;
     };
 
     // start values of the accumulators (screen_i8.hpp: the bias and the 2^31 offset ride along in the first products)
@@ -279,7 +266,7 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
     }
 
     // back half: products, decisions, stores; returns the number of store instructions issued per lane (for the wait count)
-    auto finish = [&](int t, long ooff, int any) {
+    auto finish = [&](int t, long ooff) {
         const long o0 = (long)t * TILE_OUT;
         short *otile = out + ooff;                                   // wave-uniform: the tile's first output
         const bool whole = aligned_out && o0 + TILE_OUT <= n_out;
@@ -295,12 +282,6 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
                     if (o0 + oo + j < n_out) otile[oo + j] = y[j];
             }
         };
-        if (!any) {                                     // digital silence: every output sits ON the integer 0
-            const int zero[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int a = 0; a < NACC; a++) store4(a, zero);
-            return whole ? NACC : 0;
-        }
         i32x4 acc[NACC][MX_ACCS];
         {
             const signed char *bp[NACC], *bph[NACC];
@@ -366,7 +347,12 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
 #pragma unroll
             for (int a = 0; a < NACC; a++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) mine = mine + mine + (unsure[a][j] ? 1u : 0u);    // slot 4 a + j at bit 4 NACC - 1 - (4 a + j)
+                for (int j = 0; j < 4; j++) {
+                    // (not a value within eps of zero: that truncates to 0 from either side -- screen_i8.hpp)
+                    const bool look = unsure[a][j] && !scr_near_zero<NEG>(acc[a][0][j], acc[a][1][j], acc[a][2][j], acc[a][3][j],
+                                                                          acc[a][4][j], pr.rs, pr.e32);
+                    mine = mine + mine + (look ? 1u : 0u);                         // slot 4 a + j at bit 4 NACC - 1 - (4 a + j)
+                }
 #pragma unroll 1
             while (mine != 0) {
                 // an integer within eps of the value: the reference's own arithmetic decides, in the lane that found it
@@ -408,8 +394,7 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
     int young = 0;
     i16x8 v[NV];
     while (in_work || cn < channels) {
-        int any = 0;
-        if (in_work) any = stage(c, t, v, streamed, young);
+        if (in_work) stage(c, t, v, streamed, young);
         const bool next_streams = streams(cn, tn);
         // (a tile that does not stream requests the first row instead: in bounds -- the launcher requires n_in >= total --
         //  and never looked at)
@@ -418,7 +403,7 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
         for (int j = 0; j < NV; j++) v[j] = mx_load_nt(src, poff[j]);
         MX_MARK(3);                                         // next tile requested
         young = 0;
-        if (in_work) { young = finish(t, ooff, any); mx_tiles++; }
+        if (in_work) { young = finish(t, ooff); mx_tiles++; }
         c = cn;
         t = tn;
         ooff = ooff_n;
@@ -442,7 +427,7 @@ bool mx_make_shape(int T, int M, int nacc, long n_out, mx_shape *sh, size_t *lds
     sh->total = ((tile_out - 16) * M + 64 * sh->ksteps + 7) & ~7;
     sh->plane = (sh->total + 16 + 15) & ~15;
     sh->tiles_per_ch = (int)((n_out + tile_out - 1) / tile_out);
-    *lds_bytes = (size_t)MX_PLANES * sh->ksteps * 1024 + 2 * (size_t)sh->plane + sizeof(double) * (size_t)T + 2 * sizeof(int);
+    *lds_bytes = (size_t)MX_PLANES * sh->ksteps * 1024 + 2 * (size_t)sh->plane + sizeof(double) * (size_t)T;
     // pairs of plane sums are combined in 32 bits: (2 T 2^14)(256 + 1) < 2^31 needs T <= 200; the staging needs
     // total <= NV_MAX x 256 x 8 samples
     return *lds_bytes <= 160 * 1024 && sh->total <= MX_NV_MAX * MX_THREADS * 8 && T <= 200;

@@ -302,8 +302,12 @@ k_resample_i8d(const short *__restrict__ in, short *__restrict__ out, const shor
                 const int col = 16 * p + col16;
                 unsigned mine = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    mine = mine + mine + ((unsure[j] && !((settled[j] >> lane) & 1ull)) ? 1u : 0u);    // slot j at bit 3 - j
+                for (int j = 0; j < 4; j++) {
+                    // (not the settled slots, and not a value within eps of zero: that truncates to 0 from either side)
+                    const bool look = unsure[j] && !((settled[j] >> lane) & 1ull) &&
+                                      !scr_near_zero<NEG>(acc[0][j], acc[1][j], acc[2][j], acc[3][j], acc[4][j], sh.rs, sh.e32);
+                    mine = mine + mine + (look ? 1u : 0u);                                 // slot j at bit 3 - j
+                }
 #pragma unroll 1
                 while (mine != 0) {
                     // an integer within eps of the value: the reference's own arithmetic decides, in the lane that found it

@@ -62,6 +62,31 @@ __device__ __forceinline__ int scr_decide(int a0, int a1, int a2, int a3, int a4
     return I + (int)__builtin_amdgcn_ubfe((unsigned)I, 31u, not_integer);
 }
 
+// An undecided output whose value lies within eps of ZERO is decided after all: the reference's y then lies in (-1, 1) and
+// truncates to 0 from either side -- which is what scr_decide returned (I = 0: 0; I = -1: -1 + 1).  Digital silence makes EVERY
+// output such a value (all products vanish: T' = 0 exactly), so without this a silent channel takes the second look for every
+// sample (measured on k_resample_i8d: 11.0 ms against 0.64 ms for noise).  Evaluated in the rare branch only.
+template <bool NEG>
+__device__ __forceinline__ bool scr_near_zero(int a0, int a1, int a2, int a3, int a4, int rs, unsigned e32)
+{
+    const unsigned p = (unsigned)a0 + ((unsigned)a1 << 8);
+    const int q = a2 + (a3 << 8);
+    unsigned c1, c2;
+    const unsigned lo = __builtin_addc(p, (unsigned)q << 16, 0u, &c1);
+    const int hi = (int)__builtin_addc((unsigned)a4, (unsigned)(q >> 16), c1, &c2);
+    int I;
+    unsigned F;
+    if (NEG) {
+        I = (int)__builtin_amdgcn_alignbit((unsigned)hi, lo, (unsigned)(32 + rs));
+        F = lo << (-rs);
+    } else {
+        I = hi >> rs;
+        F = __builtin_amdgcn_alignbit((unsigned)hi, lo, (unsigned)rs);
+    }
+    const unsigned t = F + e32;                                 // within e32 above 0: t in [e32, 2 e32]; below 0: t in [0, e32)
+    return (I == 0 && t >= e32 && t <= 2u * e32) || (I == -1 && t < e32);
+}
+
 // the reference's clamp (llz_resample.c:596-599) on the truncated value
 __device__ __forceinline__ short scr_clamp(int t)
 {
