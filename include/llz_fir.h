@@ -67,7 +67,8 @@ enum {
     LLZ_FIR_ALGO_OVERLAP_SAVE = 2, /* 1024-point in-LDS FFT overlap-save, flt_len <= 257 */
     LLZ_FIR_ALGO_TIME_MFMA = 3,   /* direct form as a banded Toeplitz product on the fp32 matrix cores */
     LLZ_FIR_ALGO_OVERLAP_SAVE_2048 = 4, /* 2048-point register-transform overlap-save, 2 <= flt_len <= 1025 */
-    LLZ_FIR_ALGO_OVERLAP_SAVE_4096 = 5  /* 4096-point register-transform overlap-save, 2 <= flt_len <= 3073 */
+    LLZ_FIR_ALGO_OVERLAP_SAVE_4096 = 5, /* 4096-point register-transform overlap-save, 2 <= flt_len <= 3073 */
+    LLZ_FIR_ALGO_OVERLAP_SAVE_8192 = 6  /* 8192-point register-transform overlap-save on pairs of waves, 2 <= flt_len <= 4097 */
 };
 
 /* channels independent filters sharing one tap set. taps: HOST pointer, flt_len floats (double variant

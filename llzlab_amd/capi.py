@@ -18,6 +18,7 @@ BAD_HANDLE = C.c_ulong(-1).value
 HAMMING, BLACKMAN, KAISER = 0, 1, 2
 FIR_ALGO_AUTO, FIR_ALGO_TIME, FIR_ALGO_OVERLAP_SAVE, FIR_ALGO_TIME_MFMA, FIR_ALGO_OVERLAP_SAVE_2048 = 0, 1, 2, 3, 4
 FIR_ALGO_OVERLAP_SAVE_4096 = 5
+FIR_ALGO_OVERLAP_SAVE_8192 = 6
 OVERLAP_HIGH, OVERLAP_LOW = 0, 1      # llz_asmodel.h: 3/4 and 1/2 overlap
 MDCT_ORIGIN, MDCT_FFT, MDCT_FFT4 = 0, 1, 2
 MDCT_SINE, MDCT_KBD = 0, 1

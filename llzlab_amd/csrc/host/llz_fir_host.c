@@ -308,6 +308,52 @@ static int firm_build_ols4k_tables(firm_t *f, const float *taps)
     return rc;
 }
 
+/* 2 .. 4097 taps on pairs of waves (k_fir_ols8k_f32): DFT_8192(taps) / 8192 as eight planes (plane j = bins 8m + j), the
+ * 32 x 32 twiddles of the 1024-point transforms and W_4096^n (the kernel forms W_8192^n itself).  Direct DFT in double. */
+static int firm_build_ols8k_tables(firm_t *f, const float *taps)
+{
+    const int N = 8192, Q = 1024;
+    float *hf = (float *)malloc(sizeof(float) * 2 * (size_t)N);
+    float *tw = (float *)malloc(sizeof(float) * 2 * 1024);
+    float *w4 = (float *)malloc(sizeof(float) * 2 * 2048);
+    double *cs = (double *)malloc(sizeof(double) * 2 * (size_t)N);
+    int rc = LLZ_ERR_NOMEM;
+    if (hf && tw && w4 && cs) {
+        for (int i = 0; i < N; i++) {
+            const double ang = 2.0 * M_PI * (double)i / (double)N;
+            cs[2 * i] = (i == N / 4 || i == 3 * N / 4) ? 0.0 : cos(ang);
+            cs[2 * i + 1] = (i == 0 || i == N / 2) ? 0.0 : sin(ang);
+        }
+        for (int k = 0; k < N; k++) {
+            double re = 0.0, im = 0.0;
+            for (int t = 0; t < f->flt_len; t++) {
+                const int m = (int)(((long)k * t) % N);
+                re += (double)taps[t] * cs[2 * m];
+                im -= (double)taps[t] * cs[2 * m + 1];
+            }
+            const int dst = (k & 7) * Q + (k >> 3);
+            hf[2 * dst] = (float)(re / N);
+            hf[2 * dst + 1] = (float)(im / N);
+        }
+        for (int a = 0; a < 32; a++)
+            for (int b = 0; b < 32; b++) {
+                const int m = (8 * a * b) % N;                         /* W_1024^(ab) = W_8192^(8ab) */
+                tw[2 * (a * 32 + b)] = (float)cs[2 * m];
+                tw[2 * (a * 32 + b) + 1] = (float)(-cs[2 * m + 1]);
+            }
+        for (int i = 0; i < 2048; i++) { w4[2 * i] = (float)cs[2 * (2 * i)]; w4[2 * i + 1] = (float)(-cs[2 * (2 * i) + 1]); }
+        f->d_hfreq = (float *)llzs_malloc(sizeof(float) * 2 * (size_t)N);
+        f->d_twid = (float *)llzs_malloc(sizeof(float) * 2 * 1024);
+        f->d_tw4k = (float *)llzs_malloc(sizeof(float) * 2 * 2048);
+        rc = (f->d_hfreq && f->d_twid && f->d_tw4k) ? LLZ_OK : LLZ_ERR_NOMEM;
+        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_hfreq, hf, sizeof(float) * 2 * (size_t)N);
+        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_twid, tw, sizeof(float) * 2 * 1024);
+        if (rc == LLZ_OK) rc = llzs_h2d_table(f->d_tw4k, w4, sizeof(float) * 2 * 2048);
+    }
+    free(hf); free(tw); free(w4); free(cs);
+    return rc;
+}
+
 unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *taps, int flt_len, int algo)
 {
     if (channels < 1 || channels > 65535 || frame_len < 1 || !taps || flt_len < 1) {
@@ -340,6 +386,10 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
         llzs_set_error("llz_fir_filter_mc_init: the 4096-point overlap-save takes 2..%d taps", LLZS_OLS4K_MAX_TAPS);
         return LLZ_BAD_HANDLE;
     }
+    if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_8192 && (flt_len < 2 || flt_len > LLZS_OLS8K_MAX_TAPS)) {
+        llzs_set_error("llz_fir_filter_mc_init: the 8192-point overlap-save takes 2..%d taps", LLZS_OLS8K_MAX_TAPS);
+        return LLZ_BAD_HANDLE;
+    }
     if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE && flt_len > LLZS_OLS_MAX_TAPS) {
         llzs_set_error("llz_fir_filter_mc_init: overlap-save supports at most %d taps", LLZS_OLS_MAX_TAPS);
         return LLZ_BAD_HANDLE;
@@ -349,7 +399,7 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
         return LLZ_BAD_HANDLE;
     }
     if (algo != LLZ_FIR_ALGO_TIME && algo != LLZ_FIR_ALGO_OVERLAP_SAVE && algo != LLZ_FIR_ALGO_TIME_MFMA &&
-        algo != LLZ_FIR_ALGO_OVERLAP_SAVE_2048 && algo != LLZ_FIR_ALGO_OVERLAP_SAVE_4096) {
+        algo != LLZ_FIR_ALGO_OVERLAP_SAVE_2048 && algo != LLZ_FIR_ALGO_OVERLAP_SAVE_4096 && algo != LLZ_FIR_ALGO_OVERLAP_SAVE_8192) {
         llzs_set_error("llz_fir_filter_mc_init: unknown algo %d", algo);
         return LLZ_BAD_HANDLE;
     }
@@ -379,6 +429,7 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
     if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE_2048) rc = firm_build_ols2k_tables(f, taps);
     if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE_4096)
         rc = firm_build_ols4k_tables(f, taps);
+    if (rc == LLZ_OK && algo == LLZ_FIR_ALGO_OVERLAP_SAVE_8192) rc = firm_build_ols8k_tables(f, taps);
     if (rc == LLZ_OK) rc = llzs_sync(NULL);
     free(padded);
     if (rc != LLZ_OK) {
@@ -480,6 +531,9 @@ static int firm_launch(firm_t *f, const float *d_in, float *d_out, int n, long p
     else if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_4096)
         rc = llzs_fir_ols4k_f32(d_in, d_out, hist, f->d_hfreq, f->d_twid, f->d_tw2k, f->d_tw4k, f->channels, n, pitch_in,
                                 pitch_out, f->flt_len, f->stream);
+    else if (algo == LLZ_FIR_ALGO_OVERLAP_SAVE_8192)
+        rc = llzs_fir_ols8k_f32(d_in, d_out, hist, f->d_hfreq, f->d_twid, f->d_tw4k, f->channels, n, pitch_in, pitch_out,
+                                f->flt_len, f->stream);
     else if (algo == LLZ_FIR_ALGO_TIME_MFMA)
         rc = llzs_fir_mfma_f32(d_in, d_out, hist, f->d_taps, f->channels, n, n, pitch_in, pitch_out, f->flt_len, 1,
                                1.0f, f->stream);

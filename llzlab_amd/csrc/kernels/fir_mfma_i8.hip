@@ -139,7 +139,9 @@ __device__ unsigned long long mx_trace_buf[65536 * 8];
 #endif
 namespace {
 
-// KS: the number of 64-sample steps when it is 1..3 (every LDS operand address is then base + constant), 0 = read sh.ksteps
+// KS: the number of 64-sample steps when it is 1 or 2 (every LDS operand address is then base + constant), 0 = read sh.ksteps
+// (three unrolled steps measured SLOWER than the loop on config 5: 130 registers against 123, 3 waves per SIMD against 4 --
+// 21.9 against 21.6 ms, same box)
 template <int NACC, int NV, bool NEG, int KS>
 __global__ void __launch_bounds__(MX_THREADS)
 k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const short *__restrict__ hist,
@@ -319,7 +321,6 @@ k_fir_mfma_i8x(const short *__restrict__ in, short *__restrict__ out, const shor
             step(0, std::true_type{});
             if constexpr (KS > 0) {
                 if constexpr (KS > 1) step(1, std::false_type{});
-                if constexpr (KS > 2) step(2, std::false_type{});
             } else {
                 for (int s = 1; s < ksteps; s++) step(s, std::false_type{});
             }
@@ -521,7 +522,6 @@ extern "C" int llzs_fir_mfma_i16x(const short *in, short *out, const short *hist
     do {                                                                                                                       \
         if (sh.ksteps == 1) MX_GO3(A, V, N, 1);                                                                                \
         if (sh.ksteps == 2) MX_GO3(A, V, N, 2);                                                                                \
-        if (sh.ksteps == 3) MX_GO3(A, V, N, 3);                                                                                \
         MX_GO3(A, V, N, 0);                                                                                                    \
     } while (0)
 #define MX_GO(A, V)                                                                                                            \

@@ -484,6 +484,7 @@ k_fir_ols2k_chain_f32(const float *__restrict__ in, float *__restrict__ out, con
 constexpr int O4K_WAVES = 8, O4K_THREADS = 64 * O4K_WAVES;
 
 // one 2048-point problem of the wave: v[p] = row 2p + h (p < 32) in, y[p] out (same ownership); see k_fir_ols2k_chain_f32
+template <int WS = 1>                                                 // WS = 2: s_w is the W_4096^n table (every other entry)
 __device__ __forceinline__ void ols2k_core(cf (&v)[32], cf (&y)[32], float *buf, const float2 *s_tw, const float2 *my_h,
                                            const float2 *s_w, int l5, int rowoff)
 {
@@ -491,7 +492,7 @@ __device__ __forceinline__ void ols2k_core(cf (&v)[32], cf (&y)[32], float *buf,
 #pragma unroll
     for (int p = 0; p < 16; p++) {
         cf sm = cadd(v[p], v[p + 16]);
-        const float2 t = s_w[64 * p + rowoff];
+        const float2 t = s_w[WS * (64 * p + rowoff)];
         cf df = cmul<false>(csub(v[p], v[p + 16]), cf{t.x, t.y});
         swap32(sm.x, df.x);
         swap32(sm.y, df.y);
@@ -504,7 +505,7 @@ __device__ __forceinline__ void ols2k_core(cf (&v)[32], cf (&y)[32], float *buf,
         cf P = u[brev5(2 * p)], Q = u[brev5(2 * p + 1)];
         swap32(P.x, Q.x);
         swap32(P.y, Q.y);
-        const float2 t = s_w[64 * p + rowoff];
+        const float2 t = s_w[WS * (64 * p + rowoff)];
         Q = cmul<true>(Q, cf{t.x, t.y});
         y[p] = cadd(P, Q);
         y[p + 16] = csub(P, Q);
@@ -622,6 +623,272 @@ k_fir_ols4k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
                 } else {
                     if (oa < n) orow[oa] = y1.x;
                     if (ob < n) orow[ob] = y1.y;
+                }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 1538 .. 3073 taps: 8192-point transforms on a PAIR of waves.  With 3072 samples of overlap a 4096-point block yields 1024
+// outputs (25 % of the transform), an 8192-point block 5120 (62.5 %) at 13/12 of the work per point.
+//     X[2k] = FFT_4096( a[n] + a[n+4096] )  -> wave 0 of the pair,     X[2k+1] = FFT_4096( (a[n] - a[n+4096]) W_8192^n )  -> wave 1,
+// each wave then runs the 4096-point problem of k_fir_ols4k_f32 (radix-2 step + two 2048-point problems); back:
+// y[n] = E'[n] + W_8192^-n O'[n], y[n+4096] = E'[n] - W_8192^-n O'[n].
+// A block is 128 rows of 64 samples (position i = samples 64 i + lane).  Wave w requests positions 32w .. 32w+31 and the
+// same + 64 of both blocks (64 complex values per lane, as the 4096-point kernel), forms its 32 sums and 32 twiddled
+// differences, and the two waves SWAP halves through LDS: wave 0 gives its differences for wave 1's sums.  On the way back
+// wave 1 twiddles its results, the waves swap halves again and each forms and stores the outputs among "its" 64 positions.
+// W_8192^(64 i + lane) = W_128^i (a literal after unrolling) x W_8192^lane (two registers): no table.
+//
+// The swap goes through the transpose buffers the two waves own anyway (8.25 KB per wave: two rounds of 16 values per lane),
+// and the pair synchronises on four LDS words of its own instead of a workgroup barrier, so that the four pairs of a workgroup
+// drift apart and one pair's memory wait is another's arithmetic -- a barrier would hold all eight waves in the same phase
+// (64 complex values per lane leave no registers for a prefetch).  Both waves of a pair run the same loop bounds, hence the
+// same number of rounds; the waits are bounded (a pair out of step would produce wrong samples, which the tests see, never
+// a hang).  LDS: W_1024^(ab) 8 KB, W_4096^n 16 KB (W_2048^n = every other entry), spectrum 8 x 8 KB, buffers 66 KB = 154 KB.
+struct w128_tab {
+    float c[64], s[64];
+};
+constexpr double o8k_sin(double x)
+{
+    double term = x, sum = x;
+    for (int k = 1; k < 16; k++) {
+        term *= -x * x / (double)((2 * k) * (2 * k + 1));
+        sum += term;
+    }
+    return sum;
+}
+constexpr double o8k_cos(double x)
+{
+    double term = 1.0, sum = 1.0;
+    for (int k = 1; k < 16; k++) {
+        term *= -x * x / (double)((2 * k - 1) * (2 * k));
+        sum += term;
+    }
+    return sum;
+}
+constexpr w128_tab o8k_make_w128()
+{
+    w128_tab t{};
+    for (int j = 0; j < 64; j++) {
+        const double a = 3.14159265358979323846 * (double)j / 64.0;
+        t.c[j] = j == 32 ? 0.f : (float)o8k_cos(a);
+        t.s[j] = j == 0 ? 0.f : (float)o8k_sin(a);
+    }
+    return t;
+}
+__device__ constexpr w128_tab kW128 = o8k_make_w128();          // W_128^j = c[j] - i s[j]
+
+constexpr int O8K_WAVES = 8, O8K_THREADS = 64 * O8K_WAVES, O8K_PAIRS = O8K_WAVES / 2;
+constexpr int O8K_SPIN_LIMIT = 1 << 18;
+
+typedef __attribute__((address_space(3))) volatile int *o8k_flag_p;          // 32-bit LDS addresses: generic pointers in the
+typedef float o8k_f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) o8k_f2 *o8k_box_p;                 // struct would become 64-bit flat accesses
+struct o8k_pair {
+    o8k_flag_p my_free, my_sent, pt_free, pt_sent;             // round counters, one writer each
+    o8k_box_p my_box, pt_box;                                   // [16][64] (+ lane): the wave's own transpose buffers
+    int k;
+};
+__device__ __forceinline__ void o8k_signal(o8k_flag_p flag, int k)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // what this wave wrote / read before is done
+    *flag = k;
+}
+__device__ __forceinline__ void o8k_wait(o8k_flag_p flag, int k)
+{
+    int spins = 0;
+    while (__builtin_amdgcn_readfirstlane(*flag) < k && ++spins < O8K_SPIN_LIMIT) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+// the wave hands a[OFF .. OFF+31] to its partner and takes the partner's 32 values in their place
+template <int OFF>
+__device__ __forceinline__ void o8k_swap(cf (&a)[64], o8k_pair &ps)
+{
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        ps.k++;
+        o8k_signal(ps.my_free, ps.k);                           // my buffers may take round k
+        o8k_wait(ps.pt_free, ps.k);
+#pragma unroll
+        for (int i = 0; i < 16; i++) ps.pt_box[64 * i] = (o8k_f2){a[OFF + 16 * r + i].x, a[OFF + 16 * r + i].y};
+        o8k_signal(ps.my_sent, ps.k);
+        o8k_wait(ps.pt_sent, ps.k);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const o8k_f2 t = ps.my_box[64 * i];
+            a[OFF + 16 * r + i] = cf{t[0], t[1]};
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the buffers go back to the transposes
+}
+
+// the 4096-point problem of one wave, in place: a[p] = position p (sample 64 p + lane of the 4096) in and out; h_e / h_o = the
+// spectrum planes of its even-bin and odd-bin 2048-point problems for this half-wave
+__device__ __forceinline__ void ols4k_core(cf (&a)[64], float *buf, const float2 *s_tw, const float2 *s_w4, const float2 *h_e,
+                                           const float2 *h_o, int l5, int rowoff)
+{
+    cf e[32], o[32];
+#pragma unroll
+    for (int p = 0; p < 32; p++) {
+        e[p] = cadd(a[p], a[p + 32]);
+        const float2 t = s_w4[64 * p + rowoff];
+        o[p] = cmul<false>(csub(a[p], a[p + 32]), cf{t.x, t.y});
+    }
+    cf ye[32], yo[32];
+    ols2k_core<2>(e, ye, buf, s_tw, h_e, s_w4, l5, rowoff);
+    ols2k_core<2>(o, yo, buf, s_tw, h_o, s_w4, l5, rowoff);
+#pragma unroll
+    for (int p = 0; p < 32; p++) {
+        const float2 t = s_w4[64 * p + rowoff];
+        const cf q = cmul<true>(yo[p], cf{t.x, t.y});
+        a[p] = cadd(ye[p], q);
+        a[p + 32] = csub(ye[p], q);
+    }
+}
+
+// O = overlap, a multiple of 64 with flt_len - 1 <= O <= 4096; a job is two blocks = 2 (8192 - O) new samples of one channel
+template <int O>
+__global__ void __launch_bounds__(O8K_THREADS, 2)
+k_fir_ols8k_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
+                const float2 *__restrict__ hfreq8 /* [8][1024] */, const float2 *__restrict__ twid /* [32][32] W_1024^(ab) */,
+                const float2 *__restrict__ tw4k /* [2048] W_4096^n */, ols_geom G)
+{
+    constexpr int V = 8192 - O, JOB = 2 * V, PO = O / 64;
+    static_assert(O % 64 == 0 && O <= 4096, "block B must start inside the row");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *s_tw = reinterpret_cast<float2 *>(smem);           // [1024]
+    float2 *s_w4 = s_tw + 1024;                                 // [2048]
+    float2 *s_h = s_w4 + 2048;                                  // [8][1024]
+    float *s_buf = reinterpret_cast<float *>(s_h + 8192);       // [16][OLS_XBUF]
+    int *s_flag = reinterpret_cast<int *>(s_buf + 2 * O8K_WAVES * OLS_XBUF);                      // [8][2]
+    for (int i = threadIdx.x; i < 1024; i += O8K_THREADS) {
+        s_tw[i] = twid[i];
+        s_w4[i] = tw4k[i];
+        s_w4[1024 + i] = tw4k[1024 + i];
+#pragma unroll
+        for (int j = 0; j < 8; j++) s_h[1024 * j + i] = hfreq8[1024 * j + i];
+    }
+    if (threadIdx.x < 2 * O8K_WAVES) s_flag[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = wave & 1, pair = wave >> 1;
+    const int half = lane >> 5, l5 = lane & 31;
+    float *buf = s_buf + (wave * 2 + half) * OLS_XBUF;
+    o8k_pair ps;
+    ps.my_free = (o8k_flag_p)(s_flag + 2 * wave);
+    ps.my_sent = (o8k_flag_p)(s_flag + 2 * wave + 1);
+    ps.pt_free = (o8k_flag_p)(s_flag + 2 * (wave ^ 1));
+    ps.pt_sent = (o8k_flag_p)(s_flag + 2 * (wave ^ 1) + 1);
+    ps.my_box = (o8k_box_p)(reinterpret_cast<o8k_f2 *>(s_buf + (wave * 2) * OLS_XBUF) + lane);
+    ps.pt_box = (o8k_box_p)(reinterpret_cast<o8k_f2 *>(s_buf + ((wave ^ 1) * 2) * OLS_XBUF) + lane);
+    ps.k = 0;
+    const float2 *h_e = s_h + (4 * half + w) * 1024, *h_o = s_h + (4 * half + 2 + w) * 1024;
+    // W_8192^lane, times W_128^(32 w) = (-i)^w for the positions this wave requests
+    cf wl;
+    {
+        float sn, cs;
+        sincospif((float)lane * (1.0f / 4096.0f), &sn, &cs);
+        wl = cf{cs, -sn};
+    }
+    const long pairs_total = (long)gridDim.x * O8K_PAIRS;
+    const int n = G.n;
+    const int pos0 = 32 * w;
+
+    for (long seg = (long)blockIdx.x * O8K_PAIRS + pair; seg < G.total_segs; seg += pairs_total) {
+        const int c = (int)(seg / G.segs_per_channel);
+        const int j0 = (int)(seg - (long)c * G.segs_per_channel) * G.seg_len;
+        const int count = min(G.seg_len, G.jobs_per_channel - j0);
+        const float *row = in + (size_t)c * G.in_pitch;
+        float *orow = out + (size_t)c * G.out_pitch;
+        const float *hrow = hist ? hist + (size_t)c * G.keep : nullptr;
+#pragma unroll 1
+        for (int jj = 0; jj < count; jj++) {
+            const int s = (j0 + jj) * JOB;
+            // block A (real parts) = [s - O, s + V), block B (imaginary parts) = [s + V - O, s + 2V): B's first O samples are
+            // A's last O, the same addresses (requested again: cache hits, the other wave may hold them)
+            cf a[64];
+            const bool whole = s >= O && s + JOB <= n;
+            if (whole) {
+                const float *ra = row + s - O + 64 * pos0 + lane, *rb = ra + V;
+#pragma unroll
+                for (int j = 0; j < 32; j++) {
+                    a[j].x = __builtin_nontemporal_load(&ra[64 * j]);
+                    a[32 + j].x = __builtin_nontemporal_load(&ra[64 * (j + 64)]);
+                }
+#pragma unroll
+                for (int j = 0; j < 32; j++) {
+                    a[j].y = __builtin_nontemporal_load(&rb[64 * j]);
+                    a[32 + j].y = __builtin_nontemporal_load(&rb[64 * (j + 64)]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 64; j++) {
+                    const int pos = pos0 + (j < 32 ? j : j + 32);
+                    const int ia = s - O + 64 * pos + lane, ib = ia + V;
+                    float xa = 0.f;
+                    if (ia >= 0) xa = row[min(ia, n - 1)];
+                    else if (hrow && ia >= -G.keep) xa = hrow[G.keep + ia];
+                    a[j].x = ia < n ? xa : 0.f;
+                    const float xb = row[min(ib, n - 1)];
+                    a[j].y = ib < n ? xb : 0.f;
+                }
+            }
+            // ---- radix-2 step down over the wave's 32 positions.  Wave 1 works with the halves of its arrays exchanged (slot j =
+            // position j + 32 mod 64), so that BOTH waves keep slots 0..31 and swap slots 32..63 (one code path, no register
+            // shuffles where two would join): the 4096-point problem is indifferent to it -- exchanged input halves flip the
+            // sign of its odd-bin branch, which exchanges the output halves the same way.
+            // (the twiddles are formed where they are used: hoisted out of the job loop they would be 192 more live registers)
+            cf wv = w ? cf{wl.y, -wl.x} : wl;
+            asm volatile("" : "+v"(wv.x), "+v"(wv.y));
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                const cf sm = cadd(a[j], a[32 + j]), df = csub(a[j], a[32 + j]);
+                const cf t = cmul<false>(cf{kW128.c[j], -kW128.s[j]}, wv);
+                const cf dt = cmul<false>(df, t);
+                a[j] = w ? dt : sm;                                      // kept: wave 0 its sums (positions 0..31), wave 1 its
+                a[32 + j] = w ? sm : dt;                                 // differences (positions 32..63); the other 32 go over
+            }
+            o8k_swap<32>(a, ps);
+            ols4k_core(a, buf, s_tw, s_w4, h_e, h_o, l5, lane);
+            // ---- back: wave 1 turns its results by W_8192^-n (slot j = position j + 32 mod 64), gives the 32 of positions 0..31
+            // for wave 0's E' of positions 32..63, and position 32 w + j gets E' + q, position 32 w + j + 64 gets E' - q
+            if (w) {
+                cf wu = wl;
+                asm volatile("" : "+v"(wu.x), "+v"(wu.y));
+#pragma unroll
+                for (int p = 0; p < 64; p++) {
+                    const cf t = cmul<false>(cf{kW128.c[p ^ 32], -kW128.s[p ^ 32]}, wu);
+                    a[p] = cmul<true>(a[p], t);
+                }
+            }
+            o8k_swap<32>(a, ps);
+            const float sg = w ? -1.f : 1.f;                             // wave 0: a[j] = E', a[32 + j] = q; wave 1: the reverse
+            const bool all_out = s + JOB <= n;
+            const int jmin = PO - pos0;                                  // positions below PO are overlap
+            float *oa0 = orow + s + 64 * (pos0 - PO) + lane;
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                const cf y0 = cadd(a[j], a[32 + j]), d1 = csub(a[j], a[32 + j]);
+                const cf y1 = cf{d1.x * sg, d1.y * sg};
+                const int oa = s + 64 * (pos0 + j - PO) + lane, ob = oa + V;
+                if (all_out) {
+                    if (j >= jmin) {
+                        __builtin_nontemporal_store(y0.x, &oa0[64 * j]);
+                        __builtin_nontemporal_store(y0.y, &oa0[64 * j + V]);
+                    }
+                    __builtin_nontemporal_store(y1.x, &oa0[64 * (j + 64)]);
+                    __builtin_nontemporal_store(y1.y, &oa0[64 * (j + 64) + V]);
+                } else {
+                    if (j >= jmin) {
+                        if (oa < n) orow[oa] = y0.x;
+                        if (ob < n) orow[ob] = y0.y;
+                    }
+                    if (oa + 4096 < n) orow[oa + 4096] = y1.x;
+                    if (ob + 4096 < n) orow[ob + 4096] = y1.y;
                 }
             }
         }
@@ -792,4 +1059,62 @@ extern "C" int llzs_fir_ols4k_f32(const float *in, float *out, const float *hist
     if (flt_len <= 2561) LLZ_OLS4K_GO(2560);
     LLZ_OLS4K_GO(3072);
 #undef LLZ_OLS4K_GO
+}
+
+// 2 .. 4097 taps on 8192-point transforms (k_fir_ols8k_f32: a pair of waves per job; overlap 1536 / 2048 / ... / 4096 by tap
+// count): hfreq8 = [8][1024] complex, plane j = bins 8m + j of DFT_8192(taps) / 8192; twid [32][32] W_1024^(ab); tw4k [2048] W_4096^n
+template <int O>
+static int ols8k_launch(const float *in, float *out, const float *hist, const float *hfreq8, const float *twid,
+                        const float *tw4k, int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream)
+{
+    constexpr int JOB = 2 * (8192 - O);
+    ols_geom G;
+    G.n = n;
+    G.keep = flt_len - 1;
+    G.in_pitch = in_pitch;
+    G.out_pitch = out_pitch;
+    G.jobs_per_channel = (n + JOB - 1) / JOB;
+    const size_t lds_bytes = (1024 + 2048 + 8192) * sizeof(float2) + (size_t)O8K_WAVES * 2 * OLS_XBUF * sizeof(float) +
+                             2 * O8K_WAVES * sizeof(int);
+    const long max_blocks = 256L;                               // one 8-wave workgroup per CU
+    const long slots = max_blocks * O8K_PAIRS;
+    int seg_len = OLS_SEG;
+    if ((long)((G.jobs_per_channel + OLS_SEG - 1) / OLS_SEG) * channels < 4 * slots) {
+        double best = 1e300;
+        for (int sl = OLS_SEG; sl >= 1; sl--) {
+            const long segs = (long)((G.jobs_per_channel + sl - 1) / sl) * channels;
+            const double cost = (double)((segs + slots - 1) / slots) * sl;
+            if (cost < best * 0.999) { best = cost; seg_len = sl; }
+        }
+    }
+    G.seg_len = seg_len;
+    G.segs_per_channel = (G.jobs_per_channel + seg_len - 1) / seg_len;
+    G.total_segs = (long)G.segs_per_channel * channels;
+    long blocks = (G.total_segs + O8K_PAIRS - 1) / O8K_PAIRS;
+    if (blocks > max_blocks) blocks = max_blocks;
+    LLZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_ols8k_f32<O>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(k_fir_ols8k_f32<O>, dim3((unsigned)blocks), dim3(O8K_THREADS), lds_bytes, as_stream(stream), in, out, hist,
+                       reinterpret_cast<const float2 *>(hfreq8), reinterpret_cast<const float2 *>(twid),
+                       reinterpret_cast<const float2 *>(tw4k), G);
+    LLZ_LAUNCH_CHECK("k_fir_ols8k_f32");
+    return LLZ_OK;
+}
+
+extern "C" int llzs_fir_ols8k_f32(const float *in, float *out, const float *hist, const float *hfreq8, const float *twid,
+                                  const float *tw4k, int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream)
+{
+    if (!in || !out || !hfreq8 || !twid || !tw4k || channels <= 0 || n <= 0 || in_pitch < n || out_pitch < n ||
+        flt_len < 2 || flt_len > LLZS_OLS8K_MAX_TAPS) {
+        llzs_set_error("fir_ols8k_f32: bad arguments (flt_len=%d, 2..%d)", flt_len, LLZS_OLS8K_MAX_TAPS);
+        return LLZ_ERR_ARG;
+    }
+#define LLZ_OLS8K_GO(O) return ols8k_launch<O>(in, out, hist, hfreq8, twid, tw4k, channels, n, in_pitch, out_pitch, flt_len, stream)
+    if (flt_len <= 1537) LLZ_OLS8K_GO(1536);
+    if (flt_len <= 2049) LLZ_OLS8K_GO(2048);
+    if (flt_len <= 2561) LLZ_OLS8K_GO(2560);
+    if (flt_len <= 3073) LLZ_OLS8K_GO(3072);
+    if (flt_len <= 3585) LLZ_OLS8K_GO(3584);
+    LLZ_OLS8K_GO(4096);
+#undef LLZ_OLS8K_GO
 }

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import (BAD_HANDLE, BLACKMAN, FIR_ALGO_AUTO, FIR_ALGO_OVERLAP_SAVE, FIR_ALGO_OVERLAP_SAVE_2048, FIR_ALGO_OVERLAP_SAVE_4096, FIR_ALGO_TIME,  # noqa: F401
+from .capi import (BAD_HANDLE, BLACKMAN, FIR_ALGO_AUTO, FIR_ALGO_OVERLAP_SAVE, FIR_ALGO_OVERLAP_SAVE_2048, FIR_ALGO_OVERLAP_SAVE_4096, FIR_ALGO_OVERLAP_SAVE_8192, FIR_ALGO_TIME,  # noqa: F401
                    FIR_ALGO_TIME_MFMA, HAMMING, KAISER,
                    PCM_F32, PCM_I16, PCM_I16_FAST, LlzError, check, check_handle)
 

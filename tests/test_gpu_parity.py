@@ -1165,6 +1165,35 @@ def test_fir_ols4096_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
         g.close()
 
 
+@pytest.mark.parametrize("taps_n,channels,n", [(3073, 2, 10240 * 3 + 5), (3073, 70, 10240 * 2), (2561, 3, 11264 * 2 + 100), (2049, 5, 12288 * 3),
+                                               (1537, 4, 13312 * 2 + 1), (4097, 2, 8192 * 3 + 9), (3585, 9, 9216 * 4), (3000, 300, 10240 * 3),
+                                               (2, 3, 20000), (1000, 7, 5000), (4097, 33, 8192 * 5 + 4000), (3073, 1100, 10240 * 2 + 17)])
+def test_fir_ols8192_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
+    """filters of up to 4097 taps on the 8192-point overlap-save (k_fir_ols8k_f32: a PAIR of waves per pair of blocks, the halves
+    of the radix-2 step swapped through LDS under the pair's own round counters; overlap 1536 ... 4096 by tap count): two frames
+    (the second starts from the first's history), ragged lengths, blocks that end past the frame, more pairs of waves than
+    segments and fewer.  Large batches are checked on a spread of 24 channels (the oracle is one core)."""
+    taps = oracle.fir_design(po.LPF, taps_n, 0.2, 0.0, po.KAISER)
+    x = oracle.synth_f32(channels, 2 * n, seed=taps_n)
+    sel = np.arange(channels) if channels <= 40 else np.unique(np.linspace(0, channels - 1, 24).astype(int))
+    t64 = taps.astype(np.float32).astype(np.float64)
+    ref = oracle.fir_batch_f32(np.ascontiguousarray(x[sel]), t64)
+    f = filters.FirFilterMC(channels, n, taps, algo=filters.FIR_ALGO_OVERLAP_SAVE_8192)
+    assert f.algo == filters.FIR_ALGO_OVERLAP_SAVE_8192
+    outs = []
+    for o in (0, n):
+        xd = torch.from_numpy(np.ascontiguousarray(x[:, o:o + n])).to(dev)
+        yd = torch.empty_like(xd)
+        f.filter(xd, yd)
+        outs.append(yd.cpu().numpy()[sel])
+    tail = torch.empty(channels, taps_n - 1, dtype=torch.float32, device=dev)
+    f.flush(tail)
+    f.close()
+    rms_check(np.concatenate(outs, axis=1), ref, f"fir ols8192 taps={taps_n}")
+    full = oracle.fir_batch_f32(np.concatenate([x[sel], np.zeros((len(sel), taps_n - 1), np.float32)], axis=1), t64)
+    assert np.sqrt(np.mean((tail.cpu().numpy()[sel] - full[:, 2 * n:]) ** 2)) <= TOL
+
+
 # ------------------------------------------------------------------------------------------------ overlap-save, chain form
 def test_fir_ols_small_and_ragged_batches(dev, oracle):
     """the 1024-point overlap-save kernel on batches far smaller than the headline (test_fir_ols_headline_shape_full_length
