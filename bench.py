@@ -155,7 +155,7 @@ def main():
     # and outside every guarded block: setup collectives either work on all ranks or end the job
     tables = {"fir257": taps}
     if not args.no_also:
-        for t in (513, 1025, 2049):
+        for t in (513, 1025, 2049, 3073):
             d = filters.fir_design("lpf", t, 0.1, 0.0, filters.KAISER) if rank == 0 else np.zeros(t)
             tables[f"fir{t}"] = shard.broadcast_table(d, src=0, device=comm_dev)
         mat = None
@@ -298,15 +298,15 @@ def main():
                time_local=time_local, orc=(orc if rank == 0 else None), tables=tables)
 
     # long filters on the same batch (weak scaling like the headline): 513 taps on the 2048-point overlap-save, 1025 and
-    # 2049 taps on the 4096-point one (the library's own choice)
-    LONG = (513, 1025, 2049)
+    # 2049 taps on the 4096-point one, 3073 on the 8192-point one (the library's own choice)
+    LONG = (513, 1025, 2049, 3073)
 
     def long_fir():
         res = {}
         for long_taps in LONG:
             lf = filters.FirFilterMC(channels, n, tables[f"fir{long_taps}"], stream=stream)
             lms = time_local(lambda: lf.filter(x, y), 3)
-            algo = {4: "overlap-save-2048", 5: "overlap-save-4096"}.get(lf.algo, str(lf.algo))
+            algo = {4: "overlap-save-2048", 5: "overlap-save-4096", 6: "overlap-save-8192"}.get(lf.algo, str(lf.algo))
             lf.close()
             res[f"fir_{long_taps}taps_{channels}ch_per_gpu"] = (lms, lambda ms, algo=algo: {
                 "Msamples_s": channels * n * world / ms / 1e3, "GBs_per_gpu": BYTES_PER_SAMPLE * channels * n / ms / 1e6,

@@ -2,6 +2,7 @@
 //   k_fir_ols_chain_f32      up to 257 taps   1024-point transforms, a half-wave per job (described first, below)
 //   k_fir_ols2k_chain_f32<O> up to 1025 taps  2048-point transforms, a whole wave per job (one radix-2 step over the half-waves)
 //   k_fir_ols4k_f32<O>       up to 3073 taps  4096-point transforms, a whole wave per job (two radix-2 steps)
+//   k_fir_ols8k_f32<O>       up to 4097 taps  8192-point transforms, a pair of waves per job (one more radix-2 step, across the pair)
 //
 // New functionality relative to the reference (llz_fir.c is time-domain only); its end-to-end
 // oracle is the time-domain llz_fir_filter (llz_fir.c:547-584), its FFT stage follows the sign/scale
@@ -631,7 +632,7 @@ k_fir_ols4k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 1538 .. 3073 taps: 8192-point transforms on a PAIR of waves.  With 3072 samples of overlap a 4096-point block yields 1024
+// 2 .. 4097 taps (the library's choice from 2050 on): 8192-point transforms on a PAIR of waves.  With 3072 samples of overlap a 4096-point block yields 1024
 // outputs (25 % of the transform), an 8192-point block 5120 (62.5 %) at 13/12 of the work per point.
 //     X[2k] = FFT_4096( a[n] + a[n+4096] )  -> wave 0 of the pair,     X[2k+1] = FFT_4096( (a[n] - a[n+4096]) W_8192^n )  -> wave 1,
 // each wave then runs the 4096-point problem of k_fir_ols4k_f32 (radix-2 step + two 2048-point problems); back:
@@ -648,6 +649,20 @@ k_fir_ols4k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
 // (64 complex values per lane leave no registers for a prefetch).  Both waves of a pair run the same loop bounds, hence the
 // same number of rounds; the waits are bounded (a pair out of step would produce wrong samples, which the tests see, never
 // a hang).  LDS: W_1024^(ab) 8 KB, W_4096^n 16 KB (W_2048^n = every other entry), spectrum 8 x 8 KB, buffers 66 KB = 154 KB.
+// O8K_TRACE (a measurement build only): shader-clock time of each phase of a job, summed per wave (tools/trace_ols8k.py)
+#ifdef O8K_TRACE
+__device__ unsigned long long o8k_trace_buf[2048 * 8];
+#define O8K_T0() unsigned long long o8_t = __builtin_readcyclecounter(), o8_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define O8K_MARK(i) do { const unsigned long long now = __builtin_readcyclecounter(); o8_acc[i] += now - o8_t; o8_t = now; } while (0)
+#define O8K_PIN(x) asm volatile("s_nop 0" ::"v"(x))
+#define O8K_DUMP() do { if ((threadIdx.x & 63) == 0) { const unsigned wv_ = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 2047u; \
+    for (int i = 0; i < 8; i++) o8k_trace_buf[wv_ * 8 + i] = o8_acc[i]; } } while (0)
+#else
+#define O8K_T0() do { } while (0)
+#define O8K_MARK(i) do { } while (0)
+#define O8K_PIN(x) do { } while (0)
+#define O8K_DUMP() do { } while (0)
+#endif
 struct w128_tab {
     float c[64], s[64];
 };
@@ -682,16 +697,28 @@ constexpr w128_tab o8k_make_w128()
 __device__ constexpr w128_tab kW128 = o8k_make_w128();          // W_128^j = c[j] - i s[j]
 
 constexpr int O8K_WAVES = 8, O8K_THREADS = 64 * O8K_WAVES, O8K_PAIRS = O8K_WAVES / 2;
-constexpr int O8K_SPIN_LIMIT = 1 << 18;
+#ifndef O8K_SPIN
+#define O8K_SPIN (1 << 18)                 // (A/B builds: -DO8K_SPIN=0 takes the waiting out, with wrong samples)
+#endif
+constexpr int O8K_SPIN_LIMIT = O8K_SPIN;
 
 typedef __attribute__((address_space(3))) volatile int *o8k_flag_p;          // 32-bit LDS addresses: generic pointers in the
 typedef float o8k_f2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) o8k_f2 *o8k_box_p;                 // struct would become 64-bit flat accesses
 struct o8k_pair {
     o8k_flag_p my_free, my_sent, pt_free, pt_sent;             // round counters, one writer each
-    o8k_box_p my_box, pt_box;                                   // [16][64] (+ lane): the wave's own transpose buffers
+    o8k_box_p my_box, pt_box;                                   // [16][64]: the wave's own transpose buffers (wave-uniform bases)
     int k;
 };
+// the lane id, formed afresh where it is needed: what the phases of a job derive from it (buffer addresses, the lane's twiddle)
+// then lives inside that phase only -- carried across the 4096-point problem, which needs every register there is, each of
+// them is a spill
+__device__ __forceinline__ int o8k_lane()
+{
+    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+}
 __device__ __forceinline__ void o8k_signal(o8k_flag_p flag, int k)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // what this wave wrote / read before is done
@@ -707,18 +734,20 @@ __device__ __forceinline__ void o8k_wait(o8k_flag_p flag, int k)
 template <int OFF>
 __device__ __forceinline__ void o8k_swap(cf (&a)[64], o8k_pair &ps)
 {
+    const int lane = o8k_lane();
+    const o8k_box_p mine = ps.my_box + lane, theirs = ps.pt_box + lane;
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         ps.k++;
         o8k_signal(ps.my_free, ps.k);                           // my buffers may take round k
         o8k_wait(ps.pt_free, ps.k);
 #pragma unroll
-        for (int i = 0; i < 16; i++) ps.pt_box[64 * i] = (o8k_f2){a[OFF + 16 * r + i].x, a[OFF + 16 * r + i].y};
+        for (int i = 0; i < 16; i++) theirs[64 * i] = (o8k_f2){a[OFF + 16 * r + i].x, a[OFF + 16 * r + i].y};
         o8k_signal(ps.my_sent, ps.k);
         o8k_wait(ps.pt_sent, ps.k);
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const o8k_f2 t = ps.my_box[64 * i];
+            const o8k_f2 t = mine[64 * i];
             a[OFF + 16 * r + i] = cf{t[0], t[1]};
         }
     }
@@ -764,6 +793,7 @@ k_fir_ols8k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
     float2 *s_h = s_w4 + 2048;                                  // [8][1024]
     float *s_buf = reinterpret_cast<float *>(s_h + 8192);       // [16][OLS_XBUF]
     int *s_flag = reinterpret_cast<int *>(s_buf + 2 * O8K_WAVES * OLS_XBUF);                      // [8][2]
+    float2 *s_wl = reinterpret_cast<float2 *>(s_flag + 2 * O8K_WAVES);                            // [64] W_8192^lane
     for (int i = threadIdx.x; i < 1024; i += O8K_THREADS) {
         s_tw[i] = twid[i];
         s_w4[i] = tw4k[i];
@@ -772,28 +802,23 @@ k_fir_ols8k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
         for (int j = 0; j < 8; j++) s_h[1024 * j + i] = hfreq8[1024 * j + i];
     }
     if (threadIdx.x < 2 * O8K_WAVES) s_flag[threadIdx.x] = 0;
+    if (threadIdx.x < 64) {
+        float sn, cs;
+        sincospif((float)threadIdx.x * (1.0f / 4096.0f), &sn, &cs);
+        s_wl[threadIdx.x] = make_float2(cs, -sn);
+    }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int w = wave & 1, pair = wave >> 1;
-    const int half = lane >> 5, l5 = lane & 31;
-    float *buf = s_buf + (wave * 2 + half) * OLS_XBUF;
     o8k_pair ps;
     ps.my_free = (o8k_flag_p)(s_flag + 2 * wave);
     ps.my_sent = (o8k_flag_p)(s_flag + 2 * wave + 1);
     ps.pt_free = (o8k_flag_p)(s_flag + 2 * (wave ^ 1));
     ps.pt_sent = (o8k_flag_p)(s_flag + 2 * (wave ^ 1) + 1);
-    ps.my_box = (o8k_box_p)(reinterpret_cast<o8k_f2 *>(s_buf + (wave * 2) * OLS_XBUF) + lane);
-    ps.pt_box = (o8k_box_p)(reinterpret_cast<o8k_f2 *>(s_buf + ((wave ^ 1) * 2) * OLS_XBUF) + lane);
+    ps.my_box = (o8k_box_p)(reinterpret_cast<o8k_f2 *>(s_buf + (wave * 2) * OLS_XBUF));
+    ps.pt_box = (o8k_box_p)(reinterpret_cast<o8k_f2 *>(s_buf + ((wave ^ 1) * 2) * OLS_XBUF));
     ps.k = 0;
-    const float2 *h_e = s_h + (4 * half + w) * 1024, *h_o = s_h + (4 * half + 2 + w) * 1024;
-    // W_8192^lane, times W_128^(32 w) = (-i)^w for the positions this wave requests
-    cf wl;
-    {
-        float sn, cs;
-        sincospif((float)lane * (1.0f / 4096.0f), &sn, &cs);
-        wl = cf{cs, -sn};
-    }
+    O8K_T0();
     const long pairs_total = (long)gridDim.x * O8K_PAIRS;
     const int n = G.n;
     const int pos0 = 32 * w;
@@ -810,10 +835,11 @@ k_fir_ols8k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
             const int s = (j0 + jj) * JOB;
             // block A (real parts) = [s - O, s + V), block B (imaginary parts) = [s + V - O, s + 2V): B's first O samples are
             // A's last O, the same addresses (requested again: cache hits, the other wave may hold them)
+            O8K_MARK(6);                                                 // loop overhead
             cf a[64];
             const bool whole = s >= O && s + JOB <= n;
             if (whole) {
-                const float *ra = row + s - O + 64 * pos0 + lane, *rb = ra + V;
+                const float *ra = row + s - O + 64 * pos0 + o8k_lane(), *rb = ra + V;
 #pragma unroll
                 for (int j = 0; j < 32; j++) {
                     a[j].x = __builtin_nontemporal_load(&ra[64 * j]);
@@ -825,6 +851,7 @@ k_fir_ols8k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
                     a[32 + j].y = __builtin_nontemporal_load(&rb[64 * (j + 64)]);
                 }
             } else {
+                const int lane = o8k_lane();
 #pragma unroll
                 for (int j = 0; j < 64; j++) {
                     const int pos = pos0 + (j < 32 ? j : j + 32);
@@ -837,13 +864,15 @@ k_fir_ols8k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
                     a[j].y = ib < n ? xb : 0.f;
                 }
             }
+            O8K_PIN(a[0].x); O8K_PIN(a[63].y); O8K_PIN(a[31].y); O8K_PIN(a[32].x);
+            O8K_MARK(0);                                                 // requests, awaited
             // ---- radix-2 step down over the wave's 32 positions.  Wave 1 works with the halves of its arrays exchanged (slot j =
             // position j + 32 mod 64), so that BOTH waves keep slots 0..31 and swap slots 32..63 (one code path, no register
             // shuffles where two would join): the 4096-point problem is indifferent to it -- exchanged input halves flip the
             // sign of its odd-bin branch, which exchanges the output halves the same way.
             // (the twiddles are formed where they are used: hoisted out of the job loop they would be 192 more live registers)
-            cf wv = w ? cf{wl.y, -wl.x} : wl;
-            asm volatile("" : "+v"(wv.x), "+v"(wv.y));
+            const float2 wd = s_wl[o8k_lane()];                          // W_8192^lane, times W_128^(32 w) = (-i)^w
+            const cf wv = w ? cf{wd.y, -wd.x} : cf{wd.x, wd.y};
 #pragma unroll
             for (int j = 0; j < 32; j++) {
                 const cf sm = cadd(a[j], a[32 + j]), df = csub(a[j], a[32 + j]);
@@ -852,13 +881,23 @@ k_fir_ols8k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
                 a[j] = w ? dt : sm;                                      // kept: wave 0 its sums (positions 0..31), wave 1 its
                 a[32 + j] = w ? sm : dt;                                 // differences (positions 32..63); the other 32 go over
             }
+            O8K_PIN(a[0].x); O8K_PIN(a[63].y);
+            O8K_MARK(1);                                                 // step down
             o8k_swap<32>(a, ps);
-            ols4k_core(a, buf, s_tw, s_w4, h_e, h_o, l5, lane);
+            O8K_PIN(a[32].x); O8K_PIN(a[63].y);
+            O8K_MARK(2);                                                 // swap
+            {
+                const int ln = o8k_lane(), hf = ln >> 5;
+                ols4k_core(a, s_buf + (wave * 2 + hf) * OLS_XBUF, s_tw, s_w4, s_h + (4 * hf + w) * 1024, s_h + (4 * hf + 2 + w) * 1024,
+                           ln & 31, ln);
+            }
+            O8K_PIN(a[0].x); O8K_PIN(a[63].y); O8K_PIN(a[32].x);
+            O8K_MARK(3);                                                 // the 4096-point problem
             // ---- back: wave 1 turns its results by W_8192^-n (slot j = position j + 32 mod 64), gives the 32 of positions 0..31
             // for wave 0's E' of positions 32..63, and position 32 w + j gets E' + q, position 32 w + j + 64 gets E' - q
             if (w) {
-                cf wu = wl;
-                asm volatile("" : "+v"(wu.x), "+v"(wu.y));
+                const float2 wr = s_wl[o8k_lane()];
+                const cf wu = cf{wr.x, wr.y};
 #pragma unroll
                 for (int p = 0; p < 64; p++) {
                     const cf t = cmul<false>(cf{kW128.c[p ^ 32], -kW128.s[p ^ 32]}, wu);
@@ -866,7 +905,10 @@ k_fir_ols8k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
                 }
             }
             o8k_swap<32>(a, ps);
+            O8K_PIN(a[32].x); O8K_PIN(a[63].y); O8K_PIN(a[0].x);
+            O8K_MARK(4);                                                 // turn + swap
             const float sg = w ? -1.f : 1.f;                             // wave 0: a[j] = E', a[32 + j] = q; wave 1: the reverse
+            const int lane = o8k_lane();
             const bool all_out = s + JOB <= n;
             const int jmin = PO - pos0;                                  // positions below PO are overlap
             float *oa0 = orow + s + 64 * (pos0 - PO) + lane;
@@ -891,8 +933,13 @@ k_fir_ols8k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
                     if (ob + 4096 < n) orow[ob + 4096] = y1.y;
                 }
             }
+            O8K_MARK(5);                                                 // outputs formed, stores issued
+#ifdef O8K_TRACE
+            o8_acc[7]++;
+#endif
         }
     }
+    O8K_DUMP();
 }
 
 } // namespace
@@ -1075,7 +1122,7 @@ static int ols8k_launch(const float *in, float *out, const float *hist, const fl
     G.out_pitch = out_pitch;
     G.jobs_per_channel = (n + JOB - 1) / JOB;
     const size_t lds_bytes = (1024 + 2048 + 8192) * sizeof(float2) + (size_t)O8K_WAVES * 2 * OLS_XBUF * sizeof(float) +
-                             2 * O8K_WAVES * sizeof(int);
+                             2 * O8K_WAVES * sizeof(int) + 64 * sizeof(float2);
     const long max_blocks = 256L;                               // one 8-wave workgroup per CU
     const long slots = max_blocks * O8K_PAIRS;
     int seg_len = OLS_SEG;
@@ -1118,3 +1165,12 @@ extern "C" int llzs_fir_ols8k_f32(const float *in, float *out, const float *hist
     LLZ_OLS8K_GO(4096);
 #undef LLZ_OLS8K_GO
 }
+
+#ifdef O8K_TRACE
+extern "C" int llzs_o8k_trace_read(unsigned long long *dst, int count)
+{
+    LLZ_HIP_CHECK(hipDeviceSynchronize());
+    LLZ_HIP_CHECK(hipMemcpyFromSymbol(dst, HIP_SYMBOL(o8k_trace_buf), sizeof(unsigned long long) * (size_t)count));
+    return LLZ_OK;
+}
+#endif
