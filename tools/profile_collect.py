@@ -197,6 +197,7 @@ ALGO = [   # (kernel name part, occurrence in dispatch order, workload, algorith
     ("k_mdct4_q15", 1, "fixed-point MDCT inverse, N = 2048 x 65536 frames", 6 * 2048 * 65536),
     ("k_mdct_reg_f32", 0, "MDCT frames analysis, F = 256, 1024 ch x 1024 frames (float32 in and out)", 8 * 256 * 1024 * 1024),
     ("k_mdct_reg_f32", 1, "MDCT frames synthesis in runs of 16 segments, same shape", 8 * 256 * 1024 * 1024),
+    ("k_fir_ols8k_f32", 0, "FIR 3073 taps, 8192-point overlap-save on pairs of waves, 2048 ch x 2^20", 8 * 2048 * (1 << 20)),
 ]
 
 
@@ -221,7 +222,7 @@ def sha_of(files):
 SRC = {"k_iir": ["iir.hip"], "k_fir_mfma_bf16x3": ["fir_mfma.hip"], "k_fir_mfma_i16": ["fir_mfma.hip"],
        "k_fir_mfma_i8x": ["fir_mfma_i8.hip", "screen_i8.hpp"], "k_resample_mfma": ["resample_mfma.hip"],
        "k_resample_i8d": ["resample_i8.hip", "screen_i8.hpp"], "k_mdct4_q15": ["mdct_q15.hip", "fft_core.hpp"],
-       "k_mdct_reg_f32": ["fft.hip", "fft_core.hpp"]}
+       "k_mdct_reg_f32": ["fft.hip", "fft_core.hpp"], "k_fir_ols8k": ["fir_ols.hip", "fft32.hpp"]}
 if os.path.isdir(os.path.join(src, "set_fetch")):
     sf, sw, ssq = counters("set_fetch"), counters("set_write"), counters("set_sq")
     kernels = {}

@@ -140,5 +140,13 @@ elif what == "traffic_set":
     go(lambda: mf.synthesis(Xf, xf))
     mf.close()
     del xf, Xf
+    ch, n = 2048, 1 << 20                                           # long FIR: 3073 taps on the 8192-point pairs-of-waves kernel
+    x = torch.empty(ch, n, dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    filters.synth_f32(x, 1)
+    lf = filters.FirFilterMC(ch, n, filters.fir_design("lpf", 3073, 0.1, 0.0, filters.KAISER))
+    go(lambda: lf.filter(x, y))
+    lf.close()
+    del x, y
 torch.cuda.synchronize()
 print("done", what)
