@@ -1453,7 +1453,7 @@ def _virtual(n):
 
 @pytest.mark.parametrize("n_shards", [2, 8])
 @pytest.mark.parametrize("algo,taps_n", [(filters.FIR_ALGO_OVERLAP_SAVE, 257), (filters.FIR_ALGO_TIME, 63),
-                                         (filters.FIR_ALGO_OVERLAP_SAVE_2048, 400)])
+                                         (filters.FIR_ALGO_OVERLAP_SAVE_2048, 400), (filters.FIR_ALGO_OVERLAP_SAVE_8192, 2100)])
 def test_sharded_fir_equals_unsharded(dev, oracle, n_shards, algo, taps_n):
     """the C ABI's sharded FIR handle (contiguous channel ranges, one stream per shard, tables broadcast from shard 0) gives
     bit-identical output to one unsharded handle, over two streamed frames and the flush"""
