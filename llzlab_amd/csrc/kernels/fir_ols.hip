@@ -482,6 +482,15 @@ k_fir_ols2k_chain_f32(const float *__restrict__ in, float *__restrict__ out, con
 //
 // The spectrum is split four ways: plane j = 2 half + sub holds H[4m + j] / 4096 (sub 0 = the even-bin problem E, 1 = the
 // odd-bin problem O; inside a problem the lower half-wave has its even bins, the upper its odd bins).
+// the lane id, formed afresh where it is needed: what the phases of a job derive from it (buffer addresses, the lane's twiddle)
+// then lives inside that phase only -- carried across the 4096-point problem, which needs every register there is, each of
+// them is a spill
+__device__ __forceinline__ int o8k_lane()
+{
+    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+}
 constexpr int O4K_WAVES = 8, O4K_THREADS = 64 * O4K_WAVES;
 
 // one 2048-point problem of the wave: v[p] = row 2p + h (p < 32) in, y[p] out (same ownership); see k_fir_ols2k_chain_f32
@@ -538,12 +547,9 @@ k_fir_ols4k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
         for (int j = 0; j < 4; j++) s_h[1024 * j + i] = hfreq4[1024 * j + i];
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int half = lane >> 5, l5 = lane & 31;
-    float *buf = reinterpret_cast<float *>(s_h + 4096) + (wave * 2 + half) * OLS_XBUF;
+    float *s_buf = reinterpret_cast<float *>(s_h + 4096);
     const long waves_total = (long)gridDim.x * O4K_WAVES;
-    const int rowoff = 32 * half + l5;
     const int n = G.n;
 
     for (long seg = (long)blockIdx.x * O4K_WAVES + wave; seg < G.total_segs; seg += waves_total) {
@@ -561,6 +567,8 @@ k_fir_ols4k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
             // Block B's first O samples are block A's last O.
             cf v[64];
             const bool whole = s >= O && s + JOB <= n;
+            {
+            const int rowoff = o8k_lane();
             if (whole) {
 #pragma unroll
                 for (int i = 0; i < PO; i++) v[i].x = row[s - O + 64 * i + rowoff];
@@ -584,8 +592,11 @@ k_fir_ols4k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
                     v[i].y = ib < n ? xb : 0.f;
                 }
             }
+            }
 #pragma unroll
             for (int i = 0; i < PO; i++) v[i].y = v[i + PV].x;
+            const int rowoff = o8k_lane(), half = rowoff >> 5, l5 = rowoff & 31;
+            float *buf = s_buf + (wave * 2 + half) * OLS_XBUF;
             // ---- radix-2 step down: positions p and p + 32 are 2048 samples apart
             cf e[32], o[32];
 #pragma unroll
@@ -710,15 +721,6 @@ struct o8k_pair {
     o8k_box_p my_box, pt_box;                                   // [16][64]: the wave's own transpose buffers (wave-uniform bases)
     int k;
 };
-// the lane id, formed afresh where it is needed: what the phases of a job derive from it (buffer addresses, the lane's twiddle)
-// then lives inside that phase only -- carried across the 4096-point problem, which needs every register there is, each of
-// them is a spill
-__device__ __forceinline__ int o8k_lane()
-{
-    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(l));
-    return l;
-}
 __device__ __forceinline__ void o8k_signal(o8k_flag_p flag, int k)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // what this wave wrote / read before is done
