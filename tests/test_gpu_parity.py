@@ -1169,7 +1169,9 @@ def test_fir_ols4096_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
 
 @pytest.mark.parametrize("taps_n,channels,n", [(3073, 2, 10240 * 3 + 5), (3073, 70, 10240 * 2), (2561, 3, 11264 * 2 + 100), (2049, 5, 12288 * 3),
                                                (1537, 4, 13312 * 2 + 1), (4097, 2, 8192 * 3 + 9), (3585, 9, 9216 * 4), (3000, 300, 10240 * 3),
-                                               (2, 3, 20000), (1000, 7, 5000), (4097, 33, 8192 * 5 + 4000), (3073, 1100, 10240 * 2 + 17)])
+                                               (2, 3, 20000), (1000, 7, 5000), (4097, 33, 8192 * 5 + 4000), (3073, 1100, 10240 * 2 + 17),
+                                               # frames shorter than the overlap (the history supplies most of a block), one channel
+                                               (3073, 3, 1700), (2100, 1, 5000), (4097, 2, 2500)])
 def test_fir_ols8192_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
     """filters of up to 4097 taps on the 8192-point overlap-save (k_fir_ols8k_f32: a PAIR of waves per pair of blocks, the halves
     of the radix-2 step swapped through LDS under the pair's own round counters; overlap 1536 ... 4096 by tap count): two frames
