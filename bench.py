@@ -297,8 +297,8 @@ def main():
     ctx = dict(torch=torch, filters=filters, capi=capi, shard=shard, dev=dev, stream=stream, rank=rank, world=world,
                time_local=time_local, orc=(orc if rank == 0 else None), tables=tables)
 
-    # long filters on the same batch (weak scaling like the headline): 513 taps on the 2048-point overlap-save, 1025 and
-    # 2049 taps on the 4096-point one, 3073 on the 8192-point one (the library's own choice)
+    # long filters on the same batch (weak scaling like the headline): 513 taps on the 2048-point overlap-save, 1025 on the
+    # 4096-point one, 2049 and 3073 on the 8192-point one (the library's own choice)
     LONG = (513, 1025, 2049, 3073)
 
     def long_fir():

@@ -62,7 +62,7 @@ double llz_conv(const double *x, const double *h, int h_len);
 
 enum {
     LLZ_FIR_ALGO_AUTO = 0,       /* time domain up to 32 taps, overlap-save for 33..257 (1024-point), 258..513
-                                  * (2048-point), 514..2049 (4096-point) and 2050..4097 (8192-point), matrix-core time
+                                  * (2048-point), 514..1025 (4096-point) and 1026..4097 (8192-point), matrix-core time
                                   * domain beyond */
     LLZ_FIR_ALGO_TIME = 1,       /* direct form, taps broadcast, input window staged in LDS */
     LLZ_FIR_ALGO_OVERLAP_SAVE = 2, /* 1024-point in-LDS FFT overlap-save, flt_len <= 257 */

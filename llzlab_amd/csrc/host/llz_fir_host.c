@@ -375,9 +375,9 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
          * of overlap); 4096 points 8.0 / 7.9 / 8.3 / 9.6 / 11.3 / 14.7 / 19.5 ms with 512 / 768 / 1024 / 1536 / 2048 / 2560 /
          * 3072 of overlap */
         else if (flt_len <= 513) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_2048;
-        /* 8192 points on pairs of waves, same batch: 9.9 / 11.7 / 11.7 / 12.3 / 14.4 ms with 1536 / 2048 / 2560 / 3072 / 4096 of
-         * overlap -> from 2050 taps on (4096 points: 14.4 and 19.2 ms there), and up to 4097 taps */
-        else if (flt_len <= 2049) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_4096;
+        /* 8192 points on pairs of waves, same batch: 9.1 / 10.9 / 10.9 / 11.3 / 13.8 ms with 1536 / 2304 / 2560 / 3072 / 4096 of
+         * overlap -> from 1026 taps on (4096 points: 9.4 / 11.2 / 14.4 / 19.2 ms with 1536 / 2048 / 2560 / 3072), up to 4097 taps */
+        else if (flt_len <= 1025) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_4096;
         else if (flt_len <= LLZS_OLS8K_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_8192;
         else algo = llzs_fir_mfma_f32_fits(flt_len, 1) ? LLZ_FIR_ALGO_TIME_MFMA : LLZ_FIR_ALGO_TIME;
     }

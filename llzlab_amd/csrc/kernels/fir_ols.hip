@@ -811,14 +811,22 @@ k_fir_ols8k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
     }
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int w = wave & 1, pair = wave >> 1;
+    // the pair = waves p and p + 4 of the workgroup: the two waves of ONE SIMD.  Whenever one of them waits for the other, the
+    // other is the wave its SIMD runs, so the waits cost no issue slots anybody wanted; with neighbouring waves (two SIMDs)
+    // a waiting wave leaves its SIMD to a wave of another pair, which may be waiting as well (12.23 against 11.42 ms at 3073
+    // taps, same box: -DO8K_CROSS_SIMD)
+#ifdef O8K_CROSS_SIMD
+    const int w = wave & 1, pair = wave >> 1, partner = wave ^ 1;
+#else
+    const int w = wave >> 2, pair = wave & 3, partner = wave ^ 4;
+#endif
     o8k_pair ps;
     ps.my_free = (o8k_flag_p)(s_flag + 2 * wave);
     ps.my_sent = (o8k_flag_p)(s_flag + 2 * wave + 1);
-    ps.pt_free = (o8k_flag_p)(s_flag + 2 * (wave ^ 1));
-    ps.pt_sent = (o8k_flag_p)(s_flag + 2 * (wave ^ 1) + 1);
+    ps.pt_free = (o8k_flag_p)(s_flag + 2 * partner);
+    ps.pt_sent = (o8k_flag_p)(s_flag + 2 * partner + 1);
     ps.my_box = (o8k_box_p)(reinterpret_cast<o8k_f2 *>(s_buf + (wave * 2) * OLS_XBUF));
-    ps.pt_box = (o8k_box_p)(reinterpret_cast<o8k_f2 *>(s_buf + ((wave ^ 1) * 2) * OLS_XBUF));
+    ps.pt_box = (o8k_box_p)(reinterpret_cast<o8k_f2 *>(s_buf + (partner * 2) * OLS_XBUF));
     ps.k = 0;
     O8K_T0();
     const long pairs_total = (long)gridDim.x * O8K_PAIRS;
@@ -1160,7 +1168,9 @@ extern "C" int llzs_fir_ols8k_f32(const float *in, float *out, const float *hist
     }
 #define LLZ_OLS8K_GO(O) return ols8k_launch<O>(in, out, hist, hfreq8, twid, tw4k, channels, n, in_pitch, out_pitch, flt_len, stream)
     if (flt_len <= 1537) LLZ_OLS8K_GO(1536);
-    if (flt_len <= 2049) LLZ_OLS8K_GO(2048);
+    // (a job costs 27 .. 31 us whatever the overlap between 2048 and 2560 -- 10.96 / 10.92 / 10.90 ms for 2048 / 2304 / 2560 on
+    // the headline batch -- so the ladder is coarse there)
+    if (flt_len <= 2305) LLZ_OLS8K_GO(2304);
     if (flt_len <= 2561) LLZ_OLS8K_GO(2560);
     if (flt_len <= 3073) LLZ_OLS8K_GO(3072);
     if (flt_len <= 3585) LLZ_OLS8K_GO(3584);

@@ -150,8 +150,8 @@ def test_fir_mc_host_pointers_and_errors(dev, oracle):
     assert filters.FirFilterMC(2, 64, np.ones(63)).algo == filters.FIR_ALGO_OVERLAP_SAVE      # AUTO: 33..257 taps
     assert filters.FirFilterMC(2, 64, np.ones(32)).algo == filters.FIR_ALGO_TIME
     assert filters.FirFilterMC(2, 64, np.ones(300)).algo == filters.FIR_ALGO_OVERLAP_SAVE_2048   # 258..513
-    assert filters.FirFilterMC(2, 64, np.ones(2000)).algo == filters.FIR_ALGO_OVERLAP_SAVE_4096  # 514..2049
-    assert filters.FirFilterMC(2, 64, np.ones(3000)).algo == filters.FIR_ALGO_OVERLAP_SAVE_8192  # 2050..4097
+    assert filters.FirFilterMC(2, 64, np.ones(1000)).algo == filters.FIR_ALGO_OVERLAP_SAVE_4096  # 514..1025
+    assert filters.FirFilterMC(2, 64, np.ones(3000)).algo == filters.FIR_ALGO_OVERLAP_SAVE_8192  # 1026..4097
     assert filters.FirFilterMC(2, 64, np.ones(4098)).algo in (filters.FIR_ALGO_TIME_MFMA, filters.FIR_ALGO_TIME)   # time domain beyond
     assert filters.FirFilterMC(2, 64, np.ones(300), algo=filters.FIR_ALGO_TIME_MFMA).algo == filters.FIR_ALGO_TIME_MFMA
 
@@ -1162,8 +1162,8 @@ def test_fir_ols4096_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
                                 taps.astype(np.float32).astype(np.float64))
     assert np.sqrt(np.mean((tail.cpu().numpy() - full[:, 2 * n:]) ** 2)) <= TOL
     if taps_n > 513:
-        g = filters.FirFilterMC(channels, n, taps)                 # AUTO: 514..2049 taps here, the 8192-point form beyond
-        assert g.algo == (filters.FIR_ALGO_OVERLAP_SAVE_4096 if taps_n <= 2049 else filters.FIR_ALGO_OVERLAP_SAVE_8192)
+        g = filters.FirFilterMC(channels, n, taps)                 # AUTO: 514..1025 taps here, the 8192-point form beyond
+        assert g.algo == (filters.FIR_ALGO_OVERLAP_SAVE_4096 if taps_n <= 1025 else filters.FIR_ALGO_OVERLAP_SAVE_8192)
         g.close()
 
 
