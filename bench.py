@@ -305,7 +305,7 @@ def main():
         res = {}
         for long_taps in LONG:
             lf = filters.FirFilterMC(channels, n, tables[f"fir{long_taps}"], stream=stream)
-            lms = time_local(lambda: lf.filter(x, y), 3)
+            lms = time_local(lambda: lf.filter(x, y), 4, warm=2)
             algo = {4: "overlap-save-2048", 5: "overlap-save-4096", 6: "overlap-save-8192"}.get(lf.algo, str(lf.algo))
             lf.close()
             res[f"fir_{long_taps}taps_{channels}ch_per_gpu"] = (lms, lambda ms, algo=algo: {
