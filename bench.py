@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--channels", type=int, default=CHANNELS, help="channels per GPU (weak scaling)")
     ap.add_argument("--samples", type=int, default=N_SAMPLES)
     ap.add_argument("--algo", type=int, default=0, help="0 auto (overlap-save), 1 time domain, 2 overlap-save, 3 time domain on the matrix cores, 4 / 5 overlap-save with\n"
-                         "2048- / 4096-point transforms")
+                         "2048- / 4096-point transforms, 6 overlap-save with 8192-point transforms on pairs of waves")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--extra", action="store_true", help="(kept for old command lines: the extra configs now run by default)")
     ap.add_argument("--no-also", action="store_true",
@@ -358,7 +358,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": {1: "k_fir_td_f32", 2: ols_kernel_name(channels, n), 3: "k_fir_mfma_bf16x3",
-                                    4: "k_fir_ols2k_chain_f32", 5: "k_fir_ols4k_f32"}[fir_algo],
+                                    4: "k_fir_ols2k_chain_f32", 5: "k_fir_ols4k_f32", 6: "k_fir_ols8k_f32"}[fir_algo],
                          "kernel_ms_avg": kern_ms, "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * channels * n,
                          "memcpy_d2d_GBs": memcpy_gbs,
                          "frac_of_memcpy_d2d": (achieved / memcpy_gbs) if memcpy_gbs else None},
