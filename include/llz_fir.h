@@ -62,14 +62,14 @@ double llz_conv(const double *x, const double *h, int h_len);
 
 enum {
     LLZ_FIR_ALGO_AUTO = 0,       /* time domain up to 32 taps, overlap-save for 33..257 (1024-point), 258..513
-                                  * (2048-point), 514..1025 (4096-point) and 1026..4097 (8192-point), matrix-core time
+                                  * (2048-point), 514..1025 (4096-point) and 1026..6145 (8192-point), matrix-core time
                                   * domain beyond */
     LLZ_FIR_ALGO_TIME = 1,       /* direct form, taps broadcast, input window staged in LDS */
     LLZ_FIR_ALGO_OVERLAP_SAVE = 2, /* 1024-point in-LDS FFT overlap-save, flt_len <= 257 */
     LLZ_FIR_ALGO_TIME_MFMA = 3,   /* direct form as a banded Toeplitz product on the fp32 matrix cores */
     LLZ_FIR_ALGO_OVERLAP_SAVE_2048 = 4, /* 2048-point register-transform overlap-save, 2 <= flt_len <= 1025 */
     LLZ_FIR_ALGO_OVERLAP_SAVE_4096 = 5, /* 4096-point register-transform overlap-save, 2 <= flt_len <= 3073 */
-    LLZ_FIR_ALGO_OVERLAP_SAVE_8192 = 6  /* 8192-point register-transform overlap-save on pairs of waves, 2 <= flt_len <= 4097 */
+    LLZ_FIR_ALGO_OVERLAP_SAVE_8192 = 6  /* 8192-point register-transform overlap-save on pairs of waves, 2 <= flt_len <= 6145 */
 };
 
 /* channels independent filters sharing one tap set. taps: HOST pointer, flt_len floats (double variant

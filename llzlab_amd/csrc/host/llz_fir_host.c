@@ -308,7 +308,7 @@ static int firm_build_ols4k_tables(firm_t *f, const float *taps)
     return rc;
 }
 
-/* 2 .. 4097 taps on pairs of waves (k_fir_ols8k_f32): DFT_8192(taps) / 8192 as eight planes (plane j = bins 8m + j), the
+/* 2 .. 6145 taps on pairs of waves (k_fir_ols8k_f32): DFT_8192(taps) / 8192 as eight planes (plane j = bins 8m + j), the
  * 32 x 32 twiddles of the 1024-point transforms and W_4096^n (the kernel forms W_8192^n itself).  Direct DFT in double. */
 static int firm_build_ols8k_tables(firm_t *f, const float *taps)
 {
@@ -376,7 +376,7 @@ unsigned long llz_fir_filter_mc_init(int channels, int frame_len, const float *t
          * 3072 of overlap */
         else if (flt_len <= 513) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_2048;
         /* 8192 points on pairs of waves, same batch: 9.1 / 10.9 / 10.9 / 11.3 / 13.8 ms with 1536 / 2304 / 2560 / 3072 / 4096 of
-         * overlap -> from 1026 taps on (4096 points: 9.4 / 11.2 / 14.4 / 19.2 ms with 1536 / 2048 / 2560 / 3072), up to 4097 taps */
+         * overlap -> from 1026 taps on (4096 points: 9.4 / 11.2 / 14.4 / 19.2 ms with 1536 / 2048 / 2560 / 3072), up to 6145 taps */
         else if (flt_len <= 1025) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_4096;
         else if (flt_len <= LLZS_OLS8K_MAX_TAPS) algo = LLZ_FIR_ALGO_OVERLAP_SAVE_8192;
         else algo = llzs_fir_mfma_f32_fits(flt_len, 1) ? LLZ_FIR_ALGO_TIME_MFMA : LLZ_FIR_ALGO_TIME;

@@ -2,7 +2,7 @@
 //   k_fir_ols_chain_f32      up to 257 taps   1024-point transforms, a half-wave per job (described first, below)
 //   k_fir_ols2k_chain_f32<O> up to 1025 taps  2048-point transforms, a whole wave per job (one radix-2 step over the half-waves)
 //   k_fir_ols4k_f32<O>       up to 3073 taps  4096-point transforms, a whole wave per job (two radix-2 steps)
-//   k_fir_ols8k_f32<O>       up to 4097 taps  8192-point transforms, a pair of waves per job (one more radix-2 step, across the pair)
+//   k_fir_ols8k_f32<O>       up to 6145 taps  8192-point transforms, a pair of waves per job (one more radix-2 step, across the pair)
 //
 // New functionality relative to the reference (llz_fir.c is time-domain only); its end-to-end
 // oracle is the time-domain llz_fir_filter (llz_fir.c:547-584), its FFT stage follows the sign/scale
@@ -643,7 +643,7 @@ k_fir_ols4k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 2 .. 4097 taps (the library's choice from 2050 on): 8192-point transforms on a PAIR of waves.  With 3072 samples of overlap a 4096-point block yields 1024
+// 2 .. 6145 taps (the library's choice from 1026 on): 8192-point transforms on a PAIR of waves.  With 3072 samples of overlap a 4096-point block yields 1024
 // outputs (25 % of the transform), an 8192-point block 5120 (62.5 %) at 13/12 of the work per point.
 //     X[2k] = FFT_4096( a[n] + a[n+4096] )  -> wave 0 of the pair,     X[2k+1] = FFT_4096( (a[n] - a[n+4096]) W_8192^n )  -> wave 1,
 // each wave then runs the 4096-point problem of k_fir_ols4k_f32 (radix-2 step + two 2048-point problems); back:
@@ -780,7 +780,9 @@ __device__ __forceinline__ void ols4k_core(cf (&a)[64], float *buf, const float2
     }
 }
 
-// O = overlap, a multiple of 64 with flt_len - 1 <= O <= 4096; a job is two blocks = 2 (8192 - O) new samples of one channel
+// O = overlap, a multiple of 64 with flt_len - 1 <= O <= 6144; a job is two blocks = 2 (8192 - O) new samples of one channel
+// (beyond 4096 block B starts in front of the row for the first job: the history serves it too, and rows 64 .. O/64 - 1 of a
+// block are overlap as well)
 template <int O>
 __global__ void __launch_bounds__(O8K_THREADS, 2)
 k_fir_ols8k_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ hist,
@@ -788,7 +790,7 @@ k_fir_ols8k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
                 const float2 *__restrict__ tw4k /* [2048] W_4096^n */, ols_geom G)
 {
     constexpr int V = 8192 - O, JOB = 2 * V, PO = O / 64;
-    static_assert(O % 64 == 0 && O <= 4096, "block B must start inside the row");
+    static_assert(O % 64 == 0 && O <= 6144, "at least 2048 new samples per block");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *s_tw = reinterpret_cast<float2 *>(smem);           // [1024]
     float2 *s_w4 = s_tw + 1024;                                 // [2048]
@@ -870,7 +872,9 @@ k_fir_ols8k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
                     if (ia >= 0) xa = row[min(ia, n - 1)];
                     else if (hrow && ia >= -G.keep) xa = hrow[G.keep + ia];
                     a[j].x = ia < n ? xa : 0.f;
-                    const float xb = row[min(ib, n - 1)];
+                    float xb;
+                    if (O > 4096 && ib < 0) xb = (hrow && ib >= -G.keep) ? hrow[G.keep + ib] : 0.f;
+                    else xb = row[min(ib, n - 1)];
                     a[j].y = ib < n ? xb : 0.f;
                 }
             }
@@ -932,15 +936,19 @@ k_fir_ols8k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
                         __builtin_nontemporal_store(y0.x, &oa0[64 * j]);
                         __builtin_nontemporal_store(y0.y, &oa0[64 * j + V]);
                     }
-                    __builtin_nontemporal_store(y1.x, &oa0[64 * (j + 64)]);
-                    __builtin_nontemporal_store(y1.y, &oa0[64 * (j + 64) + V]);
+                    if (PO <= 64 || j >= jmin - 64) {
+                        __builtin_nontemporal_store(y1.x, &oa0[64 * (j + 64)]);
+                        __builtin_nontemporal_store(y1.y, &oa0[64 * (j + 64) + V]);
+                    }
                 } else {
                     if (j >= jmin) {
                         if (oa < n) orow[oa] = y0.x;
                         if (ob < n) orow[ob] = y0.y;
                     }
-                    if (oa + 4096 < n) orow[oa + 4096] = y1.x;
-                    if (ob + 4096 < n) orow[ob + 4096] = y1.y;
+                    if (PO <= 64 || j >= jmin - 64) {
+                        if (oa + 4096 < n) orow[oa + 4096] = y1.x;
+                        if (ob + 4096 < n) orow[ob + 4096] = y1.y;
+                    }
                 }
             }
             O8K_MARK(5);                                                 // outputs formed, stores issued
@@ -1118,7 +1126,7 @@ extern "C" int llzs_fir_ols4k_f32(const float *in, float *out, const float *hist
 #undef LLZ_OLS4K_GO
 }
 
-// 2 .. 4097 taps on 8192-point transforms (k_fir_ols8k_f32: a pair of waves per job; overlap 1536 / 2048 / ... / 4096 by tap
+// 2 .. 6145 taps on 8192-point transforms (k_fir_ols8k_f32: a pair of waves per job; overlap 1536 / 2304 / ... / 6144 by tap
 // count): hfreq8 = [8][1024] complex, plane j = bins 8m + j of DFT_8192(taps) / 8192; twid [32][32] W_1024^(ab); tw4k [2048] W_4096^n
 template <int O>
 static int ols8k_launch(const float *in, float *out, const float *hist, const float *hfreq8, const float *twid,
@@ -1174,7 +1182,9 @@ extern "C" int llzs_fir_ols8k_f32(const float *in, float *out, const float *hist
     if (flt_len <= 2561) LLZ_OLS8K_GO(2560);
     if (flt_len <= 3073) LLZ_OLS8K_GO(3072);
     if (flt_len <= 3585) LLZ_OLS8K_GO(3584);
-    LLZ_OLS8K_GO(4096);
+    if (flt_len <= 4097) LLZ_OLS8K_GO(4096);
+    if (flt_len <= 5121) LLZ_OLS8K_GO(5120);
+    LLZ_OLS8K_GO(6144);
 #undef LLZ_OLS8K_GO
 }
 

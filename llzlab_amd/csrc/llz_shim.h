@@ -114,11 +114,11 @@ int llzs_fir_ols4k_f32(const float *in, float *out, const float *hist, const flo
                        const float *tw2k, const float *tw4k, int channels, int n, long in_pitch, long out_pitch, int flt_len,
                        void *stream);
 #define LLZS_OLS4K_MAX_TAPS 3073
-/* 8192-point transforms on a pair of waves (fir_ols.hip: radix-2 step across the pair + the 4096-point problem per wave), 2..4097
- * taps (overlap 1536 ... 4096 by tap count): hfreq8 [8][1024] complex = bins 8m + j of DFT_8192(taps) / 8192; twid, tw4k as above */
+/* 8192-point transforms on a pair of waves (fir_ols.hip: radix-2 step across the pair + the 4096-point problem per wave), 2..6145
+ * taps (overlap 1536 ... 6144 by tap count): hfreq8 [8][1024] complex = bins 8m + j of DFT_8192(taps) / 8192; twid, tw4k as above */
 int llzs_fir_ols8k_f32(const float *in, float *out, const float *hist, const float *hfreq8, const float *twid,
                        const float *tw4k, int channels, int n, long in_pitch, long out_pitch, int flt_len, void *stream);
-#define LLZS_OLS8K_MAX_TAPS 4097
+#define LLZS_OLS8K_MAX_TAPS 6145
 /* time domain on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), with optional decimation:
  * y[c][i] = gain * sum_{k<T} taps[k] * x[c][i*M - k], x[c][<0] = hist[c][T-1+idx] (hist NULL = zeros); n_out outputs
  * per channel from n_in inputs, (n_out-1)*M < n_in.  taps: T floats (no padding needed). */

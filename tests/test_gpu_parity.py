@@ -151,8 +151,9 @@ def test_fir_mc_host_pointers_and_errors(dev, oracle):
     assert filters.FirFilterMC(2, 64, np.ones(32)).algo == filters.FIR_ALGO_TIME
     assert filters.FirFilterMC(2, 64, np.ones(300)).algo == filters.FIR_ALGO_OVERLAP_SAVE_2048   # 258..513
     assert filters.FirFilterMC(2, 64, np.ones(1000)).algo == filters.FIR_ALGO_OVERLAP_SAVE_4096  # 514..1025
-    assert filters.FirFilterMC(2, 64, np.ones(3000)).algo == filters.FIR_ALGO_OVERLAP_SAVE_8192  # 1026..4097
-    assert filters.FirFilterMC(2, 64, np.ones(4098)).algo in (filters.FIR_ALGO_TIME_MFMA, filters.FIR_ALGO_TIME)   # time domain beyond
+    assert filters.FirFilterMC(2, 64, np.ones(3000)).algo == filters.FIR_ALGO_OVERLAP_SAVE_8192  # 1026..6145
+    assert filters.FirFilterMC(2, 64, np.ones(6145)).algo == filters.FIR_ALGO_OVERLAP_SAVE_8192
+    assert filters.FirFilterMC(2, 64, np.ones(6146)).algo in (filters.FIR_ALGO_TIME_MFMA, filters.FIR_ALGO_TIME)   # time domain beyond
     assert filters.FirFilterMC(2, 64, np.ones(300), algo=filters.FIR_ALGO_TIME_MFMA).algo == filters.FIR_ALGO_TIME_MFMA
 
 
@@ -1171,10 +1172,12 @@ def test_fir_ols4096_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
                                                (1537, 4, 13312 * 2 + 1), (4097, 2, 8192 * 3 + 9), (3585, 9, 9216 * 4), (3000, 300, 10240 * 3),
                                                (2, 3, 20000), (1000, 7, 5000), (4097, 33, 8192 * 5 + 4000), (3073, 1100, 10240 * 2 + 17),
                                                # frames shorter than the overlap (the history supplies most of a block), one channel
-                                               (3073, 3, 1700), (2100, 1, 5000), (4097, 2, 2500)])
+                                               (3073, 3, 1700), (2100, 1, 5000), (4097, 2, 2500),
+                                               # more overlap than new samples: block B starts in the history too, rows 64.. are overlap
+                                               (6145, 2, 4096 * 3 + 50), (5000, 40, 6144 * 2), (5121, 3, 3000), (6145, 1, 2000)])
 def test_fir_ols8192_vs_oracle_streaming(dev, oracle, taps_n, channels, n):
-    """filters of up to 4097 taps on the 8192-point overlap-save (k_fir_ols8k_f32: a PAIR of waves per pair of blocks, the halves
-    of the radix-2 step swapped through LDS under the pair's own round counters; overlap 1536 ... 4096 by tap count): two frames
+    """filters of up to 6145 taps on the 8192-point overlap-save (k_fir_ols8k_f32: a PAIR of waves per pair of blocks, the halves
+    of the radix-2 step swapped through LDS under the pair's own round counters; overlap 1536 ... 6144 by tap count): two frames
     (the second starts from the first's history), ragged lengths, blocks that end past the frame, more pairs of waves than
     segments and fewer.  Large batches are checked on a spread of 24 channels (the oracle is one core)."""
     taps = oracle.fir_design(po.LPF, taps_n, 0.2, 0.0, po.KAISER)
