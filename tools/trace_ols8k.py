@@ -26,12 +26,14 @@ count = 2048
 buf = np.zeros(count * 8, dtype=np.uint64)
 Lb.llzs_o8k_trace_read(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(count * 8))
 t = buf.reshape(count, 8).astype(np.float64)
+role = (np.arange(count) % 8) >> 2            # the pair = waves p and p + 4 of a workgroup: wave 0 of the pair is p
+role = role[t[:, 7] > 0]
 t = t[t[:, 7] > 0]
 jobs = t[:, 7]
 names = ("requests awaited", "step down", "swap", "4096-point problem", "swap + turn", "outputs, stores issued", "loop")
-print(f"{T} taps: {len(t)} waves, {jobs.mean():.1f} jobs each; shader clocks (100 MHz counter x clock ratio) per job")
+print(f"{T} taps: {len(t)} waves, {jobs.mean():.1f} jobs each; shader clocks (s_memtime) per job")
 for par, nm in ((0, "waves 0 of the pairs"), (1, "waves 1 of the pairs")):
-    sel = t[par::2]
+    sel = t[role == par]
     print(f" {nm}")
     for i, name in enumerate(names):
         print(f"  {name:28s} {(sel[:, i] / sel[:, 7]).mean():9.0f}")
