@@ -652,12 +652,16 @@ k_fir_ols4k_f32(const float *__restrict__ in, float *__restrict__ out, const flo
 // same + 64 of both blocks (64 complex values per lane, as the 4096-point kernel), forms its 32 sums and 32 twiddled
 // differences, and the two waves SWAP halves through LDS: wave 0 gives its differences for wave 1's sums.  On the way back
 // wave 1 twiddles its results, the waves swap halves again and each forms and stores the outputs among "its" 64 positions.
-// W_8192^(64 i + lane) = W_128^i (a literal after unrolling) x W_8192^lane (two registers): no table.
+// W_8192^(64 i + lane) = W_128^i (a literal after unrolling) x W_8192^lane (a 512-byte LDS table, read where it is used): no
+// 32 KB table, and nothing lane-derived is carried across the 4096-point problem (o8k_lane()).
+// Wave 1 keeps the two halves of its register array exchanged (slot j = position j + 32 mod 64), so that both waves keep slots
+// 0..31 and swap slots 32..63 through one code path; the 4096-point problem is indifferent to it.
 //
 // The swap goes through the transpose buffers the two waves own anyway (8.25 KB per wave: two rounds of 16 values per lane),
 // and the pair synchronises on four LDS words of its own instead of a workgroup barrier, so that the four pairs of a workgroup
 // drift apart and one pair's memory wait is another's arithmetic -- a barrier would hold all eight waves in the same phase
-// (64 complex values per lane leave no registers for a prefetch).  Both waves of a pair run the same loop bounds, hence the
+// (64 complex values per lane leave no registers for a prefetch).  The pair is the two waves of ONE SIMD (waves p, p + 4): a
+// wave that waits for its partner leaves the SIMD to exactly that partner.  Both waves of a pair run the same loop bounds, hence the
 // same number of rounds; the waits are bounded (a pair out of step would produce wrong samples, which the tests see, never
 // a hang).  LDS: W_1024^(ab) 8 KB, W_4096^n 16 KB (W_2048^n = every other entry), spectrum 8 x 8 KB, buffers 66 KB = 154 KB.
 // O8K_TRACE (a measurement build only): shader-clock time of each phase of a job, summed per wave (tools/trace_ols8k.py)
