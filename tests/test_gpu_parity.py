@@ -184,6 +184,45 @@ def test_fir_linearity_and_impulse_large(dev):
     assert float((ys[2] - (0.5 * ys[0] + ys[1])).pow(2).mean().sqrt()) < 1e-6
 
 
+def test_fir_long_filter_full_size_impulse_and_linearity(dev):
+    """the 3073-tap filter on the headline batch (4096 ch x 2^20: every pair of waves walks many segments of 16 jobs through
+    k_fir_ols8k_f32), by properties that need no oracle: an impulse per channel, at a position that moves with the channel,
+    returns the taps there and nothing elsewhere; filter(a x1 + x2) = a filter(x1) + filter(x2)"""
+    T = 3073
+    taps = filters.fir_design("lpf", T, 0.1, 0.0, po.KAISER)
+    ch, n = 4096, 1 << 20
+    f = filters.FirFilterMC(ch, n, taps)
+    assert f.algo == filters.FIR_ALGO_OVERLAP_SAVE_8192
+    x = torch.zeros(ch, n, dtype=torch.float32, device=dev)
+    pos = (torch.arange(ch, device=dev) * 251) % (n - T)                      # spread over jobs, rows and block halves
+    x[torch.arange(ch, device=dev), pos] = 1.0
+    y = torch.empty_like(x)
+    f.filter(x, y)
+    idx = pos[:, None] + torch.arange(T, device=dev)[None, :]
+    got = torch.gather(y, 1, idx)
+    t32 = torch.from_numpy(taps.astype(np.float32)).to(dev)
+    assert float((got - t32[None, :]).abs().max()) < 3e-7
+    y.scatter_(1, idx, 0.0)                                                   # what is left is everything outside the responses
+    assert float(y.abs().max()) < 1e-6
+    del idx, got
+    x2 = torch.empty_like(x)
+    filters.synth_f32(x, seed=1)
+    filters.synth_f32(x2, seed=2)
+    y2 = torch.empty_like(x)
+    f.close()
+    outs = []
+    for xi in (x, x2):
+        g = filters.FirFilterMC(ch, n, taps)
+        g.filter(xi, y if xi is x else y2)
+        g.close()
+    x.mul_(0.5).add_(x2)
+    g = filters.FirFilterMC(ch, n, taps)
+    g.filter(x, x2)                                                           # x2 <- filter(0.5 x1 + x2)
+    g.close()
+    y.mul_(0.5).add_(y2)
+    assert float((x2 - y).pow(2).mean().sqrt()) < 1e-6
+
+
 # ------------------------------------------------------------------------------------------------ IIR
 def test_iir_single_channel_exact_vs_golden(dev):
     d = load("iir.npz")
